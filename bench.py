@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- NCA cell-updates/s on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One bench "step" = one pass of the hot path over one batch: ConditionedNCA.grow's loop
+(EncoderConditioning/nca.py:207-208) of T=64 fused NCA steps + finalize on BASELINE configs[1]
+(B=8, C=16, 256x256, fp32, forward) per GPU, state / goal encoding / weights resident in HBM,
+fire mask drawn in-kernel (Philox).  value = N*B*H*W*T*K / t, t = max over ranks of the barrier-
+bracketed wall time of the K steps.  Each rank owns an independent shard of the sample pool
+(weak scaling, no data-path collective -- SURVEY.md 8e).
+
+Extra objects on the JSON line:
+  roofline          fused step kernel (dominant): exact-f32 MFMA bound, algorithmic flops/launch over
+                    the HIP-event launch time (events on the launch stream).
+  roofline_stencil  standalone DyNCA perception stencil: HBM bound, 20*C bytes/cell.
+  cpu_baseline      the CPU oracle (pure-PyTorch restatement == the reference's CPU path, bit-identical)
+                    timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "video-stylization-with-nca_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+B, C, H, W, T = 8, 16, 256, 256, 64         # BASELINE configs[1]
+HIDDEN, GOAL_CH, ALIVE_CH = 64, 12, 3
+FLOPS_PER_CELL = 2 * (27 * C + 3 * C * HIDDEN + HIDDEN * HIDDEN + HIDDEN * C)   # 17 248
+BYTES_PER_CELL_STEP = 2 * C * 4 + GOAL_CH * 4 + 2                               # x in/out + goal + pre masks
+STENCIL_BYTES_PER_CELL = 20 * C                                                 # read C, write 4C floats
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0
+
+
+def make_weights(gen):
+    return {"perception_net.weight": torch.randn(3 * C, 1, 3, 3, generator=gen) * 0.3,
+            "update_net.out.0.weight": torch.randn(HIDDEN, 3 * C, 1, 1, generator=gen) / (3 * C) ** 0.5,
+            "update_net.out.0.bias": torch.randn(HIDDEN, generator=gen) * 0.1,
+            "update_net.out.2.weight": torch.randn(HIDDEN, HIDDEN, 1, 1, generator=gen) / HIDDEN ** 0.5,
+            "update_net.out.2.bias": torch.randn(HIDDEN, generator=gen) * 0.1,
+            "update_net.out.4.weight": torch.randn(C, HIDDEN, 1, 1, generator=gen) * (0.1 / HIDDEN ** 0.5)}
+
+
+def event_ms(fn, iters):
+    """Average device time of fn() over `iters` back-to-back calls, HIP events on the launch stream."""
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    e0.record(st)
+    for _ in range(iters):
+        fn()
+    e1.record(st)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def cpu_baseline(prm, x0, goal):
+    """Oracle (kind 'port': the reference's PyTorch CPU op sequence) on a bounded sample."""
+    from oracle import nca_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gpad = O.cond_pad_goal(goal, C)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.cond_grow_rng(x0, gpad, 1, prm, ALIVE_CH)          # warm-up + estimate
+        est = time.perf_counter() - t0
+        steps = int(min(T, max(2, round(12.0 / max(est, 1e-3)))))
+        t0 = time.perf_counter()
+        O.cond_grow_rng(x0, gpad, steps, prm, ALIVE_CH)
+        dt = time.perf_counter() - t0
+    return {"value": B * H * W * steps / dt, "unit": "cell-updates/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"oracle cond_grow, same (B={B},C={C},{H}x{W}) grid, {steps} of {T} NCA steps, "
+                                      f"{dt:.1f}s, torch CPU fp32, {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ncahip import ops
+    ops.selftest(dev)
+
+    gen = torch.Generator().manual_seed(0)
+    prm = make_weights(gen)
+    dgen = torch.Generator().manual_seed(1234 + rank)       # each rank: its own pool shard
+    x0 = torch.rand(B, C, H, W, generator=dgen)
+    goal = torch.randn(B, GOAL_CH, H, W, generator=dgen) * 0.5
+    xd, gd = x0.to(dev), goal.to(dev)
+    w = ops.CondWeights(prm["perception_net.weight"], prm["update_net.out.0.weight"], prm["update_net.out.0.bias"],
+                        prm["update_net.out.2.weight"], prm["update_net.out.2.bias"], prm["update_net.out.4.weight"], xd)
+
+    # preallocated ring buffers; one bench step == ncahip_cond_grow_fwd_f32 (T launches + finalize)
+    states = torch.empty(2, B, C, H, W, device=dev)
+    pre = torch.empty(2, B, H, W, device=dev, dtype=torch.uint8)
+    out = torch.empty_like(xd)
+    states[0].copy_(xd)
+    L, st = ops.lib(), torch.cuda.current_stream().cuda_stream
+    step_no = [0]
+
+    def one_step():
+        ops.check(L.ncahip_cond_grow_fwd_f32(states.data_ptr(), pre.data_ptr(), 2, T, out.data_ptr(), gd.data_ptr(),
+                                             GOAL_CH, None, w.wp.data_ptr(), w.w1.data_ptr(), w.b1.data_ptr(),
+                                             w.w2.data_ptr(), w.b2.data_ptr(), w.w3.data_ptr(), B, C, H, W, HIDDEN,
+                                             ALIVE_CH, 0.1, 0.5, -10.0, 10.0, 42, step_no[0], st), "cond_grow")
+        step_no[0] += T
+        states[0].copy_(out)          # the pool write-back: next pass continues from this state
+
+    def barrier():
+        if dist_on:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    alive_frac = float(ops.cond_alive(out, ALIVE_CH).float().mean())
+
+    result = None
+    if rank == 0:
+        value = world * B * H * W * T * args.steps / dt
+        # ---- roofline of the dominant kernel: step launches only, events on the launch stream
+        xa, xb = states[0], states[1]
+
+        def step_pair():
+            for (i, o, pi) in ((xa, xb, None), (xb, xa, pre[1])):
+                ops.check(L.ncahip_cond_step_fwd_f32(i.data_ptr(), None if pi is None else pi.data_ptr(), o.data_ptr(),
+                                                     (pre[1] if pi is None else pre[0]).data_ptr(), gd.data_ptr(), GOAL_CH,
+                                                     None, w.wp.data_ptr(), w.w1.data_ptr(), w.b1.data_ptr(), w.w2.data_ptr(),
+                                                     w.b2.data_ptr(), w.w3.data_ptr(), B, C, H, W, HIDDEN, ALIVE_CH, 0.1, 0.5,
+                                                     -10.0, 10.0, 42, 0, st), "cond_step")
+        ms_launch = event_ms(step_pair, 100) / 2
+        cells = B * H * W
+        tflops = cells * FLOPS_PER_CELL / (ms_launch * 1e-3) / 1e12
+        # ---- HBM-bound stencil
+        y = torch.empty(B, 4 * C, H, W, device=dev)
+        ms_st = event_ms(lambda: ops.check(L.ncahip_dynca_perceive_f32(xd.data_ptr(), y.data_ptr(), B, C, H, W, 1, st), "perceive"), 200)
+        gbs = cells * STENCIL_BYTES_PER_CELL / (ms_st * 1e-3) / 1e9
+        result = {
+            "metric": "NCA cell-updates/sec (B*H*W*steps/s) at 256^2 C=16", "value": value, "unit": "cell-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: ConditionedNCA grow loop, B=8 C=16 256x256, 64 NCA steps per bench step, fp32 forward",
+                       "B_per_gpu": B, "C": C, "H": H, "W": W, "nca_steps_per_bench_step": T, "hidden": HIDDEN,
+                       "mask_rng": "in-kernel philox4x32-10", "alive_fraction_at_end": round(alive_frac, 4),
+                       "parallelism": f"pool-shard x{world} (no data-path collective)"},
+            "roofline": {"kernel": "cond_step_fwd_kernel<16,8,32,4>", "bound": "mfma", "achieved": tflops,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None, "launch_ms": ms_launch, "flops_per_cell": FLOPS_PER_CELL,
+                         "algorithmic_bytes_per_cell": BYTES_PER_CELL_STEP, "cells_per_launch": cells},
+            "roofline_stencil": {"kernel": "dynca_perceive_kernel<vec4>", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
+                                 "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None, "launch_ms": ms_st,
+                                 "bytes_per_cell": STENCIL_BYTES_PER_CELL, "cells_per_launch": cells,
+                                 "cells_per_s": cells / (ms_st * 1e-3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(prm, x0, goal)
+            result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+        print(json.dumps(result), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+/* ncahip.h -- C ABI of libncahip.so: the MI355X (gfx950) NCA step hot path.
+ *
+ * The reference (smehra34/Video-Stylization-with-NCA) is 100 % Python/PyTorch and has no FFI
+ * layer; its "plugin surface" for this path is the Python class API.  This header
+ * is the boundary a maintainer binds with ctypes from those classes (INTEGRATION.md shows the
+ * stub).  Every entry point names the reference code it replaces (file:line in the reference).
+ *
+ * Conventions (all functions):
+ *   - plain C types only; every pointer is a DEVICE pointer (tensor.data_ptr()), contiguous NCHW;
+ *   - the caller owns every buffer, nothing is allocated, freed or retained across calls;
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t; NULL = default stream), the
+ *     call never synchronises and is safe from several host threads on distinct streams;
+ *   - return 0 on success, a negative NCAHIP_E* on an argument error (nothing was launched),
+ *     or a positive hipError_t if the launch failed; ncahip_last_error() describes the last
+ *     failure of the calling thread.
+ *   - in/out buffers of one call must not alias unless stated.
+ */
+#ifndef NCAHIP_H
+#define NCAHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NCAHIP_VERSION 100 /* major*10000 + minor*100 + patch : 0.1.0 */
+
+/* argument errors */
+#define NCAHIP_EINVAL (-1)   /* null pointer / non-positive size / bad enum            */
+#define NCAHIP_ERANGE (-2)   /* shape outside what the kernels are instantiated for     */
+
+/* F.pad modes used by DyNCA perception (ConditioneDyNCA/models/dynca.py:85, default :31) */
+#define NCAHIP_PAD_ZERO      0   /* 'constant'  */
+#define NCAHIP_PAD_REPLICATE 1
+#define NCAHIP_PAD_CIRCULAR  2
+#define NCAHIP_PAD_REFLECT   3
+
+typedef void *ncahip_stream_t;   /* hipStream_t */
+
+int ncahip_version(void);
+const char *ncahip_last_error(void);
+
+/* Largest shapes the fused step kernels accept (C <= max_c, fc <= max_fc, hidden <= 64). */
+int ncahip_limits(int *max_c, int *max_fc, int *max_hidden);
+
+/* Device-side check that the MFMA operand/accumulator lane maps the kernels assume hold on
+ * this GPU (exact integer data, asymmetric B).  `scratch` >= 4096 bytes of device memory;
+ * returns 0 and writes 1 to ((int*)scratch)[0] when the maps hold.  Synchronises `stream`. */
+int ncahip_selftest(void *scratch, ncahip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Standalone perception stencils (HBM-bound; the kernels the HBM roofline is measured on)
+ * ---------------------------------------------------------------------------------------- */
+
+/* DyNCA.perceive_torch(x, scale=0)          ConditioneDyNCA/models/dynca.py:75-100
+ *   y[B,4C,H,W] = [ x | Sx*x | Sy*x | L*x ]  fixed filters :67-73, F.pad mode `pad_mode`.    */
+int ncahip_dynca_perceive_f32(const float *x, float *y, int B, int C, int H, int W,
+                              int pad_mode, ncahip_stream_t stream);
+
+/* ConditionedNCA.perception_net(z)          EncoderConditioning/nca.py:99-107,177
+ *   y[B,3C,H,W], y[3c+k] = wp[3c+k] (3x3, zero pad) * z[c];  wp = perception_net.weight [3C,1,3,3]. */
+int ncahip_cond_perceive_f32(const float *z, const float *wp, float *y, int B, int C, int H, int W,
+                             ncahip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DyNCA fused step                          ConditioneDyNCA/models/dynca.py:117-138
+ *   (ExtraChannels/models/dynca.py:113-128 is the same step with c_cond = 2 or 0)
+ *   x_out = x_in + (w2 relu(w1 [perc(x_in) | cond] + b1) + b2) * floor(u + update_rate)
+ *   x_in,x_out [B,C,H,W]; cond [B,c_cond,H,W] = already-extracted conditioning (EdgeExtractor
+ *   :204-213 or CPE2D :226-253 output; NULL iff c_cond == 0); u [B,1,H,W] = the torch.rand draw
+ *   of :131, or NULL to draw it in-kernel (Philox4x32-10 keyed (seed, step, cell)).
+ *   w1 [fc, 4C+c_cond], b1 [fc], w2 [C, fc], b2 [C]  (reference layouts, 1x1 dims squeezed).
+ * ---------------------------------------------------------------------------------------- */
+int ncahip_dynca_step_fwd_f32(const float *x_in, float *x_out, const float *cond, const float *u,
+                              const float *w1, const float *b1, const float *w2, const float *b2,
+                              int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                              float update_rate, uint64_t seed, uint64_t step,
+                              ncahip_stream_t stream);
+
+/* DyNCA.forward_nsteps                      ConditioneDyNCA/models/dynca.py:168-178
+ *   `states` holds `ring` slots of B*C*H*W floats; slot 0 is the input state, step t reads slot
+ *   t % ring and writes slot (t+1) % ring.  ring = 2: ping-pong (inference); ring = T+1: every
+ *   state is kept (what the backward pass re-reads).  u: [T,B,1,H,W] or NULL (Philox, step0+t). */
+int ncahip_dynca_nsteps_fwd_f32(float *states, int ring, int T, const float *cond, const float *u,
+                                const float *w1, const float *b1, const float *w2, const float *b2,
+                                int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                                float update_rate, uint64_t seed, uint64_t step0,
+                                ncahip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ConditionedNCA fused step                 EncoderConditioning/nca.py:181-195
+ *
+ * The step's post-life mask (:191-193) needs the NEW alpha on a 3x3 neighbourhood, i.e. a
+ * grid-wide exchange after the update.  The kernel therefore emits the state in PENDING form:
+ *     x_out   = x + rand_mask * update(x)                 (:189, before :191-194)
+ *     pre_out = alive(x)                                  (:185, uint8 [B,H,W])
+ * and the NEXT step (or ncahip_cond_finalize_f32) resolves
+ *     x'' = clamp(x_out * (pre_out & alive(x_out)), lo, hi)   (:191-194)
+ * while it loads its tile (alpha halo of 3 cells).  Pass pre_in = NULL when x_in is a true
+ * state (first step), or the previous call's pre_out when x_in is pending.
+ *
+ *   goal  [B,goal_ch,H,W] = encoder(goal) UNPADDED (nca.py:198); it is added to the LAST
+ *         goal_ch channels (:199-203 pads zeros in front).  goal_ch may equal C.
+ *   u     [B,1,H,W] rand_like draw (:172) or NULL (in-kernel Philox); mask = u < fire_rate.
+ *   wp [3C,9]; w1 [hidden,3C], b1 [hidden]; w2 [hidden,hidden], b2 [hidden]; w3 [C,hidden].
+ *   alive_ch < 0  <=>  use_living_channel=False (:153-154): every cell alive.
+ * ---------------------------------------------------------------------------------------- */
+int ncahip_cond_step_fwd_f32(const float *x_in, const uint8_t *pre_in, float *x_out, uint8_t *pre_out,
+                             const float *goal, int goal_ch, const float *u,
+                             const float *wp, const float *w1, const float *b1,
+                             const float *w2, const float *b2, const float *w3,
+                             int B, int C, int H, int W, int hidden,
+                             int alive_ch, float alive_thr, float fire_rate,
+                             float clamp_lo, float clamp_hi, uint64_t seed, uint64_t step,
+                             ncahip_stream_t stream);
+
+/* Resolve a pending state: x_out = clamp(x_pend * (pre & alive(x_pend)), lo, hi)  nca.py:191-194.
+ * x_out may alias x_pend only if alive_ch < 0.                                              */
+int ncahip_cond_finalize_f32(const float *x_pend, const uint8_t *pre, float *x_out,
+                             int B, int C, int H, int W, int alive_ch, float alive_thr,
+                             float clamp_lo, float clamp_hi, ncahip_stream_t stream);
+
+/* ConditionedNCA.alive(x)                   EncoderConditioning/nca.py:152-163 -> uint8 [B,H,W] */
+int ncahip_cond_alive_u8(const float *x, uint8_t *out, int B, int C, int H, int W,
+                         int alive_ch, float alive_thr, ncahip_stream_t stream);
+
+/* ConditionedNCA.grow's loop                EncoderConditioning/nca.py:207-208
+ *   T fused steps + one finalize.  states: `ring` slots of B*C*H*W floats, slot 0 = input (true
+ *   state); slot k (k>=1) receives the PENDING output of step k-1; pre: `ring` slots of B*H*W
+ *   bytes, slot k pairs with states slot k (slot 0 unused).  x_final receives grow()'s result.
+ *   ring = 2 ping-pong, ring = T+1 keeps every pending state for the backward pass.          */
+int ncahip_cond_grow_fwd_f32(float *states, uint8_t *pre, int ring, int T, float *x_final,
+                             const float *goal, int goal_ch, const float *u,
+                             const float *wp, const float *w1, const float *b1,
+                             const float *w2, const float *b2, const float *w3,
+                             int B, int C, int H, int W, int hidden,
+                             int alive_ch, float alive_thr, float fire_rate,
+                             float clamp_lo, float clamp_hi, uint64_t seed, uint64_t step0,
+                             ncahip_stream_t stream);
+
+/* The [B,1,H,W] uniforms the kernels draw for (seed, step) when u == NULL (for tests/tools). */
+int ncahip_philox_uniform_f32(float *u, int B, int H, int W, uint64_t seed, uint64_t step,
+                              ncahip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NCAHIP_H */

@@ -1,0 +1,74 @@
+"""CPU-side checks of the drop-in boundary: libncahip.so loads and exports exactly what
+include/ncahip.h declares, the ctypes table matches the header's arity, argument validation
+rejects bad shapes without launching (no GPU needed: validation happens before any HIP call)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ncahip.h")
+
+
+def header_prototypes():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|const char \*)\s*(ncahip_\w+)\s*\(([^)]*)\)\s*;", src):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args == "void" else len([a for a in args.split(",") if a.strip()])
+    return protos
+
+
+def test_header_declares_the_path():
+    p = header_prototypes()
+    for name in ("ncahip_dynca_perceive_f32", "ncahip_dynca_step_fwd_f32", "ncahip_dynca_nsteps_fwd_f32",
+                 "ncahip_cond_step_fwd_f32", "ncahip_cond_finalize_f32", "ncahip_cond_grow_fwd_f32",
+                 "ncahip_cond_alive_u8", "ncahip_cond_perceive_f32", "ncahip_version", "ncahip_last_error"):
+        assert name in p, name
+
+
+def test_library_exports_every_declared_symbol():
+    from ncahip import _capi
+    if not os.path.exists(_capi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    L = ctypes.CDLL(_capi.LIB_PATH)
+    protos = header_prototypes()
+    for name, nargs in protos.items():
+        assert hasattr(L, name), f"{name} declared in ncahip.h but not exported"
+        assert name in _capi.SIGNATURES, f"{name} missing from the ctypes table"
+        assert len(_capi.SIGNATURES[name]) == nargs, (name, len(_capi.SIGNATURES[name]), nargs)
+    assert set(_capi.SIGNATURES) == set(protos)
+    assert _capi.version() == 100
+    assert _capi.limits()[0] >= 16
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are refused on the host before any launch (negative codes, message set)."""
+    from ncahip import _capi
+    L = _capi.lib()
+    one = ctypes.c_void_p(0x1000)  # never dereferenced: validation fails first
+    rc = L.ncahip_dynca_perceive_f32(None, one, 1, 4, 8, 8, 1, None)
+    assert rc == -1 and b"null" in L.ncahip_last_error()
+    rc = L.ncahip_dynca_perceive_f32(one, ctypes.c_void_p(0x2000), 1, 4, 8, 8, 7, None)
+    assert rc == -1
+    rc = L.ncahip_dynca_step_fwd_f32(one, ctypes.c_void_p(0x2000), None, None, one, one, one, one,
+                                     1, 64, 8, 8, 96, 0, 1, 0.5, 0, 0, None)
+    assert rc == -2 and b"exceeds" in L.ncahip_last_error()  # C=64 outside the instantiated range
+    rc = L.ncahip_dynca_step_fwd_f32(one, one, None, None, one, one, one, one, 1, 12, 8, 8, 96, 0, 1, 0.5, 0, 0, None)
+    assert rc == -1 and b"alias" in L.ncahip_last_error()
+    rc = L.ncahip_cond_step_fwd_f32(one, None, ctypes.c_void_p(0x2000), one, None, 3, None, one, one, one, one, one,
+                                    one, 1, 12, 8, 8, 64, 3, 0.1, 0.5, -10.0, 10.0, 0, 0, None)
+    assert rc == -1 and b"goal" in L.ncahip_last_error()
+    with pytest.raises(_capi.NcaHipError):
+        _capi.check(rc, "cond_step")
+
+
+def test_hot_path_refuses_cpu_tensors():
+    """No CPU fallback: the op wrappers fail loudly for non-CUDA tensors."""
+    import torch
+    from ncahip import ops, _capi
+    with pytest.raises(_capi.NcaHipError):
+        ops.dynca_perceive(torch.zeros(1, 4, 8, 8))

@@ -1,0 +1,321 @@
+"""Parity tests proper: the HIP path, called through the C ABI (ctypes), against the CPU oracle
+and the golden vectors captured from the reference.  Tolerance: 1e-4 relative fp32 (north_star)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nca_oracle as O
+from util import REL_TOL, T, load, rel_err, sd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from ncahip import ops as _ops
+    _ops.selftest()
+    return _ops
+
+
+def dyn_w(ops, prm, like):
+    return ops.DyncaWeights(prm["w1.weight"], prm["w1.bias"], prm["w2.weight"], prm["w2.bias"], like)
+
+
+def cond_w(ops, prm, like):
+    return ops.CondWeights(prm["perception_net.weight"], prm["update_net.out.0.weight"], prm["update_net.out.0.bias"],
+                           prm["update_net.out.2.weight"], prm["update_net.out.2.bias"],
+                           prm["update_net.out.4.weight"], like)
+
+
+def rand_dynca_prm(C, fc, c_cond, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    k1 = 4 * C + c_cond
+    return {"w1.weight": torch.randn(fc, k1, 1, 1, generator=g) * (0.5 / k1 ** 0.5),
+            "w1.bias": torch.randn(fc, generator=g) * 0.1,
+            "w2.weight": torch.randn(C, fc, 1, 1, generator=g) * (scale * 0.3 / fc ** 0.5),
+            "w2.bias": torch.randn(C, generator=g) * 0.02}
+
+
+def rand_cond_prm(C, seed, hidden=64, out_scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return {"perception_net.weight": torch.randn(3 * C, 1, 3, 3, generator=g) * 0.3,
+            "update_net.out.0.weight": torch.randn(hidden, 3 * C, 1, 1, generator=g) * (1.0 / (3 * C) ** 0.5),
+            "update_net.out.0.bias": torch.randn(hidden, generator=g) * 0.1,
+            "update_net.out.2.weight": torch.randn(hidden, hidden, 1, 1, generator=g) * (1.0 / hidden ** 0.5),
+            "update_net.out.2.bias": torch.randn(hidden, generator=g) * 0.1,
+            "update_net.out.4.weight": torch.randn(C, hidden, 1, 1, generator=g) * (out_scale * 0.3 / hidden ** 0.5)}
+
+
+# ------------------------------------------------------------------ basics
+def test_philox_matches_oracle_bit_exact(ops):
+    for (B, H, W, seed, step) in ((2, 8, 8, 42, 3), (3, 13, 37, 2 ** 40 + 17, 2 ** 33 + 5), (1, 256, 256, 0, 0)):
+        u = ops.philox_uniform(B, H, W, seed, step).cpu().numpy()
+        assert np.array_equal(u, O.philox_uniform(seed, step, B, H, W))
+
+
+@pytest.mark.parametrize("pad", O.PAD_MODES)
+@pytest.mark.parametrize("shape", [(2, 12, 12, 16), (1, 16, 64, 64), (3, 5, 13, 37), (1, 3, 2, 2), (2, 4, 1, 8), (1, 2, 9, 1)])
+def test_dynca_perceive(ops, pad, shape):
+    B, C, H, W = shape
+    if pad == "reflect" and (H < 2 or W < 2):
+        pytest.skip("F.pad reflect needs >= 2 cells")
+    x = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(B * 1000 + W))
+    ref = O.dynca_perceive(x, pad)
+    got = ops.dynca_perceive(x.to(DEV), pad)
+    assert got.shape == ref.shape and rel_err(got, ref) < 1e-5
+
+
+def test_dynca_perceive_golden_known_answers(ops):
+    g = load("g4_perception")
+    for pad in O.PAD_MODES:
+        for name in ("ramp", "imp"):
+            got = ops.dynca_perceive(T(g[name], DEV), pad).cpu().numpy()
+            assert np.array_equal(got, g[f"{name}.{pad}"]), (name, pad)  # small integers: exact
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 32, 32), (1, 16, 16, 64), (2, 5, 7, 9), (1, 3, 1, 1)])
+def test_cond_perceive(ops, shape):
+    B, C, H, W = shape
+    gen = torch.Generator().manual_seed(C)
+    z, wp = torch.randn(B, C, H, W, generator=gen), torch.randn(3 * C, 1, 3, 3, generator=gen)
+    assert rel_err(ops.cond_perceive(z.to(DEV), wp), O.cond_perceive(z, wp)) < 1e-5
+
+
+# ------------------------------------------------------------------ DyNCA fused step
+def test_dynca_step_golden_all_cases(ops):
+    g = load("g3_dynca")
+    cases = json.loads(str(g["cases"]))
+    for c in cases:
+        t = c["tag"]
+        prm = {k: T(g[f"{t}.{k}"]) for k in ("w1.weight", "w1.bias", "w2.weight", "w2.bias")}
+        x0 = T(g[f"{t}.x0"], DEV)
+        cond = T(g[f"{t}.cond"], DEV) if f"{t}.cond" in g else None
+        w = dyn_w(ops, prm, x0)
+        us = T(g[f"{t}.us"], DEV)
+        x1 = ops.dynca_step(x0, cond, us[0], w, c["pad"], 0.5)
+        assert rel_err(x1, T(g[f"{t}.state_first"])) < REL_TOL, c
+        xT, _ = ops.dynca_nsteps(x0, c["T"], cond, us, w, c["pad"], 0.5)
+        assert rel_err(xT, T(g[f"{t}.state_last"])) < REL_TOL, c
+
+
+@pytest.mark.parametrize("C,fc,cc,shape,pad", [
+    (12, 96, 3, (2, 40, 72), "circular"), (16, 128, 3, (2, 64, 64), "replicate"), (16, 128, 0, (1, 33, 47), "reflect"),
+    (13, 96, 2, (2, 20, 28), "replicate"), (8, 32, 1, (3, 9, 5), "constant"), (16, 100, 4, (1, 8, 32), "circular"),
+    (3, 16, 0, (1, 1, 1), "replicate")])
+def test_dynca_free_running_64_steps(ops, C, fc, cc, shape, pad):
+    """Free-running 64-step parity (no state-dependent threshold in DyNCA, so 1e-4 must hold)."""
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(C * 100 + W)
+    prm = rand_dynca_prm(C, fc, cc, seed=C + fc)
+    x0 = torch.rand(B, C, H, W, generator=gen) - 0.5
+    cond = torch.rand(B, cc, H, W, generator=gen) * 2 - 1 if cc else None
+    Tn = 64
+    us = torch.rand(Tn, B, 1, H, W, generator=gen)
+    ref = O.dynca_nsteps(x0, cond, list(us), prm, pad, 0.5)
+    w = dyn_w(ops, prm, x0.to(DEV))
+    got, states = ops.dynca_nsteps(x0.to(DEV), Tn, None if cond is None else cond.to(DEV), us.to(DEV), w, pad, 0.5,
+                                   keep_history=True)
+    assert float(ref.abs().max()) > 0.3  # the trajectory is non-trivial
+    assert rel_err(got, ref) < REL_TOL
+    assert states.shape[0] == Tn + 1 and torch.equal(states[Tn], got) and torch.equal(states[0].cpu(), x0)
+    got2, _ = ops.dynca_nsteps(x0.to(DEV), Tn, None if cond is None else cond.to(DEV), us.to(DEV), w, pad, 0.5)
+    assert torch.equal(got2, got)  # ping-pong ring == history ring, deterministic
+
+
+def test_dynca_trained_weights_100_steps(ops):
+    g = load("g5_real_weights")
+    prm = {"w1.weight": T(g["w1"]), "w1.bias": T(g["b1"]), "w2.weight": T(g["w2"]), "w2.bias": T(g["b2"])}
+    cond = O.edge_extractor(T(g["cond_img"]), "tanh").to(DEV)
+    torch.manual_seed(int(g["rng_seed"]))
+    us = torch.stack([torch.rand(1, 1, 48, 48) for _ in range(100)]).to(DEV)
+    x = torch.zeros(1, 12, 48, 48, device=DEV)
+    w = dyn_w(ops, prm, x)
+    _, states = ops.dynca_nsteps(x, 100, cond, us, w, "circular", 0.5, keep_history=True)
+    for t in (25, 50, 100):
+        assert rel_err(states[t], T(g[f"x_t{t}"])) < REL_TOL, t
+
+
+def test_dynca_extra_channels_variant(ops):
+    g = load("g6_extra_channels")
+    prm = {k: T(g[k]) for k in ("w1.weight", "w1.bias", "w2.weight", "w2.bias")}
+    x0 = T(g["x0"], DEV)
+    w = dyn_w(ops, prm, x0)
+    _, states = ops.dynca_nsteps(x0, 5, T(g["pos_emb"], DEV), T(g["us"], DEV), w, "replicate", 0.5, keep_history=True)
+    assert rel_err(states[1:], T(g["states"])) < REL_TOL
+
+
+def test_dynca_inkernel_philox_equals_explicit_u(ops):
+    prm = rand_dynca_prm(12, 96, 0, seed=5)
+    x0 = (torch.rand(2, 12, 24, 40) - 0.5).to(DEV)
+    w = dyn_w(ops, prm, x0)
+    a = ops.dynca_step(x0, None, None, w, "circular", 0.5, seed=1234, step=7)
+    b = ops.dynca_step(x0, None, ops.philox_uniform(2, 24, 40, 1234, 7), w, "circular", 0.5)
+    assert torch.equal(a, b)
+    xa, _ = ops.dynca_nsteps(x0, 3, None, None, w, "circular", 0.5, seed=9, step0=100)
+    us = torch.stack([ops.philox_uniform(2, 24, 40, 9, 100 + t) for t in range(3)])
+    xb, _ = ops.dynca_nsteps(x0, 3, None, us, w, "circular", 0.5)
+    assert torch.equal(xa, xb)
+    frac = float((a != x0).any(dim=1).float().mean())
+    assert 0.4 < frac < 0.6  # ~update_rate of the cells fired
+
+
+def test_dynca_properties_full_size(ops):
+    """BASELINE configs[1] shape (8,16,256,256): size-independent properties + oracle on 2 steps."""
+    B, C, H, W, fc = 8, 16, 256, 256, 128
+    prm = rand_dynca_prm(C, fc, 3, seed=77)
+    gen = torch.Generator().manual_seed(1234)
+    x0 = (torch.rand(B, C, H, W, generator=gen) - 0.5)
+    cond = torch.rand(B, 3, H, W, generator=gen) * 2 - 1
+    us = torch.rand(2, B, 1, H, W, generator=gen)
+    xd, cd, ud = x0.to(DEV), cond.to(DEV), us.to(DEV)
+    w = dyn_w(ops, prm, xd)
+    got, _ = ops.dynca_nsteps(xd, 2, cd, ud, w, "circular", 0.5)
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    ref = O.dynca_nsteps(x0, cond, list(us), prm, "circular", 0.5)
+    assert rel_err(got, ref) < REL_TOL
+    # translation equivariance under circular padding (roll state, cond and u together)
+    sh = (5, -9)
+    r = lambda t: torch.roll(t, sh, dims=(-2, -1))
+    got_r, _ = ops.dynca_nsteps(r(xd).contiguous(), 2, r(cd).contiguous(), r(ud).contiguous(), w, "circular", 0.5)
+    assert torch.equal(got_r, r(got))
+    # batch independence: sample 3 alone == sample 3 in the batch
+    one, _ = ops.dynca_nsteps(xd[3:4], 2, cd[3:4], ud[:, 3:4].contiguous(), w, "circular", 0.5)
+    assert torch.equal(one[0], got[3])
+    # update_rate 0 => identity; cells whose mask is 0 keep their state exactly
+    same = ops.dynca_step(xd, cd, ud[0], w, "circular", 0.0)
+    assert torch.equal(same, xd)
+    x1 = ops.dynca_step(xd, cd, ud[0], w, "circular", 0.5)
+    quiet = (ud[0] + 0.5).floor() == 0
+    assert torch.equal(x1[quiet.expand_as(x1)], xd[quiet.expand_as(xd)])
+
+
+# ------------------------------------------------------------------ ConditionedNCA fused step
+def _near_threshold(alpha_pool: torch.Tensor, thr: float, eps: float = 2e-6) -> torch.Tensor:
+    return (alpha_pool - thr).abs() < eps
+
+
+def test_cond_step_golden_g1(ops):
+    g = load("g1_cond_step")
+    prm = sd(g)
+    x, genc, u = T(g["x"], DEV), T(g["genc"], DEV), T(g["u"], DEV)
+    a, thr, rate = int(g["alive_ch"]), float(g["thr"]), float(g["fire_rate"])
+    w = cond_w(ops, prm, x)
+    goal = genc[:, 4:].contiguous()  # unpadded encoder output (8 channels), as the C ABI takes it
+    xp, pre = ops.cond_step(x, None, goal, u, w, a, thr, rate)
+    assert torch.equal(pre.cpu().bool(), T(g["pre"])[:, 0])
+    assert rel_err(xp, T(g["x1"])) < REL_TOL
+    x2 = ops.cond_finalize(xp, pre, a, thr)
+    # a cell whose pooled new alpha sits within 2e-6 of the threshold may legitimately flip
+    pooled = torch.nn.functional.max_pool2d(T(g["x1"])[:, a:a + 1], 3, 1, 1)
+    ok = ~_near_threshold(pooled, thr).expand_as(T(g["x2"]))
+    assert float(ok.float().mean()) > 0.999
+    assert rel_err(x2.cpu()[ok], T(g["x2"])[ok]) < REL_TOL
+    assert torch.equal(ops.cond_alive(x, a, thr).cpu(), T(g["pre"]))
+    # padded goal (goal_ch == C) is the same computation
+    xp2, _ = ops.cond_step(x, None, genc, u, w, a, thr, rate)
+    assert torch.equal(xp2, xp)
+
+
+@pytest.mark.parametrize("tag", ["seed", "rand"])
+def test_cond_grow_golden_g2(ops, tag):
+    g = load("g2_cond_grow")
+    prm = sd(g)
+    a = int(g["alive_ch"])
+    x0 = T(g[f"{tag}_x0"], DEV)
+    goal = T(g["genc"], DEV)
+    us = T(g[f"{tag}_us"], DEV)
+    ref_states = T(g[f"{tag}_states"])
+    w = cond_w(ops, prm, x0)
+    Tn = int(g["T"])
+    # teacher-forced single steps along the reference trajectory
+    prev = x0
+    for t in range(Tn):
+        xp, pre = ops.cond_step(prev, None, goal, us[t], w, a)
+        x2 = ops.cond_finalize(xp, pre, a)
+        assert rel_err(x2, ref_states[t]) < REL_TOL, t
+        prev = ref_states[t].to(DEV)
+    # free-running, pending protocol across steps
+    xT, states, pre = ops.cond_grow(x0, Tn, goal, us, w, a, keep_history=True)
+    assert rel_err(xT, ref_states[-1]) < REL_TOL
+    xT2, _, _ = ops.cond_grow(x0, Tn, goal, us, w, a)
+    assert torch.equal(xT2, xT)
+    # every intermediate pending state resolves to the reference state
+    for t in range(1, Tn + 1):
+        assert rel_err(ops.cond_finalize(states[t], pre[t], a), ref_states[t - 1]) < REL_TOL, t
+
+
+@pytest.mark.parametrize("C,shape,gch,alive", [(12, (2, 32, 32), 8, 3), (16, (2, 48, 80), 12, 3), (16, (1, 21, 35), 16, 3),
+                                               (10, (2, 16, 16), 6, 3), (16, (2, 24, 24), 12, -1), (5, (1, 3, 3), 1, 4)])
+def test_cond_free_running_vs_oracle(ops, C, shape, gch, alive):
+    """16 free-running steps vs the oracle.  Alive thresholds make trajectories chaotic near
+    alpha==0.1, so cells are compared away from flipped masks; the flip rate itself is bounded."""
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(C * 7 + W)
+    prm = rand_cond_prm(C, seed=C, out_scale=1.0)
+    x0 = torch.rand(B, C, H, W, generator=gen)
+    if alive >= 0:
+        x0[:, alive] = torch.rand(B, H, W, generator=gen) * 0.3
+        x0[0, :, : H // 3] = 0.0
+    goal = torch.randn(B, gch, H, W, generator=gen)
+    Tn = 16
+    us = torch.rand(Tn, B, 1, H, W, generator=gen)
+    gpad = O.cond_pad_goal(goal, C)
+    use_alive = alive >= 0
+    ref = x0
+    refs = []
+    for t in range(Tn):
+        ref = O.cond_step(ref, gpad, us[t], prm, max(alive, 0), 0.1, 0.5, use_living_channel=use_alive)
+        refs.append(ref)
+    w = cond_w(ops, prm, x0.to(DEV))
+    got, states, pre = ops.cond_grow(x0.to(DEV), Tn, goal.to(DEV), us.to(DEV), w, alive, keep_history=True)
+    bad = ((got.cpu() - ref).abs() > REL_TOL * max(1.0, float(ref.abs().max()))).any(dim=1)
+    assert float(bad.float().mean()) < 0.01, float(bad.float().mean())
+    # teacher-forced from the oracle's own state at every step: strict
+    prev = x0
+    for t in range(Tn):
+        xp, pr = ops.cond_step(prev.to(DEV), None, goal.to(DEV), us[t].to(DEV), w, alive)
+        x2 = ops.cond_finalize(xp, pr, alive).cpu()
+        if use_alive:
+            x1 = prev + O.cond_fire_mask(us[t], 0.5) * O.cond_update_net(
+                O.cond_perceive(prev + gpad * O.cond_alive(prev, alive), prm["perception_net.weight"]), prm)
+            near = _near_threshold(torch.nn.functional.max_pool2d(x1[:, alive:alive + 1], 3, 1, 1), 0.1).expand_as(x2)
+        else:
+            near = torch.zeros_like(x2, dtype=torch.bool)
+        assert rel_err(x2[~near], refs[t][~near]) < REL_TOL, t
+        prev = refs[t]
+
+
+def test_cond_dead_grid_stays_dead_and_seed_grows(ops):
+    prm = rand_cond_prm(16, seed=3, out_scale=3.0)
+    x = torch.zeros(2, 16, 64, 64, device=DEV)
+    goal = torch.randn(2, 12, 64, 64, device=DEV)
+    w = cond_w(ops, prm, x)
+    out, _, _ = ops.cond_grow(x, 8, goal, None, w, 3, seed=1)
+    assert float(out.abs().max()) == 0.0  # nothing alive -> pre mask false everywhere -> stays zero
+    seed = O.cond_generate_seed(2, 16, 3, 64).to(DEV)
+    out, _, _ = ops.cond_grow(seed, 8, goal, None, w, 3, seed=1)
+    assert int((out != 0).any(dim=1).sum()) > 2 and float(out.abs().max()) <= 10.0
+
+
+def test_cond_full_size_cfg2_vs_oracle(ops):
+    """BASELINE configs[1]: B=8 C=16 256x256 fp32 forward, 3 steps against the oracle."""
+    B, C, H, W = 8, 16, 256, 256
+    prm = rand_cond_prm(C, seed=0, out_scale=0.5)
+    gen = torch.Generator().manual_seed(1234)
+    x0 = torch.rand(B, C, H, W, generator=gen)
+    goal = torch.randn(B, 12, H, W, generator=gen) * 0.5
+    us = torch.rand(3, B, 1, H, W, generator=gen)
+    ref = O.cond_grow(x0, O.cond_pad_goal(goal, C), list(us), prm, 3)
+    w = cond_w(ops, prm, x0.to(DEV))
+    got, _, _ = ops.cond_grow(x0.to(DEV), 3, goal.to(DEV), us.to(DEV), w, 3)
+    bad = ((got.cpu() - ref).abs() > REL_TOL * max(1.0, float(ref.abs().max()))).any(dim=1)
+    assert float(bad.float().mean()) < 1e-3
+    # in-kernel Philox == explicit uniforms, bit for bit, at full size
+    a, _, _ = ops.cond_grow(x0.to(DEV), 2, goal.to(DEV), None, w, 3, seed=5, step0=11)
+    ue = torch.stack([ops.philox_uniform(B, H, W, 5, 11 + t) for t in range(2)])
+    b, _, _ = ops.cond_grow(x0.to(DEV), 2, goal.to(DEV), ue, w, 3)
+    assert torch.equal(a, b)

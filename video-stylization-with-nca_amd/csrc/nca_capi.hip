@@ -1,0 +1,189 @@
+// nca_capi.hip -- extern "C" entry points of libncahip.so (declared in include/ncahip.h).
+// Validates arguments on the host (shapes the kernels and their grids assume), then enqueues.
+#include "../../include/ncahip.h"
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "nca_kernels.h"
+
+namespace {
+
+constexpr int kMaxC = 16, kMaxFc = 128, kMaxHidden = 64, kMaxCond = 4;
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_result(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+bool dims_ok(int B, int C, int H, int W) {
+    return B > 0 && C > 0 && H > 0 && W > 0 && (size_t)B * C * H * W < ((size_t)1 << 40);
+}
+
+int check_dynca(const void* x_in, const void* x_out, const void* cond, const void* w1, const void* b1, const void* w2,
+                const void* b2, int B, int C, int H, int W, int fc, int c_cond, int pad_mode) {
+    if (!x_in || !x_out || !w1 || !b1 || !w2 || !b2) return fail(NCAHIP_EINVAL, "dynca step: null pointer");
+    if (!dims_ok(B, C, H, W) || fc <= 0 || c_cond < 0) return fail(NCAHIP_EINVAL, "dynca step: bad size");
+    if ((c_cond > 0) != (cond != nullptr)) return fail(NCAHIP_EINVAL, "dynca step: cond pointer / c_cond mismatch");
+    if (pad_mode < 0 || pad_mode > 3) return fail(NCAHIP_EINVAL, "dynca step: bad pad_mode %d", pad_mode);
+    if (pad_mode == NCAHIP_PAD_REFLECT && (H < 2 || W < 2)) return fail(NCAHIP_EINVAL, "reflect pad needs H,W >= 2");
+    if (C > kMaxC || fc > kMaxFc || c_cond > kMaxCond)
+        return fail(NCAHIP_ERANGE, "dynca step: C=%d fc=%d c_cond=%d exceeds (%d,%d,%d)", C, fc, c_cond, kMaxC, kMaxFc,
+                    kMaxCond);
+    if (x_in == x_out) return fail(NCAHIP_EINVAL, "dynca step: x_in and x_out must not alias (halo reads)");
+    return 0;
+}
+
+int check_cond(const void* x_in, const void* x_out, const void* pre_out, const void* goal, const void* wp,
+               const void* w1, const void* b1, const void* w2, const void* b2, const void* w3, int B, int C, int H,
+               int W, int hidden, int goal_ch, int alive_ch) {
+    if (!x_in || !x_out || !pre_out || !wp || !w1 || !b1 || !w2 || !b2 || !w3)
+        return fail(NCAHIP_EINVAL, "cond step: null pointer");
+    if (!dims_ok(B, C, H, W) || hidden <= 0 || goal_ch < 0) return fail(NCAHIP_EINVAL, "cond step: bad size");
+    if ((goal_ch > 0) != (goal != nullptr)) return fail(NCAHIP_EINVAL, "cond step: goal pointer / goal_ch mismatch");
+    if (goal_ch > C || alive_ch >= C) return fail(NCAHIP_EINVAL, "cond step: goal_ch/alive_ch outside C=%d", C);
+    if (C > kMaxC || hidden > kMaxHidden)
+        return fail(NCAHIP_ERANGE, "cond step: C=%d hidden=%d exceeds (%d,%d)", C, hidden, kMaxC, kMaxHidden);
+    if (x_in == x_out) return fail(NCAHIP_EINVAL, "cond step: x_in and x_out must not alias (halo reads)");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ncahip_version(void) { return NCAHIP_VERSION; }
+const char* ncahip_last_error(void) { return g_err; }
+
+int ncahip_limits(int* max_c, int* max_fc, int* max_hidden) {
+    if (max_c) *max_c = kMaxC;
+    if (max_fc) *max_fc = kMaxFc;
+    if (max_hidden) *max_hidden = kMaxHidden;
+    return 0;
+}
+
+int ncahip_selftest(void* scratch, ncahip_stream_t stream) {
+    if (!scratch) return fail(NCAHIP_EINVAL, "selftest: null scratch");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(scratch, 0, 64, st);
+    if (e != hipSuccess) return hip_result(e, "selftest memset");
+    e = nca_launch_selftest((int*)scratch, st);
+    if (e != hipSuccess) return hip_result(e, "selftest launch");
+    int host = 0;
+    e = hipMemcpyAsync(&host, scratch, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return hip_result(e, "selftest sync");
+    return host == 1 ? 0 : fail(NCAHIP_ERANGE, "selftest: MFMA 16x16x4 f32 lane map differs from the one assumed");
+}
+
+int ncahip_dynca_perceive_f32(const float* x, float* y, int B, int C, int H, int W, int pad_mode,
+                              ncahip_stream_t stream) {
+    if (!x || !y || x == y) return fail(NCAHIP_EINVAL, "dynca_perceive: null or aliased pointer");
+    if (!dims_ok(B, C, H, W) || pad_mode < 0 || pad_mode > 3) return fail(NCAHIP_EINVAL, "dynca_perceive: bad argument");
+    if (pad_mode == NCAHIP_PAD_REFLECT && (H < 2 || W < 2)) return fail(NCAHIP_EINVAL, "reflect pad needs H,W >= 2");
+    return hip_result(nca_launch_dynca_perceive(x, y, B, C, H, W, pad_mode, (hipStream_t)stream), "dynca_perceive");
+}
+
+int ncahip_cond_perceive_f32(const float* z, const float* wp, float* y, int B, int C, int H, int W,
+                             ncahip_stream_t stream) {
+    if (!z || !wp || !y || z == y) return fail(NCAHIP_EINVAL, "cond_perceive: null or aliased pointer");
+    if (!dims_ok(B, C, H, W)) return fail(NCAHIP_EINVAL, "cond_perceive: bad size");
+    return hip_result(nca_launch_cond_perceive(z, wp, y, B, C, H, W, (hipStream_t)stream), "cond_perceive");
+}
+
+int ncahip_dynca_step_fwd_f32(const float* x_in, float* x_out, const float* cond, const float* u, const float* w1,
+                              const float* b1, const float* w2, const float* b2, int B, int C, int H, int W, int fc,
+                              int c_cond, int pad_mode, float update_rate, uint64_t seed, uint64_t step,
+                              ncahip_stream_t stream) {
+    if (int rc = check_dynca(x_in, x_out, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
+    NcaDyncaArgs a{x_in, x_out, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step};
+    return hip_result(nca_launch_dynca_step_fwd(a, (hipStream_t)stream), "dynca_step_fwd");
+}
+
+int ncahip_dynca_nsteps_fwd_f32(float* states, int ring, int T, const float* cond, const float* u, const float* w1,
+                                const float* b1, const float* w2, const float* b2, int B, int C, int H, int W, int fc,
+                                int c_cond, int pad_mode, float update_rate, uint64_t seed, uint64_t step0,
+                                ncahip_stream_t stream) {
+    if (ring < 2 || T < 0) return fail(NCAHIP_EINVAL, "dynca nsteps: ring >= 2 and T >= 0 required");
+    if (int rc = check_dynca(states, states + 1, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
+    const size_t slot = (size_t)B * C * H * W, uslot = (size_t)B * H * W;
+    for (int t = 0; t < T; ++t) {
+        NcaDyncaArgs a{states + (size_t)(t % ring) * slot, states + (size_t)((t + 1) % ring) * slot, cond,
+                       u ? u + (size_t)t * uslot : nullptr, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode,
+                       update_rate, seed, step0 + (uint64_t)t};
+        if (int rc = hip_result(nca_launch_dynca_step_fwd(a, (hipStream_t)stream), "dynca_nsteps_fwd")) return rc;
+    }
+    return 0;
+}
+
+int ncahip_cond_step_fwd_f32(const float* x_in, const uint8_t* pre_in, float* x_out, uint8_t* pre_out,
+                             const float* goal, int goal_ch, const float* u, const float* wp, const float* w1,
+                             const float* b1, const float* w2, const float* b2, const float* w3, int B, int C, int H,
+                             int W, int hidden, int alive_ch, float alive_thr, float fire_rate, float clamp_lo,
+                             float clamp_hi, uint64_t seed, uint64_t step, ncahip_stream_t stream) {
+    if (int rc = check_cond(x_in, x_out, pre_out, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch))
+        return rc;
+    if (pre_in && pre_in == pre_out) return fail(NCAHIP_EINVAL, "cond step: pre_in and pre_out must not alias");
+    NcaCondArgs a{x_in, pre_in, x_out, pre_out, goal, u, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch,
+                  alive_ch, alive_thr, fire_rate, clamp_lo, clamp_hi, seed, step};
+    return hip_result(nca_launch_cond_step_fwd(a, (hipStream_t)stream), "cond_step_fwd");
+}
+
+int ncahip_cond_finalize_f32(const float* x_pend, const uint8_t* pre, float* x_out, int B, int C, int H, int W,
+                             int alive_ch, float alive_thr, float clamp_lo, float clamp_hi, ncahip_stream_t stream) {
+    if (!x_pend || !x_out || (alive_ch >= 0 && !pre)) return fail(NCAHIP_EINVAL, "cond_finalize: null pointer");
+    if (!dims_ok(B, C, H, W) || alive_ch >= C) return fail(NCAHIP_EINVAL, "cond_finalize: bad size");
+    if (alive_ch >= 0 && x_pend == x_out) return fail(NCAHIP_EINVAL, "cond_finalize: in-place needs alive_ch < 0");
+    return hip_result(nca_launch_cond_finalize(x_pend, pre, x_out, B, C, H, W, alive_ch, alive_thr, clamp_lo, clamp_hi,
+                                               (hipStream_t)stream), "cond_finalize");
+}
+
+int ncahip_cond_alive_u8(const float* x, uint8_t* out, int B, int C, int H, int W, int alive_ch, float alive_thr,
+                         ncahip_stream_t stream) {
+    if (!x || !out) return fail(NCAHIP_EINVAL, "cond_alive: null pointer");
+    if (!dims_ok(B, C, H, W) || alive_ch >= C) return fail(NCAHIP_EINVAL, "cond_alive: bad size");
+    return hip_result(nca_launch_cond_alive(x, out, B, C, H, W, alive_ch, alive_thr, (hipStream_t)stream), "cond_alive");
+}
+
+int ncahip_cond_grow_fwd_f32(float* states, uint8_t* pre, int ring, int T, float* x_final, const float* goal,
+                             int goal_ch, const float* u, const float* wp, const float* w1, const float* b1,
+                             const float* w2, const float* b2, const float* w3, int B, int C, int H, int W, int hidden,
+                             int alive_ch, float alive_thr, float fire_rate, float clamp_lo, float clamp_hi,
+                             uint64_t seed, uint64_t step0, ncahip_stream_t stream) {
+    if (ring < 2 || T < 1 || !pre || !x_final) return fail(NCAHIP_EINVAL, "cond grow: ring >= 2, T >= 1, buffers required");
+    if (int rc = check_cond(states, states + 1, pre, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch))
+        return rc;
+    const size_t slot = (size_t)B * C * H * W, pslot = (size_t)B * H * W;
+    hipStream_t st = (hipStream_t)stream;
+    const int sl = T % ring;
+    if (x_final == states + (size_t)sl * slot && alive_ch >= 0)
+        return fail(NCAHIP_EINVAL, "cond grow: x_final must not alias the last state slot");
+    for (int t = 0; t < T; ++t) {
+        const int si = t % ring, so = (t + 1) % ring;
+        NcaCondArgs a{states + (size_t)si * slot, t == 0 ? nullptr : pre + (size_t)si * pslot,
+                      states + (size_t)so * slot, pre + (size_t)so * pslot, goal,
+                      u ? u + (size_t)t * pslot : nullptr, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch,
+                      alive_ch, alive_thr, fire_rate, clamp_lo, clamp_hi, seed, step0 + (uint64_t)t};
+        if (int rc = hip_result(nca_launch_cond_step_fwd(a, st), "cond_grow_fwd")) return rc;
+    }
+    return hip_result(nca_launch_cond_finalize(states + (size_t)sl * slot, pre + (size_t)sl * pslot, x_final, B, C, H, W,
+                                               alive_ch, alive_thr, clamp_lo, clamp_hi, st), "cond_grow finalize");
+}
+
+int ncahip_philox_uniform_f32(float* u, int B, int H, int W, uint64_t seed, uint64_t step, ncahip_stream_t stream) {
+    if (!u || B <= 0 || H <= 0 || W <= 0) return fail(NCAHIP_EINVAL, "philox_uniform: bad argument");
+    return hip_result(nca_launch_philox_uniform(u, B, H, W, seed, step, (hipStream_t)stream), "philox_uniform");
+}
+
+}  // extern "C"

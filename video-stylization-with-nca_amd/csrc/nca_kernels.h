@@ -1,0 +1,42 @@
+// nca_kernels.h -- internal launch interface between the C ABI (nca_capi.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct NcaDyncaArgs {
+    const float* x_in;
+    float* x_out;
+    const float* cond;  // [B,c_cond,H,W] or null
+    const float* u;     // [B,1,H,W] or null (Philox)
+    const float *w1, *b1, *w2, *b2;
+    int B, C, H, W, fc, c_cond, pad_mode;
+    float rate;
+    uint64_t seed, step;
+};
+
+struct NcaCondArgs {
+    const float* x_in;
+    const uint8_t* pre_in;  // null: x_in is a true state; else x_in is pending with this pre mask
+    float* x_out;
+    uint8_t* pre_out;
+    const float* goal;  // [B,goal_ch,H,W]
+    const float* u;
+    const float *wp, *w1, *b1, *w2, *b2, *w3;
+    int B, C, H, W, hidden, goal_ch, alive_ch;
+    float thr, fire_rate, lo, hi;
+    uint64_t seed, step;
+};
+
+// fused steps (nca_step_fwd.hip); hipErrorInvalidValue when no instantiation covers the shape
+hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st);
+hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st);
+
+// stencils and small kernels (nca_stencil.hip)
+hipError_t nca_launch_dynca_perceive(const float* x, float* y, int B, int C, int H, int W, int pad, hipStream_t st);
+hipError_t nca_launch_cond_perceive(const float* z, const float* wp, float* y, int B, int C, int H, int W, hipStream_t st);
+hipError_t nca_launch_cond_finalize(const float* x, const uint8_t* pre, float* out, int B, int C, int H, int W,
+                                    int alive_ch, float thr, float lo, float hi, hipStream_t st);
+hipError_t nca_launch_cond_alive(const float* x, uint8_t* out, int B, int C, int H, int W, int alive_ch, float thr,
+                                 hipStream_t st);
+hipError_t nca_launch_philox_uniform(float* u, int B, int H, int W, uint64_t seed, uint64_t step, hipStream_t st);
+hipError_t nca_launch_selftest(int* result, hipStream_t st);

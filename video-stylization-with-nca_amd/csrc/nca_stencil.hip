@@ -1,0 +1,257 @@
+// nca_stencil.hip -- HBM-bound kernels: standalone perception stencils, pending-state finalize,
+// alive mask, Philox uniforms, MFMA lane-map self-test.  gfx950 only.
+//
+// Perception: one thread produces 4 W-contiguous cells of one (b, channel, row): three 16-byte row
+// loads (pad mode resolved per row), left/right neighbours taken from the adjacent lanes by
+// wavefront shuffle (the row edges and the wave edges fall back to one scalar load that hits
+// L1/L2), 16-byte stores of each output plane.  Algorithmic traffic: read C, write 4C (or 3C)
+// floats per cell -- 20*C (16*C) bytes/cell; that figure over the launch time is what bench.py
+// prices against the 8 TB/s HBM roof.
+#include "nca_common.h"
+#include "nca_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// Loads rows y-1,y,y+1 of one plane at columns 4*x4-1 .. 4*x4+4 into nb[3][6] (pad-resolved).
+__device__ __forceinline__ void load_rows_vec(const float* plane, int H, int W, int y, int x4, int pad,
+                                              bool lane_has_left, bool lane_has_right, float (&nb)[3][6]) {
+    const int xl = nca_pad_index(4 * x4 - 1, W, pad), xr = nca_pad_index(4 * x4 + 4, W, pad);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int sy = nca_pad_index(y + dy - 1, H, pad);
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* row = plane + (size_t)(sy < 0 ? 0 : sy) * W;
+        if (sy >= 0) c = ld4(row + 4 * x4);
+        // neighbours from the adjacent lanes (same row when lane_has_* holds)
+        float l = __shfl_up(c.w, 1), r = __shfl_down(c.x, 1);
+        if (!lane_has_left) l = (sy >= 0 && xl >= 0) ? row[xl] : 0.0f;
+        if (!lane_has_right) r = (sy >= 0 && xr >= 0) ? row[xr] : 0.0f;
+        nb[dy][0] = l; nb[dy][1] = c.x; nb[dy][2] = c.y; nb[dy][3] = c.z; nb[dy][4] = c.w; nb[dy][5] = r;
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void dynca_perceive_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             int B, int C, int H, int W, int pad) {
+    const size_t plane = (size_t)H * W;
+    if (VEC) {
+        const int W4 = W >> 2;
+        const size_t total = (size_t)B * C * H * W4;
+        const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool active = gid < total;
+        const size_t id = active ? gid : total - 1;  // keep every lane in the shuffles
+        const int x4 = (int)(id % W4);
+        const int yy = (int)((id / W4) % H);
+        const int c = (int)((id / ((size_t)W4 * H)) % C);
+        const int b = (int)(id / ((size_t)W4 * H * C));
+        const int lane = threadIdx.x & 63;
+        float nb[3][6];
+        load_rows_vec(x + ((size_t)b * C + c) * plane, H, W, yy, x4, pad, x4 > 0 && lane > 0,
+                      x4 < W4 - 1 && lane < 63 && gid + 1 < total, nb);
+        if (!active) return;
+        float4 o[4];
+        float* op[4] = {&o[0].x, &o[1].x, &o[2].x, &o[3].x};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a[3][3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) a[dy][dx] = nb[dy][j + dx];
+            op[0][j] = a[1][1];
+            op[1][j] = nca_sobel_x(a);
+            op[2][j] = nca_sobel_y(a);
+            op[3][j] = nca_laplacian(a);
+        }
+        float* const yb = y + (size_t)b * 4 * C * plane + (size_t)yy * W + 4 * x4;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) st4(yb + (size_t)(f * C + c) * plane, o[f]);  // blocked order, dynca.py:92-95
+    } else {
+        const size_t total = (size_t)B * C * plane;
+        const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (id >= total) return;
+        const int xx = (int)(id % W), yy = (int)((id / W) % H);
+        const int c = (int)((id / plane) % C), b = (int)(id / (plane * C));
+        const float* const p = x + ((size_t)b * C + c) * plane;
+        float a[3][3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int sy = nca_pad_index(yy + dy - 1, H, pad), sx = nca_pad_index(xx + dx - 1, W, pad);
+                a[dy][dx] = (sy >= 0 && sx >= 0) ? p[(size_t)sy * W + sx] : 0.0f;
+            }
+        float* const yb = y + (size_t)b * 4 * C * plane + (size_t)yy * W + xx;
+        yb[(size_t)c * plane] = a[1][1];
+        yb[(size_t)(C + c) * plane] = nca_sobel_x(a);
+        yb[(size_t)(2 * C + c) * plane] = nca_sobel_y(a);
+        yb[(size_t)(3 * C + c) * plane] = nca_laplacian(a);
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void cond_perceive_kernel(const float* __restrict__ z, const float* __restrict__ wp,
+                                                            float* __restrict__ y, int B, int C, int H, int W) {
+    const size_t plane = (size_t)H * W;
+    constexpr int V = VEC ? 4 : 1;
+    const int WV = W / V;
+    const size_t total = (size_t)B * C * H * WV;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = gid < total;
+    const size_t id = active ? gid : total - 1;
+    const int xv = (int)(id % WV);
+    const int yy = (int)((id / WV) % H);
+    const int c = (int)((id / ((size_t)WV * H)) % C);
+    const int b = (int)(id / ((size_t)WV * H * C));
+    const float* const p = z + ((size_t)b * C + c) * plane;
+    float nb[3][V + 2];
+    if (VEC) {
+        const int lane = threadIdx.x & 63;
+        float t[3][6];
+        load_rows_vec(p, H, W, yy, xv, NCA_PAD_ZERO, xv > 0 && lane > 0, xv < WV - 1 && lane < 63 && gid + 1 < total, t);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int j = 0; j < V + 2; ++j) nb[dy][j] = t[dy][j];
+    } else {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int sy = yy + dy - 1, sx = xv + dx - 1;
+                nb[dy][dx] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? p[(size_t)sy * W + sx] : 0.0f;
+            }
+    }
+    if (!active) return;
+    const float* const w = wp + (size_t)c * 27;
+    float* const yb = y + ((size_t)b * 3 * C + 3 * c) * plane + (size_t)yy * W + V * xv;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        float o[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc = fmaf(w[9 * f + 3 * dy + dx], nb[dy][j + dx], acc);
+            o[j] = acc;
+        }
+        if (VEC) st4(yb + (size_t)f * plane, make_float4(o[0], o[V > 1 ? 1 : 0], o[V > 2 ? 2 : 0], o[V > 3 ? 3 : 0]));
+        else yb[(size_t)f * plane] = o[0];
+    }
+}
+
+__device__ __forceinline__ float alpha_max3x3(const float* ap, int H, int W, int y, int x) {
+    float m = NCA_NEG_INF;  // max_pool2d pads with -inf (nca.py:156-161)
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int sy = y + dy, sx = x + dx;
+            if (sy >= 0 && sy < H && sx >= 0 && sx < W) m = fmaxf(m, ap[(size_t)sy * W + sx]);
+        }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void cond_finalize_kernel(const float* __restrict__ x, const uint8_t* __restrict__ pre,
+                                                            float* __restrict__ out, int B, int C, int H, int W,
+                                                            int alive_ch, float thr, float lo, float hi) {
+    const size_t plane = (size_t)H * W;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)B * plane) return;
+    const int xx = (int)(id % W), yy = (int)((id / W) % H), b = (int)(id / plane);
+    const float* const xb = x + (size_t)b * C * plane;
+    float life = 1.0f;
+    if (alive_ch >= 0)
+        life = (pre[id] != 0 && alpha_max3x3(xb + (size_t)alive_ch * plane, H, W, yy, xx) > thr) ? 1.0f : 0.0f;
+    const size_t off = (size_t)yy * W + xx;
+    float* const ob = out + (size_t)b * C * plane + off;
+    for (int c = 0; c < C; ++c) ob[(size_t)c * plane] = fminf(fmaxf(xb[(size_t)c * plane + off] * life, lo), hi);
+}
+
+__global__ __launch_bounds__(256) void cond_alive_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int B, int C,
+                                                         int H, int W, int alive_ch, float thr) {
+    const size_t plane = (size_t)H * W;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)B * plane) return;
+    const int xx = (int)(id % W), yy = (int)((id / W) % H), b = (int)(id / plane);
+    out[id] = alive_ch < 0 ? 1 : (alpha_max3x3(x + ((size_t)b * C + alive_ch) * plane, H, W, yy, xx) > thr ? 1 : 0);
+}
+
+__global__ __launch_bounds__(256) void philox_uniform_kernel(float* __restrict__ u, size_t n, uint64_t seed, uint64_t step) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < n) u[id] = nca_philox_cell(seed, step, id);
+}
+
+// MFMA lane-map check with exact integers and an ASYMMETRIC B: D = A*B, A[i][k] = i + 16k + 1,
+// B[k][j] = 3j + 7k + 2 (k = 0..3).  Every lane verifies its 4 accumulator values.
+__global__ void selftest_kernel(int* result) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+    const float a = (float)(i + 16 * g + 1), bq = (float)(3 * i + 7 * g + 2);
+    f32x4 d = nca_mfma(a, bq, f32x4{0.f, 0.f, 0.f, 0.f});
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r, col = i;
+        float ref = 0.f;
+        for (int k = 0; k < 4; ++k) ref += (float)(row + 16 * k + 1) * (float)(3 * col + 7 * k + 2);
+        ok = ok && (d[r] == ref);
+    }
+    const unsigned long long bad = __ballot(!ok);
+    if (lane == 0) result[0] = bad == 0ull ? 1 : 0;
+}
+
+inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+hipError_t nca_launch_dynca_perceive(const float* x, float* y, int B, int C, int H, int W, int pad, hipStream_t st) {
+    const bool vec = (W % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL(dynca_perceive_kernel<true>, dim3(blocks_for((size_t)B * C * H * (W / 4))), dim3(256), 0, st,
+                           x, y, B, C, H, W, pad);
+    else
+        hipLaunchKernelGGL(dynca_perceive_kernel<false>, dim3(blocks_for((size_t)B * C * H * W)), dim3(256), 0, st, x,
+                           y, B, C, H, W, pad);
+    return hipGetLastError();
+}
+
+hipError_t nca_launch_cond_perceive(const float* z, const float* wp, float* y, int B, int C, int H, int W, hipStream_t st) {
+    const bool vec = (W % 4 == 0) && (((uintptr_t)z | (uintptr_t)y) % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL(cond_perceive_kernel<true>, dim3(blocks_for((size_t)B * C * H * (W / 4))), dim3(256), 0, st,
+                           z, wp, y, B, C, H, W);
+    else
+        hipLaunchKernelGGL(cond_perceive_kernel<false>, dim3(blocks_for((size_t)B * C * H * W)), dim3(256), 0, st, z,
+                           wp, y, B, C, H, W);
+    return hipGetLastError();
+}
+
+hipError_t nca_launch_cond_finalize(const float* x, const uint8_t* pre, float* out, int B, int C, int H, int W,
+                                    int alive_ch, float thr, float lo, float hi, hipStream_t st) {
+    hipLaunchKernelGGL(cond_finalize_kernel, dim3(blocks_for((size_t)B * H * W)), dim3(256), 0, st, x, pre, out, B, C,
+                       H, W, alive_ch, thr, lo, hi);
+    return hipGetLastError();
+}
+
+hipError_t nca_launch_cond_alive(const float* x, uint8_t* out, int B, int C, int H, int W, int alive_ch, float thr,
+                                 hipStream_t st) {
+    hipLaunchKernelGGL(cond_alive_kernel, dim3(blocks_for((size_t)B * H * W)), dim3(256), 0, st, x, out, B, C, H, W,
+                       alive_ch, thr);
+    return hipGetLastError();
+}
+
+hipError_t nca_launch_philox_uniform(float* u, int B, int H, int W, uint64_t seed, uint64_t step, hipStream_t st) {
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(philox_uniform_kernel, dim3(blocks_for(n)), dim3(256), 0, st, u, n, seed, step);
+    return hipGetLastError();
+}
+
+hipError_t nca_launch_selftest(int* result, hipStream_t st) {
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, result);
+    return hipGetLastError();
+}

@@ -1,0 +1,583 @@
+// nca_step_fwd.hip -- fused NCA step kernels for MI355X (gfx950), fp32 exact.
+//
+// One persistent launch per NCA step.  A workgroup (4 waves) owns TH x TW cell tiles:
+//   1. the state tile (+1 halo, pad mode resolved at load time; ConditionedNCA: the pending
+//      life mask of the previous step is resolved on an alpha halo of 3) is staged in LDS;
+//   2. each wave takes 4 groups of 16 W-contiguous cells; lane l = 16*g + i computes the
+//      3x3 depthwise perception of channels {4c'+g} for cell i from LDS (the perception value
+//      IS the MFMA B operand: B[k = g][col = i]);
+//   3. the per-cell MLP runs on v_mfma_f32_16x16x4_f32 (exact f32 == fmaf chain) with cells on
+//      the N/lane axis and channels on M/K: D = W * X.  A layer's accumulator tile
+//      (rows 4g+r in reg r, guide sec.3) is the next layer's B operand without any lane
+//      movement when that layer's k order is permuted to k(s,g) = 16*(s/4) + 4g + s%4 -- the
+//      permutation is folded into the LDS weight image, built once per workgroup;
+//   4. residual add + fire mask, stores straight from the accumulator layout.
+// Weights live in LDS as the A-operand image [m-tile][k-step][lane]; hidden activations never
+// leave registers.  Layer 1 is streamed m-tile by m-tile into layer 2's accumulators so only
+// one layer-1 tile is live (keeps 2 waves/SIMD).
+#include "nca_common.h"
+#include "nca_kernels.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+constexpr int lds_cs(int rows, int rs) {  // channel stride with CS % 32 == 16 (conflict-free g/g+1 pairs)
+    int cs = rows * rs;
+    while (cs % 32 != 16) ++cs;
+    return cs;
+}
+
+// =========================================================================================
+// DyNCA step (ConditioneDyNCA/models/dynca.py:117-138)
+// =========================================================================================
+template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT>
+struct DyncaCfg {
+    static constexpr int K1S = CP + (HAS_COND ? 1 : 0);  // k-steps of layer 1 (4 inputs each)
+    static constexpr int M1T = FC / 16;                  // 16-row output tiles of layer 1
+    static constexpr int K2S = FC / 4;
+    static constexpr int M2T = (CP + 15) / 16;
+    static constexpr int ROWS = TH + 2, RS = TW + 2;
+    static constexpr int CS = lds_cs(ROWS, RS);
+    static constexpr int TWN = TW / 16;
+    static constexpr int NTILES16 = TH * TW / 16;
+    static constexpr int ITERS = NTILES16 / (4 * NT);
+    // LDS carve (floats)
+    static constexpr int OFF_W1 = 0;
+    static constexpr int OFF_W2 = OFF_W1 + M1T * K1S * 64;
+    static constexpr int OFF_B1 = OFF_W2 + M2T * K2S * 64;
+    static constexpr int OFF_B2 = OFF_B1 + FC;
+    static constexpr int OFF_Z = OFF_B2 + M2T * 16;
+    static constexpr int OFF_MK = OFF_Z + CP * CS;
+    static constexpr int OFF_CN = OFF_MK + TH * TW;
+    static constexpr int LDS_FLOATS = OFF_CN + (HAS_COND ? 4 * TH * TW : 0);
+    static_assert(FC % 16 == 0 && CP % 4 == 0 && TW % 16 == 0, "shape");
+    static_assert(NTILES16 % (4 * NT) == 0, "tile must split evenly over 4 waves x NT");
+    static_assert(OFF_Z % 4 == 0, "16-byte carve");
+};
+
+template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT>
+__global__ __launch_bounds__(kThreads, 2) void dynca_step_fwd_kernel(const NcaDyncaArgs a) {
+    using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const W1L = smem + K::OFF_W1;
+    float* const W2L = smem + K::OFF_W2;
+    float* const B1L = smem + K::OFF_B1;
+    float* const B2L = smem + K::OFF_B2;
+    float* const Z = smem + K::OFF_Z;
+    float* const MK = smem + K::OFF_MK;
+    float* const CN = smem + K::OFF_CN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ci = lane & 15;
+    const int C = a.C, H = a.H, W = a.W, fc = a.fc, CC = a.c_cond;
+    const int K1 = 4 * C + CC;
+
+    // ---- A-operand weight images, once per workgroup -------------------------------------
+    for (int idx = tid; idx < K::M1T * K::K1S * 64; idx += kThreads) {
+        const int l = idx & 63, s = (idx >> 6) % K::K1S, m = (idx >> 6) / K::K1S;
+        const int gg = l >> 4, o = 16 * m + (l & 15);
+        int k;
+        bool ok;
+        if (s < CP) {  // k-step s = 4c'+f : channel 4c'+g, filter f (0 id, 1 sobel_x, 2 sobel_y, 3 lap)
+            const int ch = (s & ~3) + gg;
+            ok = ch < C;
+            k = (s & 3) * C + ch;  // blocked [x | Sx | Sy | L] input order, dynca.py:92-95
+        } else {  // conditioning k-step
+            ok = gg < CC;
+            k = 4 * C + gg;
+        }
+        W1L[idx] = (ok && o < fc) ? a.w1[(size_t)o * K1 + k] : 0.0f;
+    }
+    for (int idx = tid; idx < K::M2T * K::K2S * 64; idx += kThreads) {
+        const int l = idx & 63, s = (idx >> 6) % K::K2S, m = (idx >> 6) / K::K2S;
+        const int gg = l >> 4, o = 16 * m + (l & 15);
+        const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
+        W2L[idx] = (o < C && k < fc) ? a.w2[(size_t)o * fc + k] : 0.0f;
+    }
+    for (int idx = tid; idx < FC; idx += kThreads) B1L[idx] = idx < fc ? a.b1[idx] : 0.0f;
+    for (int idx = tid; idx < K::M2T * 16; idx += kThreads) B2L[idx] = idx < C ? a.b2[idx] : 0.0f;
+
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntiles = a.B * tiles_x * tiles_y;
+    const size_t plane = (size_t)H * W;
+
+    for (NcaTileWalk tw = nca_tile_walk(ntiles); tw.t < tw.end; tw.t += tw.stride) {
+        const int txi = tw.t % tiles_x, tyi = (tw.t / tiles_x) % tiles_y, b = tw.t / (tiles_x * tiles_y);
+        const int ty0 = tyi * TH, tx0 = txi * TW;
+        const float* const xb = a.x_in + (size_t)b * C * plane;
+
+        __syncthreads();  // previous tile fully consumed (also orders the weight image on iter 0)
+        // ---- stage state tile + halo, pad mode resolved here -----------------------------
+        for (int idx = tid; idx < CP * K::ROWS * K::RS; idx += kThreads) {
+            const int q = idx % K::RS, r = (idx / K::RS) % K::ROWS, ch = idx / (K::RS * K::ROWS);
+            float v = 0.0f;
+            if (ch < C) {
+                const int sy = nca_pad_index(ty0 - 1 + r, H, a.pad_mode);
+                const int sx = nca_pad_index(tx0 - 1 + q, W, a.pad_mode);
+                if (sy >= 0 && sx >= 0) v = xb[ch * plane + (size_t)sy * W + sx];
+            }
+            Z[ch * K::CS + r * K::RS + q] = v;
+        }
+        for (int idx = tid; idx < TH * TW; idx += kThreads) {
+            const int q = idx % TW, r = idx / TW, gy = ty0 + r, gx = tx0 + q;
+            float m = 0.0f;
+            if (gy < H && gx < W) {
+                const size_t cell = (size_t)b * plane + (size_t)gy * W + gx;
+                const float uu = a.u ? a.u[cell] : nca_philox_cell(a.seed, a.step, cell);
+                m = floorf(uu + a.rate);  // dynca.py:131
+            }
+            MK[idx] = m;
+        }
+        if (HAS_COND) {
+            for (int idx = tid; idx < 4 * TH * TW; idx += kThreads) {
+                const int q = idx % TW, r = (idx / TW) % TH, cc = idx / (TH * TW);
+                const int gy = ty0 + r, gx = tx0 + q;
+                CN[idx] = (cc < CC && gy < H && gx < W)
+                              ? a.cond[((size_t)b * CC + cc) * plane + (size_t)gy * W + gx] : 0.0f;
+            }
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int it = 0; it < K::ITERS; ++it) {
+            int r0[NT], q0[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int j = (it * 4 + wave) * NT + n;
+                r0[n] = j / K::TWN;
+                q0[n] = (j % K::TWN) * 16 + ci;
+            }
+            // ---- perception: B operands of layer 1 ---------------------------------------
+            float P[NT][K::K1S];
+#pragma unroll
+            for (int cq = 0; cq < CP / 4; ++cq) {
+                const float* const zc = Z + (4 * cq + g) * K::CS;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    float nb[3][3];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) nb[dy][dx] = zc[(r0[n] + dy) * K::RS + q0[n] + dx];
+                    P[n][4 * cq + 0] = nb[1][1];
+                    P[n][4 * cq + 1] = nca_sobel_x(nb);
+                    P[n][4 * cq + 2] = nca_sobel_y(nb);
+                    P[n][4 * cq + 3] = nca_laplacian(nb);
+                }
+            }
+            if (HAS_COND) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) P[n][CP] = CN[g * TH * TW + r0[n] * TW + q0[n]];
+            }
+            // ---- MLP on MFMA: layer 1 streamed tile-by-tile into layer 2 -----------------
+            f32x4 acc2[K::M2T][NT];
+#pragma unroll
+            for (int m2 = 0; m2 < K::M2T; ++m2) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(B2L + 16 * m2 + 4 * g);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc2[m2][n] = bias;
+            }
+#pragma unroll 1
+            for (int m = 0; m < K::M1T; ++m) {
+                const float* const w1m = W1L + m * K::K1S * 64 + lane;
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(B1L + 16 * m + 4 * g);
+                f32x4 acc1[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc1[n] = bias;
+#pragma unroll
+                for (int s = 0; s < K::K1S; ++s) {
+                    const float wa = w1m[s * 64];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc1[n] = nca_mfma(wa, P[n][s], acc1[n]);
+                }
+                const float* const w2m = W2L + (4 * m) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int m2 = 0; m2 < K::M2T; ++m2) {
+                        const float wa = w2m[(m2 * K::K2S + r) * 64];
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc2[m2][n] = nca_mfma(wa, fmaxf(acc1[n][r], 0.0f), acc2[m2][n]);
+                    }
+                }
+            }
+            // ---- residual + stochastic mask (dynca.py:131-133) ---------------------------
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int gy = ty0 + r0[n], gx = tx0 + q0[n];
+                if (gy < H && gx < W) {
+                    const float mk = MK[r0[n] * TW + q0[n]];
+                    float* const ob = a.x_out + (size_t)b * C * plane + (size_t)gy * W + gx;
+#pragma unroll
+                    for (int m2 = 0; m2 < K::M2T; ++m2)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ch = 16 * m2 + 4 * g + r;
+                            if (ch < C) {
+                                const float xo = Z[ch * K::CS + (r0[n] + 1) * K::RS + q0[n] + 1];
+                                ob[ch * plane] = xo + acc2[m2][n][r] * mk;
+                            }
+                        }
+                }
+            }
+        }
+    }
+}
+
+// =========================================================================================
+// ConditionedNCA step (EncoderConditioning/nca.py:181-195), pending-life-mask protocol
+// =========================================================================================
+template <int CP, int TH, int TW, int NT>
+struct CondCfg {
+    static constexpr int HID = 64;
+    static constexpr int K1S = 3 * CP / 4;
+    static constexpr int M3T = (CP + 15) / 16;
+    static constexpr int ROWS = TH + 2, RS = TW + 2;
+    static constexpr int CS = lds_cs(ROWS, RS);
+    static constexpr int A3R = TH + 6, A3S = TW + 6;  // alpha', halo 3
+    static constexpr int L2R = TH + 4, L2S = TW + 4;  // life / resolved alpha, halo 2
+    static constexpr int WPS = 28;                    // 27 taps padded
+    static constexpr int TWN = TW / 16;
+    static constexpr int NTILES16 = TH * TW / 16;
+    static constexpr int ITERS = NTILES16 / (4 * NT);
+    static constexpr int OFF_W1 = 0;
+    static constexpr int OFF_W2 = OFF_W1 + 4 * K1S * 64;
+    static constexpr int OFF_W3 = OFF_W2 + 4 * 16 * 64;
+    static constexpr int OFF_B1 = OFF_W3 + M3T * 16 * 64;
+    static constexpr int OFF_B2 = OFF_B1 + HID;
+    static constexpr int OFF_WP = OFF_B2 + HID;
+    static constexpr int OFF_Z = OFF_WP + CP * WPS;
+    static constexpr int OFF_A3 = OFF_Z + CP * CS;
+    static constexpr int OFF_LIFE = OFF_A3 + A3R * A3S;
+    static constexpr int OFF_A2 = OFF_LIFE + L2R * L2S;
+    static constexpr int OFF_PN = OFF_A2 + L2R * L2S;
+    static constexpr int OFF_MK = OFF_PN + ROWS * RS;
+    static constexpr int LDS_FLOATS = OFF_MK + TH * TW;
+    static_assert(CP % 4 == 0 && TW % 16 == 0 && NTILES16 % (4 * NT) == 0, "shape");
+    static_assert(OFF_Z % 4 == 0 && OFF_WP % 4 == 0, "16-byte carve");
+};
+
+__device__ __forceinline__ float nca_max3x3(const float* p, int stride) {
+    float m = fmaxf(fmaxf(p[-stride - 1], p[-stride]), p[-stride + 1]);
+    m = fmaxf(m, fmaxf(fmaxf(p[-1], p[0]), p[1]));
+    return fmaxf(m, fmaxf(fmaxf(p[stride - 1], p[stride]), p[stride + 1]));
+}
+__device__ __forceinline__ float nca_clamp(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+template <int CP, int TH, int TW, int NT>
+__global__ __launch_bounds__(kThreads, 2) void cond_step_fwd_kernel(const NcaCondArgs a) {
+    using K = CondCfg<CP, TH, TW, NT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const W1L = smem + K::OFF_W1;
+    float* const W2L = smem + K::OFF_W2;
+    float* const W3L = smem + K::OFF_W3;
+    float* const B1L = smem + K::OFF_B1;
+    float* const B2L = smem + K::OFF_B2;
+    float* const WPL = smem + K::OFF_WP;
+    float* const Z = smem + K::OFF_Z;
+    float* const A3 = smem + K::OFF_A3;
+    float* const LIFE = smem + K::OFF_LIFE;
+    float* const A2 = smem + K::OFF_A2;
+    float* const PN = smem + K::OFF_PN;
+    float* const MK = smem + K::OFF_MK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ci = lane & 15;
+    const int C = a.C, H = a.H, W = a.W, hid = a.hidden;
+    const int K1 = 3 * C;
+    const int gch0 = C - a.goal_ch;  // first channel the goal encoding is added to (nca.py:199-203)
+    const bool pending = a.pre_in != nullptr;
+    const bool use_alive = a.alive_ch >= 0;
+
+    for (int idx = tid; idx < 4 * K::K1S * 64; idx += kThreads) {
+        const int l = idx & 63, s = (idx >> 6) % K::K1S, m = (idx >> 6) / K::K1S;
+        const int gg = l >> 4, o = 16 * m + (l & 15);
+        const int ch = 4 * (s / 3) + gg, f = s % 3;  // k-step s = 3c'+f : channel 4c'+g, filter f
+        W1L[idx] = (ch < C && o < hid) ? a.w1[(size_t)o * K1 + 3 * ch + f] : 0.0f;  // out[3c+f], nca.py:99-107
+    }
+    for (int idx = tid; idx < 4 * 16 * 64; idx += kThreads) {
+        const int l = idx & 63, s = (idx >> 6) % 16, m = (idx >> 6) / 16;
+        const int gg = l >> 4, o = 16 * m + (l & 15);
+        const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
+        W2L[idx] = (o < hid && k < hid) ? a.w2[(size_t)o * hid + k] : 0.0f;
+    }
+    for (int idx = tid; idx < K::M3T * 16 * 64; idx += kThreads) {
+        const int l = idx & 63, s = (idx >> 6) % 16, m = (idx >> 6) / 16;
+        const int gg = l >> 4, o = 16 * m + (l & 15);
+        const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
+        W3L[idx] = (o < C && k < hid) ? a.w3[(size_t)o * hid + k] : 0.0f;
+    }
+    for (int idx = tid; idx < K::HID; idx += kThreads) {
+        B1L[idx] = idx < hid ? a.b1[idx] : 0.0f;
+        B2L[idx] = idx < hid ? a.b2[idx] : 0.0f;
+    }
+    for (int idx = tid; idx < CP * K::WPS; idx += kThreads) {
+        const int ch = idx / K::WPS, j = idx % K::WPS;
+        WPL[idx] = (ch < C && j < 27) ? a.wp[(size_t)ch * 27 + j] : 0.0f;  // [3c+f][3][3] == [c][f*9+tap]
+    }
+
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntiles = a.B * tiles_x * tiles_y;
+    const size_t plane = (size_t)H * W;
+
+    for (NcaTileWalk tw = nca_tile_walk(ntiles); tw.t < tw.end; tw.t += tw.stride) {
+        const int txi = tw.t % tiles_x, tyi = (tw.t / tiles_x) % tiles_y, b = tw.t / (tiles_x * tiles_y);
+        const int ty0 = tyi * TH, tx0 = txi * TW;
+        const float* const xb = a.x_in + (size_t)b * C * plane;
+
+        __syncthreads();
+        // ---- S1: alpha' (halo 3, -inf outside the image = max_pool2d padding) + pre_in (halo 2)
+        if (use_alive) {
+            for (int idx = tid; idx < K::A3R * K::A3S; idx += kThreads) {
+                const int q = idx % K::A3S, r = idx / K::A3S, gy = ty0 - 3 + r, gx = tx0 - 3 + q;
+                A3[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                              ? xb[a.alive_ch * plane + (size_t)gy * W + gx] : NCA_NEG_INF;
+            }
+        }
+        for (int idx = tid; idx < K::L2R * K::L2S; idx += kThreads) {
+            const int q = idx % K::L2S, r = idx / K::L2S, gy = ty0 - 2 + r, gx = tx0 - 2 + q;
+            float v = 0.0f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = (pending && use_alive) ? (float)a.pre_in[(size_t)b * plane + (size_t)gy * W + gx] : 1.0f;
+            LIFE[idx] = v;
+        }
+        __syncthreads();
+        // ---- S2: life = pre & post of the PREVIOUS step; resolved alpha (nca.py:191-194) ----
+        if (use_alive) {
+            for (int idx = tid; idx < K::L2R * K::L2S; idx += kThreads) {
+                const int q = idx % K::L2S, r = idx / K::L2S, gy = ty0 - 2 + r, gx = tx0 - 2 + q;
+                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const float* const ac = A3 + (r + 1) * K::A3S + q + 1;
+                float life = LIFE[idx], av = NCA_NEG_INF;
+                if (in) {
+                    if (pending) {
+                        life = (life != 0.0f && nca_max3x3(ac, K::A3S) > a.thr) ? 1.0f : 0.0f;
+                        av = nca_clamp(ac[0] * life, a.lo, a.hi);
+                    } else {
+                        av = ac[0];
+                    }
+                }
+                LIFE[idx] = life;
+                A2[idx] = av;
+            }
+        }
+        __syncthreads();
+        // ---- S3: pre-life mask of THIS step (halo 1), fire mask --------------------------
+        for (int idx = tid; idx < K::ROWS * K::RS; idx += kThreads) {
+            const int q = idx % K::RS, r = idx / K::RS, gy = ty0 - 1 + r, gx = tx0 - 1 + q;
+            float pn = 0.0f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                pn = (!use_alive || nca_max3x3(A2 + (r + 1) * K::L2S + q + 1, K::L2S) > a.thr) ? 1.0f : 0.0f;
+                if (r >= 1 && r <= TH && q >= 1 && q <= TW)
+                    a.pre_out[(size_t)b * plane + (size_t)gy * W + gx] = (uint8_t)pn;
+            }
+            PN[idx] = pn;
+        }
+        for (int idx = tid; idx < TH * TW; idx += kThreads) {
+            const int q = idx % TW, r = idx / TW, gy = ty0 + r, gx = tx0 + q;
+            float m = 0.0f;
+            if (gy < H && gx < W) {
+                const size_t cell = (size_t)b * plane + (size_t)gy * W + gx;
+                const float uu = a.u ? a.u[cell] : nca_philox_cell(a.seed, a.step, cell);
+                m = (nca_clamp(uu, 0.0f, 1.0f) < a.fire_rate) ? 1.0f : 0.0f;  // nca.py:171-174
+            }
+            MK[idx] = m;
+        }
+        __syncthreads();
+        // ---- S4: z = x + goal * pre (nca.py:177) on halo 1, zero outside the image -------
+        for (int idx = tid; idx < CP * K::ROWS * K::RS; idx += kThreads) {
+            const int q = idx % K::RS, r = (idx / K::RS) % K::ROWS, ch = idx / (K::RS * K::ROWS);
+            const int gy = ty0 - 1 + r, gx = tx0 - 1 + q;
+            float v = 0.0f;
+            if (ch < C && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const size_t off = (size_t)gy * W + gx;
+                v = xb[ch * plane + off];
+                if (pending) v = nca_clamp(v * LIFE[(r + 1) * K::L2S + q + 1], a.lo, a.hi);
+                if (ch >= gch0)
+                    v = fmaf(a.goal[((size_t)b * a.goal_ch + (ch - gch0)) * plane + off], PN[r * K::RS + q], v);
+            }
+            Z[ch * K::CS + r * K::RS + q] = v;
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int it = 0; it < K::ITERS; ++it) {
+            int r0[NT], q0[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int j = (it * 4 + wave) * NT + n;
+                r0[n] = j / K::TWN;
+                q0[n] = (j % K::TWN) * 16 + ci;
+            }
+            // ---- learned depthwise perception (nca.py:99-107): P[3c'+f] for channel 4c'+g
+            float P[NT][K::K1S];
+#pragma unroll
+            for (int cq = 0; cq < CP / 4; ++cq) {
+                const float* const zc = Z + (4 * cq + g) * K::CS;
+                float wt[28];
+#pragma unroll
+                for (int j4 = 0; j4 < 7; ++j4) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(WPL + (4 * cq + g) * K::WPS + 4 * j4);
+                    wt[4 * j4 + 0] = w4[0]; wt[4 * j4 + 1] = w4[1]; wt[4 * j4 + 2] = w4[2]; wt[4 * j4 + 3] = w4[3];
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    float nb[9];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) nb[3 * dy + dx] = zc[(r0[n] + dy) * K::RS + q0[n] + dx];
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) {
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) acc = fmaf(wt[9 * f + t], nb[t], acc);
+                        P[n][3 * cq + f] = acc;
+                    }
+                }
+            }
+            // ---- UpdateNet (nca.py:40-46): 3C -> 64 -> 64 -> C ---------------------------
+            f32x4 acc2[4][NT];
+#pragma unroll
+            for (int m2 = 0; m2 < 4; ++m2) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(B2L + 16 * m2 + 4 * g);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc2[m2][n] = bias;
+            }
+#pragma unroll 1
+            for (int m = 0; m < 4; ++m) {
+                const float* const w1m = W1L + m * K::K1S * 64 + lane;
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(B1L + 16 * m + 4 * g);
+                f32x4 acc1[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc1[n] = bias;
+#pragma unroll
+                for (int s = 0; s < K::K1S; ++s) {
+                    const float wa = w1m[s * 64];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc1[n] = nca_mfma(wa, P[n][s], acc1[n]);
+                }
+                const float* const w2m = W2L + (4 * m) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int m2 = 0; m2 < 4; ++m2) {
+                        const float wa = w2m[(m2 * 16 + r) * 64];
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc2[m2][n] = nca_mfma(wa, fmaxf(acc1[n][r], 0.0f), acc2[m2][n]);
+                    }
+                }
+            }
+            f32x4 acc3[K::M3T][NT];
+#pragma unroll
+            for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc3[m3][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // out.4 has no bias
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int m3 = 0; m3 < K::M3T; ++m3) {
+                        const float wa = W3L[(m3 * 16 + 4 * m + r) * 64 + lane];
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc3[m3][n] = nca_mfma(wa, fmaxf(acc2[m][n][r], 0.0f), acc3[m3][n]);
+                    }
+                }
+            }
+            // ---- x' = x + rand_mask * out (nca.py:189); stays pending ---------------------
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int gy = ty0 + r0[n], gx = tx0 + q0[n];
+                if (gy < H && gx < W) {
+                    const float mk = MK[r0[n] * TW + q0[n]];
+                    const float life = LIFE[(r0[n] + 2) * K::L2S + q0[n] + 2];
+                    const size_t off = (size_t)gy * W + gx;
+                    float* const ob = a.x_out + (size_t)b * C * plane + off;
+#pragma unroll
+                    for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ch = 16 * m3 + 4 * g + r;
+                            if (ch < C) {
+                                float xo = xb[ch * plane + off];
+                                if (pending) xo = nca_clamp(xo * life, a.lo, a.hi);
+                                ob[ch * plane] = xo + mk * acc3[m3][n][r];
+                            }
+                        }
+                }
+            }
+        }
+    }
+}
+
+// ---- host-side launch helpers -------------------------------------------------------------
+template <typename KernelT>
+hipError_t set_lds(KernelT kern, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes);
+}
+
+int grid_for(int ntiles, int wg_per_cu) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int cap = cus * wg_per_cu;
+    return ntiles < cap ? ntiles : cap;
+}
+
+template <int CP, int FC, bool HAS_COND>
+hipError_t launch_dynca(const NcaDyncaArgs& a, hipStream_t st) {
+    constexpr int TH = 8, TW = 32, NT = 4;
+    using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
+    auto kern = dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT>;
+    const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
+    static thread_local bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = set_lds(kern, lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int ntiles = a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+    const int grid = grid_for(ntiles, lds * 2 <= 160 * 1024 ? 2 : 1);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, a);
+    return hipGetLastError();
+}
+
+template <int CP>
+hipError_t launch_cond(const NcaCondArgs& a, hipStream_t st) {
+    constexpr int TH = 8, TW = 32, NT = 4;
+    using K = CondCfg<CP, TH, TW, NT>;
+    auto kern = cond_step_fwd_kernel<CP, TH, TW, NT>;
+    const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
+    static thread_local bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = set_lds(kern, lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int ntiles = a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+    const int grid = grid_for(ntiles, lds * 2 <= 160 * 1024 ? 2 : 1);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// ---- dispatch: smallest instantiation that covers (C, fc); padding lanes carry zero weights ---
+hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st) {
+    const bool hc = a.c_cond > 0;
+    if (a.C <= 12 && a.fc <= 96) return hc ? launch_dynca<12, 96, true>(a, st) : launch_dynca<12, 96, false>(a, st);
+    if (a.C <= 16 && a.fc <= 128) return hc ? launch_dynca<16, 128, true>(a, st) : launch_dynca<16, 128, false>(a, st);
+    return hipErrorInvalidValue;
+}
+
+hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st) {
+    if (a.C <= 12) return launch_cond<12>(a, st);
+    if (a.C <= 16) return launch_cond<16>(a, st);
+    return hipErrorInvalidValue;
+}

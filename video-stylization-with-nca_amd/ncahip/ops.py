@@ -1,0 +1,206 @@
+"""Tensor-level wrappers over the C ABI: marshal torch CUDA tensors to raw pointers, enqueue on the
+current torch stream.  Every function here fails loudly for non-CUDA tensors -- the product path
+has no CPU fallback (the CPU restatement lives in oracle/ and is test infrastructure only)."""
+from typing import Optional, Sequence
+
+import torch
+
+from . import _capi
+from ._capi import PAD_MODES, check, lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _capi.NcaHipError(f"ncahip: `{name}` must be a CUDA (ROCm) tensor -- the NCA hot path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"ncahip: `{name}` must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _w(t: torch.Tensor, name: str, like: torch.Tensor) -> torch.Tensor:
+    """weights: detach, squeeze 1x1 conv dims, move next to the state if needed."""
+    t = t.detach()
+    if t.device != like.device:
+        t = t.to(like.device)
+    return _dev(t.float(), name)
+
+
+def selftest(device=None) -> None:
+    scratch = torch.zeros(1024, dtype=torch.int32, device=device or "cuda")
+    check(lib().ncahip_selftest(scratch.data_ptr(), _stream()), "ncahip_selftest")
+
+
+# ------------------------------------------------------------------------------------ stencils
+def dynca_perceive(x: torch.Tensor, pad_mode: str = "replicate") -> torch.Tensor:
+    x = _dev(x, "x")
+    B, C, H, W = x.shape
+    y = torch.empty(B, 4 * C, H, W, device=x.device, dtype=torch.float32)
+    check(lib().ncahip_dynca_perceive_f32(_p(x), _p(y), B, C, H, W, PAD_MODES[pad_mode], _stream()), "dynca_perceive")
+    return y
+
+
+def cond_perceive(z: torch.Tensor, wp: torch.Tensor) -> torch.Tensor:
+    z = _dev(z, "z")
+    B, C, H, W = z.shape
+    wp = _w(wp, "wp", z)
+    assert wp.numel() == 27 * C
+    y = torch.empty(B, 3 * C, H, W, device=z.device, dtype=torch.float32)
+    check(lib().ncahip_cond_perceive_f32(_p(z), _p(wp), _p(y), B, C, H, W, _stream()), "cond_perceive")
+    return y
+
+
+def philox_uniform(B: int, H: int, W: int, seed: int, step: int, device="cuda") -> torch.Tensor:
+    u = torch.empty(B, 1, H, W, device=device, dtype=torch.float32)
+    check(lib().ncahip_philox_uniform_f32(_p(u), B, H, W, seed, step, _stream()), "philox_uniform")
+    return u
+
+
+# ------------------------------------------------------------------------------------ DyNCA
+class DyncaWeights:
+    """w1 [fc,4C+c_cond,1,1], b1 [fc], w2 [C,fc,1,1], b2 [C] as contiguous fp32 device buffers."""
+
+    def __init__(self, w1, b1, w2, b2, like: torch.Tensor):
+        self.w1, self.b1 = _w(w1, "w1", like), _w(b1, "b1", like)
+        self.w2, self.b2 = _w(w2, "w2", like), _w(b2, "b2", like)
+        self.fc, self.k1 = self.w1.shape[0], self.w1.numel() // self.w1.shape[0]
+        self.c = self.w2.shape[0]
+
+
+def dynca_step(x: torch.Tensor, cond: Optional[torch.Tensor], u: Optional[torch.Tensor], w: DyncaWeights,
+               pad_mode: str = "replicate", update_rate: float = 0.5, seed: int = 0, step: int = 0,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x = _dev(x, "x")
+    B, C, H, W = x.shape
+    c_cond = 0 if cond is None else cond.shape[1]
+    if cond is not None:
+        cond = _dev(cond, "cond")
+        assert cond.shape == (B, c_cond, H, W)
+    if u is not None:
+        u = _dev(u, "u")
+        assert u.numel() == B * H * W
+    assert w.c == C and w.k1 == 4 * C + c_cond, (w.c, w.k1, C, c_cond)
+    out = torch.empty_like(x) if out is None else out
+    check(lib().ncahip_dynca_step_fwd_f32(_p(x), _p(out), _p(cond), _p(u), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2),
+                                          B, C, H, W, w.fc, c_cond, PAD_MODES[pad_mode], update_rate, seed, step,
+                                          _stream()), "dynca_step_fwd")
+    return out
+
+
+def dynca_nsteps(x: torch.Tensor, T: int, cond: Optional[torch.Tensor], us: Optional[torch.Tensor], w: DyncaWeights,
+                 pad_mode: str = "replicate", update_rate: float = 0.5, seed: int = 0, step0: int = 0,
+                 keep_history: bool = False):
+    """T fused steps.  Returns (x_T, states) where states is the [ring,B,C,H,W] buffer (ring=T+1 when
+    keep_history, else 2)."""
+    x = _dev(x, "x")
+    B, C, H, W = x.shape
+    if T == 0:
+        return x.clone(), None
+    c_cond = 0 if cond is None else cond.shape[1]
+    if cond is not None:
+        cond = _dev(cond, "cond")
+    if us is not None:
+        us = _dev(us, "us")
+        assert us.numel() == T * B * H * W
+    assert w.c == C and w.k1 == 4 * C + c_cond, (w.c, w.k1, C, c_cond)
+    ring = T + 1 if keep_history else 2
+    states = torch.empty(ring, B, C, H, W, device=x.device, dtype=torch.float32)
+    states[0].copy_(x)
+    check(lib().ncahip_dynca_nsteps_fwd_f32(_p(states), ring, T, _p(cond), _p(us), _p(w.w1), _p(w.b1), _p(w.w2),
+                                            _p(w.b2), B, C, H, W, w.fc, c_cond, PAD_MODES[pad_mode], update_rate,
+                                            seed, step0, _stream()), "dynca_nsteps_fwd")
+    return states[T % ring], states
+
+
+# ------------------------------------------------------------------------------------ ConditionedNCA
+class CondWeights:
+    """perception_net.weight [3C,1,3,3]; update_net.out.{0,2,4} weights/biases (nca.py:40-46,99-107)."""
+
+    def __init__(self, wp, w1, b1, w2, b2, w3, like: torch.Tensor):
+        self.wp = _w(wp, "wp", like)
+        self.w1, self.b1 = _w(w1, "w1", like), _w(b1, "b1", like)
+        self.w2, self.b2 = _w(w2, "w2", like), _w(b2, "b2", like)
+        self.w3 = _w(w3, "w3", like)
+        self.hidden = self.w1.shape[0]
+        self.c = self.w3.shape[0]
+        assert self.wp.numel() == 27 * self.c and self.w1.numel() == self.hidden * 3 * self.c
+
+
+def _goal_args(goal, B, C, H, W):
+    if goal is None:
+        return None, 0
+    goal = _dev(goal, "goal")
+    assert goal.shape[0] == B and goal.shape[2:] == (H, W) and goal.shape[1] <= C
+    return goal, goal.shape[1]
+
+
+def cond_step(x: torch.Tensor, pre_in: Optional[torch.Tensor], goal: Optional[torch.Tensor],
+              u: Optional[torch.Tensor], w: CondWeights, alive_ch: int = 3, thr: float = 0.1,
+              fire_rate: float = 0.5, lo: float = -10.0, hi: float = 10.0, seed: int = 0, step: int = 0):
+    """One fused step; returns (x_pending, pre) -- resolve with cond_finalize (see include/ncahip.h)."""
+    x = _dev(x, "x")
+    B, C, H, W = x.shape
+    goal, gch = _goal_args(goal, B, C, H, W)
+    if pre_in is not None:
+        pre_in = _dev(pre_in, "pre_in", torch.uint8)
+    if u is not None:
+        u = _dev(u, "u")
+        assert u.numel() == B * H * W
+    assert w.c == C
+    x_out = torch.empty_like(x)
+    pre_out = torch.empty(B, H, W, device=x.device, dtype=torch.uint8)
+    check(lib().ncahip_cond_step_fwd_f32(_p(x), _p(pre_in), _p(x_out), _p(pre_out), _p(goal), gch, _p(u), _p(w.wp),
+                                         _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), _p(w.w3), B, C, H, W, w.hidden,
+                                         alive_ch, thr, fire_rate, lo, hi, seed, step, _stream()), "cond_step_fwd")
+    return x_out, pre_out
+
+
+def cond_finalize(x_pend: torch.Tensor, pre: Optional[torch.Tensor], alive_ch: int = 3, thr: float = 0.1,
+                  lo: float = -10.0, hi: float = 10.0) -> torch.Tensor:
+    x_pend = _dev(x_pend, "x_pend")
+    B, C, H, W = x_pend.shape
+    if pre is not None:
+        pre = _dev(pre, "pre", torch.uint8)
+    out = torch.empty_like(x_pend)
+    check(lib().ncahip_cond_finalize_f32(_p(x_pend), _p(pre), _p(out), B, C, H, W, alive_ch, thr, lo, hi, _stream()),
+          "cond_finalize")
+    return out
+
+
+def cond_alive(x: torch.Tensor, alive_ch: int = 3, thr: float = 0.1) -> torch.Tensor:
+    x = _dev(x, "x")
+    B, C, H, W = x.shape
+    out = torch.empty(B, 1, H, W, device=x.device, dtype=torch.uint8)
+    check(lib().ncahip_cond_alive_u8(_p(x), _p(out), B, C, H, W, alive_ch, thr, _stream()), "cond_alive")
+    return out.bool()
+
+
+def cond_grow(x: torch.Tensor, T: int, goal: Optional[torch.Tensor], us: Optional[torch.Tensor], w: CondWeights,
+              alive_ch: int = 3, thr: float = 0.1, fire_rate: float = 0.5, lo: float = -10.0, hi: float = 10.0,
+              seed: int = 0, step0: int = 0, keep_history: bool = False):
+    """T fused steps + finalize (nca.py:207-208).  Returns (x_T, states, pre)."""
+    x = _dev(x, "x")
+    B, C, H, W = x.shape
+    if T == 0:
+        return x.clone(), None, None
+    goal, gch = _goal_args(goal, B, C, H, W)
+    if us is not None:
+        us = _dev(us, "us")
+        assert us.numel() == T * B * H * W
+    assert w.c == C
+    ring = T + 1 if keep_history else 2
+    states = torch.empty(ring, B, C, H, W, device=x.device, dtype=torch.float32)
+    pre = torch.empty(ring, B, H, W, device=x.device, dtype=torch.uint8)
+    states[0].copy_(x)
+    out = torch.empty_like(x)
+    check(lib().ncahip_cond_grow_fwd_f32(_p(states), _p(pre), ring, T, _p(out), _p(goal), gch, _p(us), _p(w.wp),
+                                         _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), _p(w.w3), B, C, H, W, w.hidden,
+                                         alive_ch, thr, fire_rate, lo, hi, seed, step0, _stream()), "cond_grow_fwd")
+    return out, states, pre
