@@ -47,7 +47,9 @@ def make_weights(gen):
             "update_net.out.0.bias": torch.randn(HIDDEN, generator=gen) * 0.1,
             "update_net.out.2.weight": torch.randn(HIDDEN, HIDDEN, 1, 1, generator=gen) / HIDDEN ** 0.5,
             "update_net.out.2.bias": torch.randn(HIDDEN, generator=gen) * 0.1,
-            "update_net.out.4.weight": torch.randn(C, HIDDEN, 1, 1, generator=gen) * (0.1 / HIDDEN ** 0.5)}
+            # small last layer: 64 steps perturb rand(0,1) states without killing or saturating them, so the
+            # grid stays ~100 % alive and full-range random (no zero-data clock bonus)
+            "update_net.out.4.weight": torch.randn(C, HIDDEN, 1, 1, generator=gen) * (0.02 / HIDDEN ** 0.5)}
 
 
 def event_ms(fn, iters):
@@ -67,19 +69,28 @@ def event_ms(fn, iters):
 def cpu_baseline(prm, x0, goal):
     """Oracle (kind 'port': the reference's PyTorch CPU op sequence) on a bounded sample."""
     from oracle import nca_oracle as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     gpad = O.cond_pad_goal(goal, C)
+    ncpu = os.cpu_count() or 1
     with torch.no_grad():
-        t0 = time.perf_counter()
-        O.cond_grow_rng(x0, gpad, 1, prm, ALIVE_CH)          # warm-up + estimate
-        est = time.perf_counter() - t0
+        # pick the thread count that serves the reference's op sequence best on this host
+        # (all cores oversubscribes these small convs badly); then time the bounded sample with it
+        best = (None, 1e30)
+        for th in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
+            torch.set_num_threads(th)
+            O.cond_grow_rng(x0, gpad, 1, prm, ALIVE_CH)
+            t0 = time.perf_counter()
+            O.cond_grow_rng(x0, gpad, 1, prm, ALIVE_CH)
+            d = time.perf_counter() - t0
+            if d < best[1]:
+                best = (th, d)
+        torch.set_num_threads(best[0])
+        est = best[1]
         steps = int(min(T, max(2, round(12.0 / max(est, 1e-3)))))
         t0 = time.perf_counter()
         O.cond_grow_rng(x0, gpad, steps, prm, ALIVE_CH)
         dt = time.perf_counter() - t0
     return {"value": B * H * W * steps / dt, "unit": "cell-updates/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"oracle cond_grow, same (B={B},C={C},{H}x{W}) grid, {steps} of {T} NCA steps, "
+            "kind": "port", "host_cpus": ncpu, "sample": f"oracle cond_grow, same (B={B},C={C},{H}x{W}) grid, {steps} of {T} NCA steps, "
                                       f"{dt:.1f}s, torch CPU fp32, {torch.get_num_threads()} threads"}
 
 
@@ -132,20 +143,23 @@ def main():
                                              w.w2.data_ptr(), w.b2.data_ptr(), w.w3.data_ptr(), B, C, H, W, HIDDEN,
                                              ALIVE_CH, 0.1, 0.5, -10.0, 10.0, 42, step_no[0], st), "cond_grow")
         step_no[0] += T
-        states[0].copy_(out)          # the pool write-back: next pass continues from this state
+
+    def one_step_with_pool():
+        states[0].copy_(xd)           # pool read: every pass grows the sampled batch for T steps
+        one_step()
 
     def barrier():
         if dist_on:
             dist.barrier()
 
     for _ in range(args.warmup):
-        one_step()
+        one_step_with_pool()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_step()
+        one_step_with_pool()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -160,6 +174,7 @@ def main():
     if rank == 0:
         value = world * B * H * W * T * args.steps / dt
         # ---- roofline of the dominant kernel: step launches only, events on the launch stream
+        states[0].copy_(xd)
         xa, xb = states[0], states[1]
 
         def step_pair():
@@ -169,7 +184,8 @@ def main():
                                                      None, w.wp.data_ptr(), w.w1.data_ptr(), w.b1.data_ptr(), w.w2.data_ptr(),
                                                      w.b2.data_ptr(), w.w3.data_ptr(), B, C, H, W, HIDDEN, ALIVE_CH, 0.1, 0.5,
                                                      -10.0, 10.0, 42, 0, st), "cond_step")
-        ms_launch = event_ms(step_pair, 100) / 2
+        ms_launch = event_ms(step_pair, 32) / 2     # 64 launches: the state stays in the regime of one grow
+        alive_frac_roof = float(ops.cond_alive(ops.cond_finalize(xa, pre[0], ALIVE_CH), ALIVE_CH).float().mean())
         cells = B * H * W
         tflops = cells * FLOPS_PER_CELL / (ms_launch * 1e-3) / 1e12
         # ---- HBM-bound stencil
@@ -183,6 +199,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: ConditionedNCA grow loop, B=8 C=16 256x256, 64 NCA steps per bench step, fp32 forward",
                        "B_per_gpu": B, "C": C, "H": H, "W": W, "nca_steps_per_bench_step": T, "hidden": HIDDEN,
                        "mask_rng": "in-kernel philox4x32-10", "alive_fraction_at_end": round(alive_frac, 4),
+                       "alive_fraction_roofline_run": round(alive_frac_roof, 4),
                        "parallelism": f"pool-shard x{world} (no data-path collective)"},
             "roofline": {"kernel": "cond_step_fwd_kernel<16,8,32,4>", "bound": "mfma", "achieved": tflops,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS,
