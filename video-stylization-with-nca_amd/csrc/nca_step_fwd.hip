@@ -2,7 +2,10 @@
 //
 // One persistent launch per NCA step.  A workgroup (4 waves) owns TH x TW cell tiles:
 //   1. the state tile (+1 halo, pad mode resolved at load time; ConditionedNCA: the pending
-//      life mask of the previous step is resolved on an alpha halo of 3) is staged in LDS;
+//      life mask of the previous step is resolved on an alpha halo of 3) is staged in LDS.
+//      Every global load of a tile is issued up front (16-byte row loads, one position per
+//      thread, channels in a register loop) so a tile exposes ONE memory latency, and the
+//      loads are issued before the barrier that retires the previous tile;
 //   2. each wave takes 4 groups of 16 W-contiguous cells; lane l = 16*g + i computes the
 //      3x3 depthwise perception of channels {4c'+g} for cell i from LDS (the perception value
 //      IS the MFMA B operand: B[k = g][col = i]);
@@ -28,6 +31,100 @@ constexpr int lds_cs(int rows, int rs) {  // channel stride with CS % 32 == 16 (
     return cs;
 }
 
+__device__ __forceinline__ float nca_clamp(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// Batched gather of a weight image: dst[idx] = map(idx) >= 0 ? src[map(idx)] : 0, 8 independent loads
+// in flight per thread (a dependent-latency loop here costs tens of microseconds per launch).
+template <int N, typename MapT>
+__device__ __forceinline__ void fill_image(float* __restrict__ dst, const float* __restrict__ src, int tid, MapT map) {
+    constexpr int U = 8;
+    for (int base = tid; base < N; base += kThreads * U) {
+        float v[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + kThreads * u;
+            const long o = idx < N ? map(idx) : -1;
+            ok[u] = o >= 0;
+            v[u] = src[ok[u] ? o : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + kThreads * u;
+            if (idx < N) dst[idx] = ok[u] ? v[u] : 0.0f;
+        }
+    }
+}
+
+// ---- halo-1 tile staging -------------------------------------------------------------------
+// LDS tile Z[ch][r][zq]: r = 0..TH+1 (image row ty0-1+r), zq = q+3 where q = 0..TW+1 is the halo-1
+// column (image col tx0-1+q), so the interior starts 16-byte aligned at zq = 4.  Row stride TW+8.
+// Thread t of each 128-thread half owns one POSITION: an interior 4-cell group (r, 4 cols) or one
+// halo cell; the two halves split the channels.  Address math happens once per thread.
+template <int TH, int TW>
+struct TilePos {
+    static constexpr int F4 = TW / 4, ROWS = TH + 2, RS = TW + 8;
+    static constexpr int NINT = ROWS * F4, NPOS = NINT + 2 * ROWS;
+    static_assert(NPOS <= 128, "positions must fit one 128-thread half");
+    int r, q;          // halo-1 coordinates of the first element
+    bool active, interior, vec;
+    unsigned eo[4];    // plane offsets of the (up to) 4 elements, always dereferenceable
+    bool ev[4];        // element is real (inside the image / pad-resolved)
+
+    template <bool VEC>
+    __device__ __forceinline__ void init(int tid, int ty0, int tx0, int H, int W, int pad) {
+        const int p = tid & 127;
+        active = p < NPOS;
+        interior = p < NINT;
+        if (interior) {
+            r = p / F4;
+            q = 1 + 4 * (p % F4);
+        } else {
+            const int h = p - NINT;
+            r = (h >> 1) % ROWS;
+            q = (h & 1) ? TW + 1 : 0;
+        }
+        const int sy = nca_pad_index(ty0 - 1 + r, H, pad);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sx = nca_pad_index(tx0 - 1 + q + j, W, pad);
+            ev[j] = active && sy >= 0 && sx >= 0 && (interior || j == 0);
+            eo[j] = ev[j] ? (unsigned)(sy * W + sx) : 0u;
+        }
+        vec = VEC && interior && ev[0] && (tx0 - 1 + q + 3 < W);
+    }
+};
+
+// Loads planes clamp(ch0 + c - sub, 0, C-1), c = 0..CPH-1, of this thread's position (the caller
+// zeroes/ignores slots whose unclamped index is out of range).  `base` is wave-uniform; offsets are
+// 32-bit (one sample's planes stay below 2^31 elements) so the loads take the saddr+voffset form.
+template <int CPH, typename PosT>
+__device__ __forceinline__ void pos_load(const PosT& ps, const float* __restrict__ base, unsigned plane, int ch0, int sub,
+                                         int C, float (&v)[CPH][4]) {
+    if (ps.vec) {
+#pragma unroll
+        for (int c = 0; c < CPH; ++c) {
+            const unsigned ch = (unsigned)min(max(ch0 + c - sub, 0), C - 1);
+            const float4 t = *reinterpret_cast<const float4*>(base + (ch * plane + ps.eo[0]));
+            v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
+        }
+    } else {  // halo cells, image-edge overhang, unaligned rows: per-element (masked elements re-read eo = 0)
+#pragma unroll
+        for (int c = 0; c < CPH; ++c) {
+            const unsigned ch = (unsigned)min(max(ch0 + c - sub, 0), C - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[c][j] = base[ch * plane + ps.eo[j]];
+        }
+    }
+}
+
+template <typename PosT>
+__device__ __forceinline__ void pos_store(const PosT& ps, float* __restrict__ Zc /* &Z[ch][0][0] */, const float (&v)[4]) {
+    float* const d = Zc + ps.r * PosT::RS + ps.q + 3;
+    if (ps.interior) *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+    else d[0] = v[0];
+}
+
 // =========================================================================================
 // DyNCA step (ConditioneDyNCA/models/dynca.py:117-138)
 // =========================================================================================
@@ -37,11 +134,12 @@ struct DyncaCfg {
     static constexpr int M1T = FC / 16;                  // 16-row output tiles of layer 1
     static constexpr int K2S = FC / 4;
     static constexpr int M2T = (CP + 15) / 16;
-    static constexpr int ROWS = TH + 2, RS = TW + 2;
+    static constexpr int ROWS = TH + 2, RS = TW + 8;
     static constexpr int CS = lds_cs(ROWS, RS);
     static constexpr int TWN = TW / 16;
     static constexpr int NTILES16 = TH * TW / 16;
     static constexpr int ITERS = NTILES16 / (4 * NT);
+    static constexpr int CPH = CP / 2;
     // LDS carve (floats)
     static constexpr int OFF_W1 = 0;
     static constexpr int OFF_W2 = OFF_W1 + M1T * K1S * 64;
@@ -53,12 +151,13 @@ struct DyncaCfg {
     static constexpr int LDS_FLOATS = OFF_CN + (HAS_COND ? 4 * TH * TW : 0);
     static_assert(FC % 16 == 0 && CP % 4 == 0 && TW % 16 == 0, "shape");
     static_assert(NTILES16 % (4 * NT) == 0, "tile must split evenly over 4 waves x NT");
-    static_assert(OFF_Z % 4 == 0, "16-byte carve");
+    static_assert(OFF_Z % 4 == 0 && CS % 4 == 0 && TH * TW == kThreads, "16-byte carve; one cell per thread");
 };
 
-template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT>
+template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT, bool VEC>
 __global__ __launch_bounds__(kThreads, 2) void dynca_step_fwd_kernel(const NcaDyncaArgs a) {
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
+    using Pos = TilePos<TH, TW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const W1L = smem + K::OFF_W1;
     float* const W2L = smem + K::OFF_W2;
@@ -73,29 +172,24 @@ __global__ __launch_bounds__(kThreads, 2) void dynca_step_fwd_kernel(const NcaDy
     const int K1 = 4 * C + CC;
 
     // ---- A-operand weight images, once per workgroup -------------------------------------
-    for (int idx = tid; idx < K::M1T * K::K1S * 64; idx += kThreads) {
+    fill_image<K::M1T * K::K1S * 64>(W1L, a.w1, tid, [&](int idx) -> long {
         const int l = idx & 63, s = (idx >> 6) % K::K1S, m = (idx >> 6) / K::K1S;
         const int gg = l >> 4, o = 16 * m + (l & 15);
-        int k;
-        bool ok;
+        if (o >= fc) return -1;
         if (s < CP) {  // k-step s = 4c'+f : channel 4c'+g, filter f (0 id, 1 sobel_x, 2 sobel_y, 3 lap)
             const int ch = (s & ~3) + gg;
-            ok = ch < C;
-            k = (s & 3) * C + ch;  // blocked [x | Sx | Sy | L] input order, dynca.py:92-95
-        } else {  // conditioning k-step
-            ok = gg < CC;
-            k = 4 * C + gg;
+            return ch < C ? (long)o * K1 + (s & 3) * C + ch : -1;  // blocked [x|Sx|Sy|L], dynca.py:92-95
         }
-        W1L[idx] = (ok && o < fc) ? a.w1[(size_t)o * K1 + k] : 0.0f;
-    }
-    for (int idx = tid; idx < K::M2T * K::K2S * 64; idx += kThreads) {
+        return gg < CC ? (long)o * K1 + 4 * C + gg : -1;  // conditioning k-step
+    });
+    fill_image<K::M2T * K::K2S * 64>(W2L, a.w2, tid, [&](int idx) -> long {
         const int l = idx & 63, s = (idx >> 6) % K::K2S, m = (idx >> 6) / K::K2S;
         const int gg = l >> 4, o = 16 * m + (l & 15);
         const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
-        W2L[idx] = (o < C && k < fc) ? a.w2[(size_t)o * fc + k] : 0.0f;
-    }
-    for (int idx = tid; idx < FC; idx += kThreads) B1L[idx] = idx < fc ? a.b1[idx] : 0.0f;
-    for (int idx = tid; idx < K::M2T * 16; idx += kThreads) B2L[idx] = idx < C ? a.b2[idx] : 0.0f;
+        return (o < C && k < fc) ? (long)o * fc + k : -1;
+    });
+    fill_image<FC>(B1L, a.b1, tid, [&](int idx) -> long { return idx < fc ? idx : -1; });
+    fill_image<K::M2T * 16>(B2L, a.b2, tid, [&](int idx) -> long { return idx < C ? idx : -1; });
 
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int ntiles = a.B * tiles_x * tiles_y;
@@ -106,35 +200,42 @@ __global__ __launch_bounds__(kThreads, 2) void dynca_step_fwd_kernel(const NcaDy
         const int ty0 = tyi * TH, tx0 = txi * TW;
         const float* const xb = a.x_in + (size_t)b * C * plane;
 
-        __syncthreads();  // previous tile fully consumed (also orders the weight image on iter 0)
-        // ---- stage state tile + halo, pad mode resolved here -----------------------------
-        for (int idx = tid; idx < CP * K::ROWS * K::RS; idx += kThreads) {
-            const int q = idx % K::RS, r = (idx / K::RS) % K::ROWS, ch = idx / (K::RS * K::ROWS);
-            float v = 0.0f;
-            if (ch < C) {
-                const int sy = nca_pad_index(ty0 - 1 + r, H, a.pad_mode);
-                const int sx = nca_pad_index(tx0 - 1 + q, W, a.pad_mode);
-                if (sy >= 0 && sx >= 0) v = xb[ch * plane + (size_t)sy * W + sx];
-            }
-            Z[ch * K::CS + r * K::RS + q] = v;
-        }
-        for (int idx = tid; idx < TH * TW; idx += kThreads) {
-            const int q = idx % TW, r = idx / TW, gy = ty0 + r, gx = tx0 + q;
-            float m = 0.0f;
-            if (gy < H && gx < W) {
-                const size_t cell = (size_t)b * plane + (size_t)gy * W + gx;
-                const float uu = a.u ? a.u[cell] : nca_philox_cell(a.seed, a.step, cell);
-                m = floorf(uu + a.rate);  // dynca.py:131
-            }
-            MK[idx] = m;
-        }
+        // ---- issue every global load of the tile, then retire the previous tile ---------
+        // (staging index made opaque per tile: its derived coordinates are recomputed here rather than
+        //  hoisted out of the tile loop and kept live -- or spilled -- across the MFMA phase)
+        int st = tid;
+        asm volatile("" : "+v"(st));
+        const int half = st >> 7;
+        Pos ps;
+        ps.template init<VEC>(st, ty0, tx0, H, W, a.pad_mode);
+        float xv[K::CPH][4];
+        pos_load<K::CPH>(ps, xb, (unsigned)plane, half * K::CPH, 0, C, xv);
+        const int cr = st / TW, cq = st % TW, cgy = ty0 + cr, cgx = tx0 + cq;  // this thread's cell
+        const bool cin = cgy < H && cgx < W;
+        const size_t cell = (size_t)b * plane + (cin ? (size_t)cgy * W + cgx : 0);
+        float uu = 0.0f, cnv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (a.u) uu = a.u[cell];
         if (HAS_COND) {
-            for (int idx = tid; idx < 4 * TH * TW; idx += kThreads) {
-                const int q = idx % TW, r = (idx / TW) % TH, cc = idx / (TH * TW);
-                const int gy = ty0 + r, gx = tx0 + q;
-                CN[idx] = (cc < CC && gy < H && gx < W)
-                              ? a.cond[((size_t)b * CC + cc) * plane + (size_t)gy * W + gx] : 0.0f;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+                cnv[cc] = a.cond[((size_t)b * CC + min(cc, CC - 1)) * plane + (cell - (size_t)b * plane)];
+        }
+        __syncthreads();  // previous tile fully consumed (also orders the weight image on iter 0)
+        if (ps.active) {
+#pragma unroll
+            for (int c = 0; c < K::CPH; ++c) {
+                const int ch = half * K::CPH + c;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (ch < C && ps.ev[j]) ? xv[c][j] : 0.0f;
+                pos_store(ps, Z + ch * K::CS, v);
             }
+        }
+        if (!a.u) uu = nca_philox_cell(a.seed, a.step, cell);
+        MK[st] = cin ? floorf(uu + a.rate) : 0.0f;  // dynca.py:131
+        if (HAS_COND) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) CN[cc * TH * TW + st] = (cin && cc < CC) ? cnv[cc] : 0.0f;
         }
         __syncthreads();
 
@@ -150,8 +251,8 @@ __global__ __launch_bounds__(kThreads, 2) void dynca_step_fwd_kernel(const NcaDy
             // ---- perception: B operands of layer 1 ---------------------------------------
             float P[NT][K::K1S];
 #pragma unroll
-            for (int cq = 0; cq < CP / 4; ++cq) {
-                const float* const zc = Z + (4 * cq + g) * K::CS;
+            for (int cq4 = 0; cq4 < CP / 4; ++cq4) {
+                const float* const zc = Z + (4 * cq4 + g) * K::CS + 3;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     float nb[3][3];
@@ -159,10 +260,10 @@ __global__ __launch_bounds__(kThreads, 2) void dynca_step_fwd_kernel(const NcaDy
                     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                         for (int dx = 0; dx < 3; ++dx) nb[dy][dx] = zc[(r0[n] + dy) * K::RS + q0[n] + dx];
-                    P[n][4 * cq + 0] = nb[1][1];
-                    P[n][4 * cq + 1] = nca_sobel_x(nb);
-                    P[n][4 * cq + 2] = nca_sobel_y(nb);
-                    P[n][4 * cq + 3] = nca_laplacian(nb);
+                    P[n][4 * cq4 + 0] = nb[1][1];
+                    P[n][4 * cq4 + 1] = nca_sobel_x(nb);
+                    P[n][4 * cq4 + 2] = nca_sobel_y(nb);
+                    P[n][4 * cq4 + 3] = nca_laplacian(nb);
                 }
             }
             if (HAS_COND) {
@@ -215,7 +316,7 @@ __global__ __launch_bounds__(kThreads, 2) void dynca_step_fwd_kernel(const NcaDy
                         for (int r = 0; r < 4; ++r) {
                             const int ch = 16 * m2 + 4 * g + r;
                             if (ch < C) {
-                                const float xo = Z[ch * K::CS + (r0[n] + 1) * K::RS + q0[n] + 1];
+                                const float xo = Z[ch * K::CS + (r0[n] + 1) * K::RS + q0[n] + 4];
                                 ob[ch * plane] = xo + acc2[m2][n][r] * mk;
                             }
                         }
@@ -233,14 +334,19 @@ struct CondCfg {
     static constexpr int HID = 64;
     static constexpr int K1S = 3 * CP / 4;
     static constexpr int M3T = (CP + 15) / 16;
-    static constexpr int ROWS = TH + 2, RS = TW + 2;
+    static constexpr int ROWS = TH + 2, RS = TW + 8;
     static constexpr int CS = lds_cs(ROWS, RS);
+    static constexpr int PNS = TW + 2;                // pre-mask tile, halo 1
     static constexpr int A3R = TH + 6, A3S = TW + 6;  // alpha', halo 3
     static constexpr int L2R = TH + 4, L2S = TW + 4;  // life / resolved alpha, halo 2
-    static constexpr int WPS = 28;                    // 27 taps padded
+    static constexpr int NA3 = A3R * A3S, NL2 = L2R * L2S, NPN = ROWS * PNS;
+    static constexpr int KA3 = (NA3 + kThreads - 1) / kThreads, KL2 = (NL2 + kThreads - 1) / kThreads,
+                         KPN = (NPN + kThreads - 1) / kThreads;
+    static constexpr int WPS = 28;  // 27 taps padded
     static constexpr int TWN = TW / 16;
     static constexpr int NTILES16 = TH * TW / 16;
     static constexpr int ITERS = NTILES16 / (4 * NT);
+    static constexpr int CPH = CP / 2;
     static constexpr int OFF_W1 = 0;
     static constexpr int OFF_W2 = OFF_W1 + 4 * K1S * 64;
     static constexpr int OFF_W3 = OFF_W2 + 4 * 16 * 64;
@@ -249,13 +355,13 @@ struct CondCfg {
     static constexpr int OFF_WP = OFF_B2 + HID;
     static constexpr int OFF_Z = OFF_WP + CP * WPS;
     static constexpr int OFF_A3 = OFF_Z + CP * CS;
-    static constexpr int OFF_LIFE = OFF_A3 + A3R * A3S;
-    static constexpr int OFF_A2 = OFF_LIFE + L2R * L2S;
-    static constexpr int OFF_PN = OFF_A2 + L2R * L2S;
-    static constexpr int OFF_MK = OFF_PN + ROWS * RS;
+    static constexpr int OFF_LIFE = OFF_A3 + NA3;
+    static constexpr int OFF_A2 = OFF_LIFE + NL2;
+    static constexpr int OFF_PN = OFF_A2 + NL2;
+    static constexpr int OFF_MK = OFF_PN + NPN;
     static constexpr int LDS_FLOATS = OFF_MK + TH * TW;
     static_assert(CP % 4 == 0 && TW % 16 == 0 && NTILES16 % (4 * NT) == 0, "shape");
-    static_assert(OFF_Z % 4 == 0 && OFF_WP % 4 == 0, "16-byte carve");
+    static_assert(OFF_Z % 4 == 0 && OFF_WP % 4 == 0 && CS % 4 == 0 && TH * TW == kThreads, "16-byte carve");
 };
 
 __device__ __forceinline__ float nca_max3x3(const float* p, int stride) {
@@ -263,11 +369,11 @@ __device__ __forceinline__ float nca_max3x3(const float* p, int stride) {
     m = fmaxf(m, fmaxf(fmaxf(p[-1], p[0]), p[1]));
     return fmaxf(m, fmaxf(fmaxf(p[stride - 1], p[stride]), p[stride + 1]));
 }
-__device__ __forceinline__ float nca_clamp(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
-template <int CP, int TH, int TW, int NT>
+template <int CP, int TH, int TW, int NT, bool VEC>
 __global__ __launch_bounds__(kThreads, 2) void cond_step_fwd_kernel(const NcaCondArgs a) {
     using K = CondCfg<CP, TH, TW, NT>;
+    using Pos = TilePos<TH, TW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const W1L = smem + K::OFF_W1;
     float* const W2L = smem + K::OFF_W2;
@@ -288,33 +394,32 @@ __global__ __launch_bounds__(kThreads, 2) void cond_step_fwd_kernel(const NcaCon
     const int gch0 = C - a.goal_ch;  // first channel the goal encoding is added to (nca.py:199-203)
     const bool pending = a.pre_in != nullptr;
     const bool use_alive = a.alive_ch >= 0;
+    const bool has_goal = a.goal_ch > 0;
 
-    for (int idx = tid; idx < 4 * K::K1S * 64; idx += kThreads) {
+    fill_image<4 * K::K1S * 64>(W1L, a.w1, tid, [&](int idx) -> long {
         const int l = idx & 63, s = (idx >> 6) % K::K1S, m = (idx >> 6) / K::K1S;
         const int gg = l >> 4, o = 16 * m + (l & 15);
         const int ch = 4 * (s / 3) + gg, f = s % 3;  // k-step s = 3c'+f : channel 4c'+g, filter f
-        W1L[idx] = (ch < C && o < hid) ? a.w1[(size_t)o * K1 + 3 * ch + f] : 0.0f;  // out[3c+f], nca.py:99-107
-    }
-    for (int idx = tid; idx < 4 * 16 * 64; idx += kThreads) {
+        return (ch < C && o < hid) ? (long)o * K1 + 3 * ch + f : -1;  // out[3c+f], nca.py:99-107
+    });
+    fill_image<4 * 16 * 64>(W2L, a.w2, tid, [&](int idx) -> long {
         const int l = idx & 63, s = (idx >> 6) % 16, m = (idx >> 6) / 16;
         const int gg = l >> 4, o = 16 * m + (l & 15);
         const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
-        W2L[idx] = (o < hid && k < hid) ? a.w2[(size_t)o * hid + k] : 0.0f;
-    }
-    for (int idx = tid; idx < K::M3T * 16 * 64; idx += kThreads) {
+        return (o < hid && k < hid) ? (long)o * hid + k : -1;
+    });
+    fill_image<K::M3T * 16 * 64>(W3L, a.w3, tid, [&](int idx) -> long {
         const int l = idx & 63, s = (idx >> 6) % 16, m = (idx >> 6) / 16;
         const int gg = l >> 4, o = 16 * m + (l & 15);
         const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
-        W3L[idx] = (o < C && k < hid) ? a.w3[(size_t)o * hid + k] : 0.0f;
-    }
-    for (int idx = tid; idx < K::HID; idx += kThreads) {
-        B1L[idx] = idx < hid ? a.b1[idx] : 0.0f;
-        B2L[idx] = idx < hid ? a.b2[idx] : 0.0f;
-    }
-    for (int idx = tid; idx < CP * K::WPS; idx += kThreads) {
+        return (o < C && k < hid) ? (long)o * hid + k : -1;
+    });
+    fill_image<K::HID>(B1L, a.b1, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
+    fill_image<K::HID>(B2L, a.b2, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
+    fill_image<CP * K::WPS>(WPL, a.wp, tid, [&](int idx) -> long {
         const int ch = idx / K::WPS, j = idx % K::WPS;
-        WPL[idx] = (ch < C && j < 27) ? a.wp[(size_t)ch * 27 + j] : 0.0f;  // [3c+f][3][3] == [c][f*9+tap]
-    }
+        return (ch < C && j < 27) ? (long)ch * 27 + j : -1;  // [3c+f][3][3] == [c][f*9+tap]
+    });
 
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int ntiles = a.B * tiles_x * tiles_y;
@@ -325,78 +430,134 @@ __global__ __launch_bounds__(kThreads, 2) void cond_step_fwd_kernel(const NcaCon
         const int ty0 = tyi * TH, tx0 = txi * TW;
         const float* const xb = a.x_in + (size_t)b * C * plane;
 
-        __syncthreads();
-        // ---- S1: alpha' (halo 3, -inf outside the image = max_pool2d padding) + pre_in (halo 2)
+        // ---- issue every global load of the tile ------------------------------------------
+        // (staging index made opaque per tile so its derived coordinates are recomputed, not kept
+        //  live -- or spilled -- across the MFMA phase)
+        int st = tid;
+        asm volatile("" : "+v"(st));
+        const int half = st >> 7;
+        // alpha' (halo 3), pre_in (halo 2), u: needed first
+        float a3v[K::KA3];
+        bool a3in[K::KA3];
         if (use_alive) {
-            for (int idx = tid; idx < K::A3R * K::A3S; idx += kThreads) {
+#pragma unroll
+            for (int k = 0; k < K::KA3; ++k) {
+                const int idx = st + k * kThreads;
                 const int q = idx % K::A3S, r = idx / K::A3S, gy = ty0 - 3 + r, gx = tx0 - 3 + q;
-                A3[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                              ? xb[a.alive_ch * plane + (size_t)gy * W + gx] : NCA_NEG_INF;
+                a3in[k] = idx < K::NA3 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                a3v[k] = xb[a.alive_ch * plane + (a3in[k] ? (size_t)gy * W + gx : 0)];
             }
         }
-        for (int idx = tid; idx < K::L2R * K::L2S; idx += kThreads) {
+        float l2v[K::KL2];
+        bool l2in[K::KL2];
+#pragma unroll
+        for (int k = 0; k < K::KL2; ++k) {
+            const int idx = st + k * kThreads;
             const int q = idx % K::L2S, r = idx / K::L2S, gy = ty0 - 2 + r, gx = tx0 - 2 + q;
-            float v = 0.0f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = (pending && use_alive) ? (float)a.pre_in[(size_t)b * plane + (size_t)gy * W + gx] : 1.0f;
-            LIFE[idx] = v;
+            l2in[k] = idx < K::NL2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            l2v[k] = 1.0f;
+            if (pending && use_alive) l2v[k] = (float)a.pre_in[(size_t)b * plane + (l2in[k] ? (size_t)gy * W + gx : 0)];
+        }
+        const int cr = st / TW, cq = st % TW, cgy = ty0 + cr, cgx = tx0 + cq;  // this thread's cell
+        const bool cin = cgy < H && cgx < W;
+        const size_t cell = (size_t)b * plane + (cin ? (size_t)cgy * W + cgx : 0);
+        float uu = 0.0f;
+        if (a.u) uu = a.u[cell];
+        // state tile + goal encoding (halo 1): one position per thread, channels split over the two halves
+        Pos ps;
+        ps.template init<VEC>(st, ty0, tx0, H, W, NCA_PAD_ZERO);
+        float xv[K::CPH][4], gv[K::CPH][4];
+        pos_load<K::CPH>(ps, xb, (unsigned)plane, half * K::CPH, 0, C, xv);
+        if (has_goal)  // slot c holds goal plane (half*CPH + c) - gch0 (used only when that index is >= 0)
+            pos_load<K::CPH>(ps, a.goal + (size_t)b * a.goal_ch * plane, (unsigned)plane, half * K::CPH, gch0, a.goal_ch, gv);
+
+        __syncthreads();  // previous tile fully consumed
+        // ---- S1: alpha' with -inf outside the image (= max_pool2d padding), pre_in -----------
+        if (use_alive) {
+#pragma unroll
+            for (int k = 0; k < K::KA3; ++k) {
+                const int idx = st + k * kThreads;
+                if (idx < K::NA3) A3[idx] = a3in[k] ? a3v[k] : NCA_NEG_INF;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K::KL2; ++k) {
+            const int idx = st + k * kThreads;
+            if (idx < K::NL2) LIFE[idx] = l2in[k] ? l2v[k] : 0.0f;
         }
         __syncthreads();
         // ---- S2: life = pre & post of the PREVIOUS step; resolved alpha (nca.py:191-194) ----
         if (use_alive) {
-            for (int idx = tid; idx < K::L2R * K::L2S; idx += kThreads) {
-                const int q = idx % K::L2S, r = idx / K::L2S, gy = ty0 - 2 + r, gx = tx0 - 2 + q;
-                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                const float* const ac = A3 + (r + 1) * K::A3S + q + 1;
-                float life = LIFE[idx], av = NCA_NEG_INF;
-                if (in) {
-                    if (pending) {
-                        life = (life != 0.0f && nca_max3x3(ac, K::A3S) > a.thr) ? 1.0f : 0.0f;
-                        av = nca_clamp(ac[0] * life, a.lo, a.hi);
-                    } else {
-                        av = ac[0];
+#pragma unroll
+            for (int k = 0; k < K::KL2; ++k) {
+                const int idx = st + k * kThreads;
+                if (idx < K::NL2) {
+                    const int q = idx % K::L2S, r = idx / K::L2S;
+                    const float* const ac = A3 + (r + 1) * K::A3S + q + 1;
+                    float life = l2in[k] ? l2v[k] : 0.0f, av = NCA_NEG_INF;
+                    if (l2in[k]) {
+                        if (pending) {
+                            life = (life != 0.0f && nca_max3x3(ac, K::A3S) > a.thr) ? 1.0f : 0.0f;
+                            av = nca_clamp(ac[0] * life, a.lo, a.hi);
+                        } else {
+                            av = ac[0];
+                        }
                     }
+                    LIFE[idx] = life;
+                    A2[idx] = av;
                 }
-                LIFE[idx] = life;
-                A2[idx] = av;
             }
         }
         __syncthreads();
         // ---- S3: pre-life mask of THIS step (halo 1), fire mask --------------------------
-        for (int idx = tid; idx < K::ROWS * K::RS; idx += kThreads) {
-            const int q = idx % K::RS, r = idx / K::RS, gy = ty0 - 1 + r, gx = tx0 - 1 + q;
-            float pn = 0.0f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                pn = (!use_alive || nca_max3x3(A2 + (r + 1) * K::L2S + q + 1, K::L2S) > a.thr) ? 1.0f : 0.0f;
-                if (r >= 1 && r <= TH && q >= 1 && q <= TW)
-                    a.pre_out[(size_t)b * plane + (size_t)gy * W + gx] = (uint8_t)pn;
+#pragma unroll
+        for (int k = 0; k < K::KPN; ++k) {
+            const int idx = st + k * kThreads;
+            if (idx < K::NPN) {
+                const int q = idx % K::PNS, r = idx / K::PNS, gy = ty0 - 1 + r, gx = tx0 - 1 + q;
+                float pn = 0.0f;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    pn = (!use_alive || nca_max3x3(A2 + (r + 1) * K::L2S + q + 1, K::L2S) > a.thr) ? 1.0f : 0.0f;
+                    if (r >= 1 && r <= TH && q >= 1 && q <= TW)
+                        a.pre_out[(size_t)b * plane + (size_t)gy * W + gx] = (uint8_t)pn;
+                }
+                PN[idx] = pn;
             }
-            PN[idx] = pn;
         }
-        for (int idx = tid; idx < TH * TW; idx += kThreads) {
-            const int q = idx % TW, r = idx / TW, gy = ty0 + r, gx = tx0 + q;
-            float m = 0.0f;
-            if (gy < H && gx < W) {
-                const size_t cell = (size_t)b * plane + (size_t)gy * W + gx;
-                const float uu = a.u ? a.u[cell] : nca_philox_cell(a.seed, a.step, cell);
-                m = (nca_clamp(uu, 0.0f, 1.0f) < a.fire_rate) ? 1.0f : 0.0f;  // nca.py:171-174
-            }
-            MK[idx] = m;
-        }
+        if (!a.u) uu = nca_philox_cell(a.seed, a.step, cell);
+        MK[st] = (cin && nca_clamp(uu, 0.0f, 1.0f) < a.fire_rate) ? 1.0f : 0.0f;  // nca.py:171-174
         __syncthreads();
         // ---- S4: z = x + goal * pre (nca.py:177) on halo 1, zero outside the image -------
-        for (int idx = tid; idx < CP * K::ROWS * K::RS; idx += kThreads) {
-            const int q = idx % K::RS, r = (idx / K::RS) % K::ROWS, ch = idx / (K::RS * K::ROWS);
-            const int gy = ty0 - 1 + r, gx = tx0 - 1 + q;
-            float v = 0.0f;
-            if (ch < C && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const size_t off = (size_t)gy * W + gx;
-                v = xb[ch * plane + off];
-                if (pending) v = nca_clamp(v * LIFE[(r + 1) * K::L2S + q + 1], a.lo, a.hi);
-                if (ch >= gch0)
-                    v = fmaf(a.goal[((size_t)b * a.goal_ch + (ch - gch0)) * plane + off], PN[r * K::RS + q], v);
+        if (ps.active) {
+            const float* const lf = LIFE + (ps.r + 1) * K::L2S + ps.q + 1;
+            const float* const pnp = PN + ps.r * K::PNS + ps.q;
+            float lfv[4], pnv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool rd = ps.interior || j == 0;
+                lfv[j] = rd ? lf[j] : 0.0f;
+                pnv[j] = rd ? pnp[j] : 0.0f;
             }
-            Z[ch * K::CS + r * K::RS + q] = v;
+#pragma unroll
+            for (int c = 0; c < K::CPH; ++c) {
+                const int ch = half * K::CPH + c;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = 0.0f;
+                    if (ch < C && ps.ev[j]) {
+                        t = xv[c][j];
+                        if (pending) t = nca_clamp(t * lfv[j], a.lo, a.hi);
+                    }
+                    v[j] = t;
+                }
+                if (has_goal && ch >= gch0 && ch < C) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (ps.ev[j]) v[j] = fmaf(gv[c][j], pnv[j], v[j]);
+                }
+                pos_store(ps, Z + ch * K::CS, v);
+            }
         }
         __syncthreads();
 
@@ -412,12 +573,12 @@ __global__ __launch_bounds__(kThreads, 2) void cond_step_fwd_kernel(const NcaCon
             // ---- learned depthwise perception (nca.py:99-107): P[3c'+f] for channel 4c'+g
             float P[NT][K::K1S];
 #pragma unroll
-            for (int cq = 0; cq < CP / 4; ++cq) {
-                const float* const zc = Z + (4 * cq + g) * K::CS;
+            for (int cq4 = 0; cq4 < CP / 4; ++cq4) {
+                const float* const zc = Z + (4 * cq4 + g) * K::CS + 3;
                 float wt[28];
 #pragma unroll
                 for (int j4 = 0; j4 < 7; ++j4) {
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(WPL + (4 * cq + g) * K::WPS + 4 * j4);
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(WPL + (4 * cq4 + g) * K::WPS + 4 * j4);
                     wt[4 * j4 + 0] = w4[0]; wt[4 * j4 + 1] = w4[1]; wt[4 * j4 + 2] = w4[2]; wt[4 * j4 + 3] = w4[3];
                 }
 #pragma unroll
@@ -432,7 +593,7 @@ __global__ __launch_bounds__(kThreads, 2) void cond_step_fwd_kernel(const NcaCon
                         float acc = 0.0f;
 #pragma unroll
                         for (int t = 0; t < 9; ++t) acc = fmaf(wt[9 * f + t], nb[t], acc);
-                        P[n][3 * cq + f] = acc;
+                        P[n][3 * cq4 + f] = acc;
                     }
                 }
             }
@@ -496,15 +657,20 @@ __global__ __launch_bounds__(kThreads, 2) void cond_step_fwd_kernel(const NcaCon
                     const float life = LIFE[(r0[n] + 2) * K::L2S + q0[n] + 2];
                     const size_t off = (size_t)gy * W + gx;
                     float* const ob = a.x_out + (size_t)b * C * plane + off;
+                    float xo[K::M3T][4];
+#pragma unroll
+                    for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xo[m3][r] = xb[min(16 * m3 + 4 * g + r, C - 1) * plane + off];
 #pragma unroll
                     for (int m3 = 0; m3 < K::M3T; ++m3)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int ch = 16 * m3 + 4 * g + r;
                             if (ch < C) {
-                                float xo = xb[ch * plane + off];
-                                if (pending) xo = nca_clamp(xo * life, a.lo, a.hi);
-                                ob[ch * plane] = xo + mk * acc3[m3][n][r];
+                                float x0 = xo[m3][r];
+                                if (pending) x0 = nca_clamp(x0 * life, a.lo, a.hi);
+                                ob[ch * plane] = x0 + mk * acc3[m3][n][r];
                             }
                         }
                 }
@@ -521,20 +687,49 @@ hipError_t set_lds(KernelT kern, size_t bytes) {
 }
 
 int grid_for(int ntiles, int wg_per_cu) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    static thread_local int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
     }
     const int cap = cus * wg_per_cu;
     return ntiles < cap ? ntiles : cap;
 }
 
-template <int CP, int FC, bool HAS_COND>
-hipError_t launch_dynca(const NcaDyncaArgs& a, hipStream_t st) {
+bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+template <int CP, int FC, bool HAS_COND, bool VEC>
+hipError_t launch_dynca_v(const NcaDyncaArgs& a, hipStream_t st) {
     constexpr int TH = 8, TW = 32, NT = 4;
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
-    auto kern = dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT>;
+    auto kern = dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, VEC>;
+    const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
+    static thread_local bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = set_lds(kern, lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int ntiles = a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+    const int grid = grid_for(ntiles, lds * 2 <= 160 * 1024 ? 2 : 1);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, a);
+    return hipGetLastError();
+}
+
+template <int CP, int FC, bool HAS_COND>
+hipError_t launch_dynca(const NcaDyncaArgs& a, hipStream_t st) {
+    const bool vec = (a.W % 4 == 0) && aligned16(a.x_in) && (((size_t)a.H * a.W) % 4 == 0);
+    return vec ? launch_dynca_v<CP, FC, HAS_COND, true>(a, st) : launch_dynca_v<CP, FC, HAS_COND, false>(a, st);
+}
+
+template <int CP, bool VEC>
+hipError_t launch_cond_v(const NcaCondArgs& a, hipStream_t st) {
+    constexpr int TH = 8, TW = 32, NT = 4;
+    using K = CondCfg<CP, TH, TW, NT>;
+    auto kern = cond_step_fwd_kernel<CP, TH, TW, NT, VEC>;
     const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
     static thread_local bool attr_done = false;
     if (!attr_done) {
@@ -550,20 +745,8 @@ hipError_t launch_dynca(const NcaDyncaArgs& a, hipStream_t st) {
 
 template <int CP>
 hipError_t launch_cond(const NcaCondArgs& a, hipStream_t st) {
-    constexpr int TH = 8, TW = 32, NT = 4;
-    using K = CondCfg<CP, TH, TW, NT>;
-    auto kern = cond_step_fwd_kernel<CP, TH, TW, NT>;
-    const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
-    static thread_local bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = set_lds(kern, lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    const int ntiles = a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
-    const int grid = grid_for(ntiles, lds * 2 <= 160 * 1024 ? 2 : 1);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, a);
-    return hipGetLastError();
+    const bool vec = (a.W % 4 == 0) && aligned16(a.x_in) && (a.goal == nullptr || aligned16(a.goal));
+    return vec ? launch_cond_v<CP, true>(a, st) : launch_cond_v<CP, false>(a, st);
 }
 
 }  // namespace
