@@ -44,6 +44,10 @@ const char *ncahip_last_error(void);
 /* Largest shapes the fused step kernels accept (C <= max_c, fc <= max_fc, hidden <= 64). */
 int ncahip_limits(int *max_c, int *max_fc, int *max_hidden);
 
+/* Test hook (process-wide): on != 0 routes every fused step through the generic any-shape kernels
+ * instead of the aligned fast paths, so both can be checked against the oracle on the same inputs. */
+int ncahip_debug_force_generic(int on);
+
 /* Device-side check that the MFMA operand/accumulator lane maps the kernels assume hold on
  * this GPU (exact integer data, asymmetric B).  `scratch` >= 4096 bytes of device memory;
  * returns 0 and writes 1 to ((int*)scratch)[0] when the maps hold.  Synchronises `stream`. */

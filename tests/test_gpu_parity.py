@@ -13,12 +13,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.fixture(scope="module")
-def ops():
+@pytest.fixture(scope="module", params=["fast", "generic"])
+def ops(request):
+    """Every parity test runs twice: aligned fast-path kernels where the shape allows, and with the
+    generic any-shape kernels forced (ncahip_debug_force_generic)."""
     assert torch.cuda.is_available(), "gpu tests need the MI355X"
     from ncahip import ops as _ops
     _ops.selftest()
-    return _ops
+    _ops.force_generic(request.param == "generic")
+    yield _ops
+    _ops.force_generic(False)
 
 
 def dyn_w(ops, prm, like):

@@ -66,6 +66,11 @@ extern "C" {
 int ncahip_version(void) { return NCAHIP_VERSION; }
 const char* ncahip_last_error(void) { return g_err; }
 
+int ncahip_debug_force_generic(int on) {
+    nca_set_force_generic(on != 0);
+    return 0;
+}
+
 int ncahip_limits(int* max_c, int* max_fc, int* max_hidden) {
     if (max_c) *max_c = kMaxC;
     if (max_fc) *max_fc = kMaxFc;

@@ -1,0 +1,443 @@
+// nca_cond_wave.hip -- ConditionedNCA fused step, wave-private tiles (gfx950, fp32 exact).
+//
+// Same math and MFMA mapping as nca_step_fwd.hip (see its header), different work decomposition:
+// every WAVE owns a 4 x 16 cell tile and a private LDS region (state tile +1 halo, resolved-state
+// copy for the residual, alpha/life/pre masks); the 8 waves of a workgroup share only the
+// A-operand weight image.  There is no workgroup barrier inside the tile loop -- LDS hand-offs are
+// between lanes of one wave (in-order DS queue; only compiler ordering is needed) -- so the two
+// waves resident on a SIMD drift out of phase and one wave's loads / mask resolution / perception
+// VALU overlap the other's MFMA chain.  Index math is shifts of the lane id; tiles whose 3-cell
+// halo lies inside the image (85 % at 256^2) skip every bounds check.
+//
+// Requires W % 4 == 0 and 16-byte aligned tensors (16-byte row loads); other shapes take the
+// generic kernel in nca_step_fwd.hip.
+#include "nca_common.h"
+#include "nca_kernels.h"
+
+namespace {
+
+constexpr int kWaves = 8, kThreadsW = kWaves * 64;
+constexpr int WTH = 4, WTW = 16;  // wave tile
+constexpr int STH = 16, STW = 32; // super-tile of a workgroup: 4 x 2 wave tiles
+constexpr int RS = 24;            // LDS row stride of every per-wave 2-D array; image col tx0+c <-> index c+4
+constexpr int ZROWS = WTH + 2, CS = ZROWS * RS;  // 144 floats per channel (144 % 32 == 16)
+constexpr int XRS = 68;           // resolved-state copy: channel stride (4*68 % 32 == 16)
+static_assert(CS % 32 == 16 && (4 * XRS) % 32 == 16, "bank layout");
+
+template <int CP>
+struct WCfg {
+    static constexpr int HID = 64;
+    static constexpr int K1S = 3 * CP / 4;
+    static constexpr int M3T = (CP + 15) / 16;
+    static constexpr int WPS = 28;
+    // shared weight image (floats)
+    static constexpr int OFF_W1 = 0;
+    static constexpr int OFF_W2 = OFF_W1 + 4 * K1S * 64;
+    static constexpr int OFF_W3 = OFF_W2 + 4 * 16 * 64;
+    static constexpr int OFF_B1 = OFF_W3 + M3T * 16 * 64;
+    static constexpr int OFF_B2 = OFF_B1 + HID;
+    static constexpr int OFF_WP = OFF_B2 + HID;
+    static constexpr int SHARED = OFF_WP + CP * WPS;
+    // per-wave region (floats)
+    static constexpr int PW_Z = 0;
+    static constexpr int PW_XR = PW_Z + CP * CS;
+    static constexpr int PW_A3 = PW_XR + CP * XRS;       // alpha' rows ty0-3.. (10 rows); after the life mask is
+                                                         // resolved: rows 0-5 = PN, rows 6-9 = fire mask MK
+    static constexpr int PW_LIFE = PW_A3 + (WTH + 6) * RS;
+    static constexpr int PW_A2 = PW_LIFE + (WTH + 4) * RS;
+    static constexpr int PW = PW_A2 + (WTH + 4) * RS;
+    static constexpr int LDS_FLOATS = SHARED + kWaves * PW;
+    static_assert(CP % 4 == 0 && SHARED % 4 == 0 && PW % 4 == 0 && PW_XR % 4 == 0 && PW_A3 % 4 == 0, "16-byte carve");
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+};
+
+__device__ __forceinline__ float wclamp(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ float max3x3(const float* p) {
+    float m = fmaxf(fmaxf(p[-RS - 1], p[-RS]), p[-RS + 1]);
+    m = fmaxf(m, fmaxf(fmaxf(p[-1], p[0]), p[1]));
+    return fmaxf(m, fmaxf(fmaxf(p[RS - 1], p[RS]), p[RS + 1]));
+}
+// LDS hand-off between lanes of ONE wave: DS ops of a wave execute in order, so only the compiler
+// must be kept from moving accesses across this point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int N, typename MapT>
+__device__ __forceinline__ void fill_image_w(float* __restrict__ dst, const float* __restrict__ src, int tid, MapT map) {
+    constexpr int U = 8;
+    for (int base = tid; base < N; base += kThreadsW * U) {
+        float v[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + kThreadsW * u;
+            const long o = idx < N ? map(idx) : -1;
+            ok[u] = o >= 0;
+            v[u] = src[ok[u] ? o : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + kThreadsW * u;
+            if (idx < N) dst[idx] = ok[u] ? v[u] : 0.0f;
+        }
+    }
+}
+
+// One wave tile: stage -> resolve masks -> perception -> MLP -> store.  CHECK=false: the tile's
+// 3-cell halo is inside the image, no bounds logic at all.
+template <int CP, bool CHECK>
+__device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __restrict__ WS, float* __restrict__ PWR,
+                                          int b, int ty0, int tx0, int lane_in) {
+    using K = WCfg<CP>;
+    constexpr int NT = WTH;
+    const float* const W1L = WS + K::OFF_W1;
+    const float* const W2L = WS + K::OFF_W2;
+    const float* const W3L = WS + K::OFF_W3;
+    const float* const B1L = WS + K::OFF_B1;
+    const float* const B2L = WS + K::OFF_B2;
+    const float* const WPL = WS + K::OFF_WP;
+    float* const Z = PWR + K::PW_Z;
+    float* const XR = PWR + K::PW_XR;
+    float* const A3 = PWR + K::PW_A3;
+    float* const PN = PWR + K::PW_A3;  // A3 is dead once the life mask is resolved
+    float* const LIFE = PWR + K::PW_LIFE;
+    float* const A2 = PWR + K::PW_A2;
+    float* const MK = PWR + K::PW_A3 + ZROWS * RS;  // 64 floats in A3 rows 6-8
+
+    const int C = a.C, H = a.H, W = a.W;
+    const unsigned plane = (unsigned)(H * W);
+    const int gch0 = C - a.goal_ch;
+    const bool pending = a.pre_in != nullptr, use_alive = a.alive_ch >= 0, has_goal = a.goal_ch > 0;
+    const float* const xb = a.x_in + (size_t)b * C * plane;
+    const float* const gb = has_goal ? a.goal + (size_t)b * a.goal_ch * plane : a.x_in;
+    const size_t cell0 = (size_t)b * plane;
+
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));  // staging coordinates are recomputed per tile, not kept live across the MFMAs
+    const int hl = lane >> 5, l5 = lane & 31, q4 = lane >> 4, ci = lane & 15;
+
+    // ================= issue every global load of the tile ==================================
+    // alpha' halo 3: rows ty0-3+r (r = 2k+hl < 10), cols tx0-3+q (q = l5 < 22)
+    float a3v[5];
+    bool a3ok[5];
+    if (use_alive) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int gy = ty0 - 3 + 2 * k + hl, gx = tx0 - 3 + l5;
+            a3ok[k] = l5 < 22 && (!CHECK || (gy >= 0 && gy < H && gx >= 0 && gx < W));
+            a3v[k] = xb[(unsigned)a.alive_ch * plane + (a3ok[k] ? (unsigned)(gy * W + gx) : 0u)];
+        }
+    }
+    // previous step's pre mask, halo 2: rows ty0-2+r (r = 2k+hl < 8), cols tx0-2+q (q = l5 < 20)
+    float prv[4];
+    bool l2ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int gy = ty0 - 2 + 2 * k + hl, gx = tx0 - 2 + l5;
+        l2ok[k] = l5 < 20 && (!CHECK || (gy >= 0 && gy < H && gx >= 0 && gx < W));
+        prv[k] = 1.0f;
+        if (pending && use_alive) prv[k] = (float)a.pre_in[cell0 + (l2ok[k] ? (unsigned)(gy * W + gx) : 0u)];
+    }
+    // fire-mask uniform of this lane's cell (row q4, col ci)
+    const int cgy = ty0 + q4, cgx = tx0 + ci;
+    const bool cin = !CHECK || (cgy < H && cgx < W);
+    const size_t cell = cell0 + (cin ? (unsigned)(cgy * W + cgx) : 0u);
+    float uu = 0.0f;
+    if (a.u) uu = a.u[cell];
+    // state + goal, interior 16-byte groups: channel 2k+hl, position l5 < 24 -> row l5>>2 (halo-1 row), group l5&3
+    const int fr = l5 >> 2, ff = l5 & 3;
+    const int fgy = ty0 - 1 + fr, fgx = tx0 + 4 * ff;
+    const bool fok = l5 < 24 && (!CHECK || (fgy >= 0 && fgy < H && fgx + 3 < W));
+    const unsigned foff = fok ? (unsigned)(fgy * W + fgx) : 0u;
+    f32x4 xf[CP / 2], gf[CP / 2];
+#pragma unroll
+    for (int k = 0; k < CP / 2; ++k) xf[k] = ld4(xb + (unsigned)min(2 * k + hl, C - 1) * plane + foff);
+    if (has_goal) {
+#pragma unroll
+        for (int k = 0; k < CP / 2; ++k)
+            gf[k] = ld4(gb + (unsigned)min(max(2 * k + hl - gch0, 0), a.goal_ch - 1) * plane + foff);
+    }
+    // state + goal, halo columns: channel 4k+q4, slot ci < 12 -> row ci>>1, side ci&1
+    const int hr = ci >> 1, hside = ci & 1;
+    const int hgy = ty0 - 1 + hr, hgx = hside ? tx0 + WTW : tx0 - 1;
+    const bool hok = ci < 12 && (!CHECK || (hgy >= 0 && hgy < H && hgx >= 0 && hgx < W));
+    const unsigned hoff = hok ? (unsigned)(hgy * W + hgx) : 0u;
+    float xh[CP / 4], gh[CP / 4];
+#pragma unroll
+    for (int k = 0; k < CP / 4; ++k) xh[k] = xb[(unsigned)min(4 * k + q4, C - 1) * plane + hoff];
+    if (has_goal) {
+#pragma unroll
+        for (int k = 0; k < CP / 4; ++k)
+            gh[k] = gb[(unsigned)min(max(4 * k + q4 - gch0, 0), a.goal_ch - 1) * plane + hoff];
+    }
+
+    // ================= S1: alpha' (-inf outside the image == max_pool2d padding) ============
+    wave_sync();  // the previous tile's LDS reads (epilogue) are ordered before these writes
+    if (use_alive) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (l5 < 22) A3[(2 * k + hl) * RS + l5 + 1] = a3ok[k] ? a3v[k] : NCA_NEG_INF;
+        wave_sync();
+        // ============= S2: life = pre & post of the PREVIOUS step, resolved alpha (nca.py:191-194)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = 2 * k + hl;
+            const float* const ac = A3 + (r + 1) * RS + l5 + 2;
+            float life = 0.0f, av = NCA_NEG_INF;
+            if (l2ok[k]) {
+                life = 1.0f;
+                av = ac[0];
+                if (pending) {
+                    life = (prv[k] != 0.0f && max3x3(ac) > a.thr) ? 1.0f : 0.0f;
+                    av = wclamp(av * life, a.lo, a.hi);
+                }
+            }
+            if (l5 < 20) {
+                LIFE[r * RS + l5 + 2] = life;
+                A2[r * RS + l5 + 2] = av;
+            }
+        }
+        wave_sync();
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (l5 < 20) LIFE[(2 * k + hl) * RS + l5 + 2] = l2ok[k] ? 1.0f : 0.0f;
+    }
+    // ================= S3: pre-life mask of THIS step on halo 1; fire mask ===================
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int r = 2 * k + hl;  // halo-1 row, col q = l5 < 18
+        const int gy = ty0 - 1 + r, gx = tx0 - 1 + l5;
+        const bool in = l5 < 18 && (!CHECK || (gy >= 0 && gy < H && gx >= 0 && gx < W));
+        float pn = 0.0f;
+        if (in) pn = (!use_alive || max3x3(A2 + (r + 1) * RS + l5 + 3) > a.thr) ? 1.0f : 0.0f;
+        if (l5 < 18) PN[r * RS + l5 + 3] = pn;
+        if (in && r >= 1 && r <= WTH && l5 >= 1 && l5 <= WTW) a.pre_out[cell0 + (unsigned)(gy * W + gx)] = (uint8_t)pn;
+    }
+    if (!a.u) uu = nca_philox_cell(a.seed, a.step, cell);
+    MK[lane] = (cin && wclamp(uu, 0.0f, 1.0f) < a.fire_rate) ? 1.0f : 0.0f;  // nca.py:171-174
+    wave_sync();
+    // ================= S4: z = x + goal * pre (nca.py:177) on halo 1; resolved copy for the residual
+    if (l5 < 24) {
+        const f32x4 lf = ld4(LIFE + (fr + 1) * RS + 4 + 4 * ff);
+        const f32x4 pn = ld4(PN + fr * RS + 4 + 4 * ff);
+        const bool inner = fr >= 1 && fr <= WTH;
+#pragma unroll
+        for (int k = 0; k < CP / 2; ++k) {
+            const int ch = 2 * k + hl;
+            f32x4 v = xf[k];
+            if (pending) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = wclamp(v[j] * lf[j], a.lo, a.hi);
+            }
+            if ((CHECK && !fok) || ch >= C) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (has_goal && ch >= gch0 && ch < C) {
+                if (inner) st4(XR + (ch - gch0) * XRS + (fr - 1) * WTW + 4 * ff, v);
+                if (!CHECK || fok) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaf(gf[k][j], pn[j], v[j]);
+                }
+            }
+            st4(Z + ch * CS + fr * RS + 4 + 4 * ff, v);
+        }
+    }
+    if (ci < 12) {
+        const int zq = hside ? WTW + 4 : 3;
+        const float lf = LIFE[(hr + 1) * RS + zq], pn = PN[hr * RS + zq];
+#pragma unroll
+        for (int k = 0; k < CP / 4; ++k) {
+            const int ch = 4 * k + q4;
+            float v = xh[k];
+            if (pending) v = wclamp(v * lf, a.lo, a.hi);
+            if ((CHECK && !hok) || ch >= C) v = 0.0f;
+            else if (has_goal && ch >= gch0) v = fmaf(gh[k], pn, v);
+            Z[ch * CS + hr * RS + zq] = v;
+        }
+    }
+    wave_sync();
+
+    // ================= perception + UpdateNet on MFMA (identical mapping to nca_step_fwd.hip) ==
+    const int g = q4;
+    float P[NT][K::K1S];
+#pragma unroll
+    for (int c4 = 0; c4 < CP / 4; ++c4) {
+        const float* const zc = Z + (4 * c4 + g) * CS + ci + 3;
+        float wt[28];
+#pragma unroll
+        for (int j4 = 0; j4 < 7; ++j4) {
+            const f32x4 w4 = ld4(WPL + (4 * c4 + g) * K::WPS + 4 * j4);
+            wt[4 * j4 + 0] = w4[0]; wt[4 * j4 + 1] = w4[1]; wt[4 * j4 + 2] = w4[2]; wt[4 * j4 + 3] = w4[3];
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            float nb[9];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) nb[3 * dy + dx] = zc[(n + dy) * RS + dx];
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc = fmaf(wt[9 * f + t], nb[t], acc);
+                P[n][3 * c4 + f] = acc;
+            }
+        }
+    }
+    f32x4 acc2[4][NT];
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2) {
+        const f32x4 bias = ld4(B2L + 16 * m2 + 4 * g);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc2[m2][n] = bias;
+    }
+#pragma unroll 1
+    for (int m = 0; m < 4; ++m) {
+        const float* const w1m = W1L + m * K::K1S * 64 + lane_in;
+        const f32x4 bias = ld4(B1L + 16 * m + 4 * g);
+        f32x4 acc1[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc1[n] = bias;
+#pragma unroll
+        for (int s = 0; s < K::K1S; ++s) {
+            const float wa = w1m[s * 64];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc1[n] = nca_mfma(wa, P[n][s], acc1[n]);
+        }
+        const float* const w2m = W2L + (4 * m) * 64 + lane_in;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int m2 = 0; m2 < 4; ++m2) {
+                const float wa = w2m[(m2 * 16 + r) * 64];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc2[m2][n] = nca_mfma(wa, fmaxf(acc1[n][r], 0.0f), acc2[m2][n]);
+            }
+        }
+    }
+    f32x4 acc3[K::M3T][NT];
+#pragma unroll
+    for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc3[m3][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // out.4 has no bias
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int m3 = 0; m3 < K::M3T; ++m3) {
+                const float wa = W3L[(m3 * 16 + 4 * m + r) * 64 + lane_in];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc3[m3][n] = nca_mfma(wa, fmaxf(acc2[m][n][r], 0.0f), acc3[m3][n]);
+            }
+        }
+    }
+    // ================= x' = x + rand_mask * out (nca.py:189); stays pending ===================
+    float* const ob = a.x_out + (size_t)b * C * plane;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int gy = ty0 + n, gx = tx0 + ci;
+        if (!CHECK || (gy < H && gx < W)) {
+            const float mk = MK[n * WTW + ci];
+            const unsigned off = (unsigned)(gy * W + gx);
+#pragma unroll
+            for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = 16 * m3 + 4 * g + r;
+                    if (ch < C) {
+                        const float xo = (has_goal && ch >= gch0) ? XR[(ch - gch0) * XRS + n * WTW + ci]
+                                                                  : Z[ch * CS + (n + 1) * RS + ci + 4];
+                        ob[(unsigned)ch * plane + off] = xo + mk * acc3[m3][n][r];
+                    }
+                }
+        }
+    }
+}
+
+template <int CP>
+__global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_wave_kernel(const NcaCondArgs a) {
+    using K = WCfg<CP>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = a.C, H = a.H, W = a.W, hid = a.hidden, K1 = 3 * C;
+
+    fill_image_w<4 * K::K1S * 64>(smem + K::OFF_W1, a.w1, tid, [&](int idx) -> long {
+        const int l = idx & 63, s = (idx >> 6) % K::K1S, m = (idx >> 6) / K::K1S;
+        const int gg = l >> 4, o = 16 * m + (l & 15);
+        const int ch = 4 * (s / 3) + gg, f = s % 3;  // k-step s = 3c'+f : channel 4c'+g, filter f
+        return (ch < C && o < hid) ? (long)o * K1 + 3 * ch + f : -1;  // out[3c+f], nca.py:99-107
+    });
+    fill_image_w<4 * 16 * 64>(smem + K::OFF_W2, a.w2, tid, [&](int idx) -> long {
+        const int l = idx & 63, s = (idx >> 6) % 16, m = (idx >> 6) / 16;
+        const int gg = l >> 4, o = 16 * m + (l & 15);
+        const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
+        return (o < hid && k < hid) ? (long)o * hid + k : -1;
+    });
+    fill_image_w<K::M3T * 16 * 64>(smem + K::OFF_W3, a.w3, tid, [&](int idx) -> long {
+        const int l = idx & 63, s = (idx >> 6) % 16, m = (idx >> 6) / 16;
+        const int gg = l >> 4, o = 16 * m + (l & 15);
+        const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
+        return (o < C && k < hid) ? (long)o * hid + k : -1;
+    });
+    fill_image_w<K::HID>(smem + K::OFF_B1, a.b1, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
+    fill_image_w<K::HID>(smem + K::OFF_B2, a.b2, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
+    fill_image_w<CP * K::WPS>(smem + K::OFF_WP, a.wp, tid, [&](int idx) -> long {
+        const int ch = idx / K::WPS, j = idx % K::WPS;
+        return (ch < C && j < 27) ? (long)ch * 27 + j : -1;  // [3c+f][3][3] == [c][f*9+tap]
+    });
+    __syncthreads();  // the only workgroup barrier: weight image complete
+
+    float* const PWR = smem + K::SHARED + wave * K::PW;
+    const int st_x = (W + STW - 1) / STW, st_y = (H + STH - 1) / STH;
+    const int nst = a.B * st_x * st_y;
+    const int halo = a.alive_ch >= 0 ? 3 : 1;
+    for (NcaTileWalk tw = nca_tile_walk(nst); tw.t < tw.end; tw.t += tw.stride) {
+        const int sxi = tw.t % st_x, syi = (tw.t / st_x) % st_y, b = tw.t / (st_x * st_y);
+        const int ty0 = syi * STH + (wave >> 1) * WTH, tx0 = sxi * STW + (wave & 1) * WTW;
+        if (ty0 >= H || tx0 >= W) continue;  // wave-uniform; no workgroup barrier below
+        const bool inner = ty0 >= halo && ty0 + WTH + halo <= H && tx0 >= halo && tx0 + WTW + halo <= W;
+        if (inner) wave_tile<CP, false>(a, smem, PWR, b, ty0, tx0, lane);
+        else wave_tile<CP, true>(a, smem, PWR, b, ty0, tx0, lane);
+    }
+}
+
+template <int CP>
+hipError_t launch_cond_wave(const NcaCondArgs& a, hipStream_t st) {
+    using K = WCfg<CP>;
+    auto kern = cond_step_fwd_wave_kernel<CP>;
+    const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
+    static thread_local bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    static thread_local int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
+    }
+    const int nst = a.B * ((a.W + STW - 1) / STW) * ((a.H + STH - 1) / STH);
+    hipLaunchKernelGGL(kern, dim3(nst < cus ? nst : cus), dim3(kThreadsW), lds, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// W % 4 == 0 and 16-byte aligned x_in / goal: caller (nca_step_fwd.hip dispatch) guarantees it.
+hipError_t nca_launch_cond_step_fwd_wave(const NcaCondArgs& a, hipStream_t st) {
+    if (a.C <= 12) return launch_cond_wave<12>(a, st);
+    if (a.C <= 16) return launch_cond_wave<16>(a, st);
+    return hipErrorInvalidValue;
+}

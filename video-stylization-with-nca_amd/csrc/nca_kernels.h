@@ -30,6 +30,11 @@ struct NcaCondArgs {
 // fused steps (nca_step_fwd.hip); hipErrorInvalidValue when no instantiation covers the shape
 hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st);
 hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st);
+// wave-private-tile variant (nca_cond_wave.hip); needs W % 4 == 0 and 16-byte aligned x_in / goal
+hipError_t nca_launch_cond_step_fwd_wave(const NcaCondArgs& a, hipStream_t st);
+
+// test hook: route every fused step through the generic (any-shape) kernels
+void nca_set_force_generic(bool on);
 
 // stencils and small kernels (nca_stencil.hip)
 hipError_t nca_launch_dynca_perceive(const float* x, float* y, int B, int C, int H, int W, int pad, hipStream_t st);

@@ -18,6 +18,8 @@
 // Weights live in LDS as the A-operand image [m-tile][k-step][lane]; hidden activations never
 // leave registers.  Layer 1 is streamed m-tile by m-tile into layer 2's accumulators so only
 // one layer-1 tile is live (keeps 2 waves/SIMD).
+#include <cstdlib>
+
 #include "nca_common.h"
 #include "nca_kernels.h"
 
@@ -751,6 +753,9 @@ hipError_t launch_cond(const NcaCondArgs& a, hipStream_t st) {
 
 }  // namespace
 
+static bool g_force_generic = getenv("NCAHIP_FORCE_GENERIC") != nullptr;
+void nca_set_force_generic(bool on) { g_force_generic = on; }
+
 // ---- dispatch: smallest instantiation that covers (C, fc); padding lanes carry zero weights ---
 hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st) {
     const bool hc = a.c_cond > 0;
@@ -760,6 +765,8 @@ hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st) {
 }
 
 hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st) {
+    if (!g_force_generic && a.C <= 16 && (a.W % 4 == 0) && aligned16(a.x_in) && (a.goal == nullptr || aligned16(a.goal)))
+        return nca_launch_cond_step_fwd_wave(a, st);
     if (a.C <= 12) return launch_cond<12>(a, st);
     if (a.C <= 16) return launch_cond<16>(a, st);
     return hipErrorInvalidValue;

@@ -18,6 +18,7 @@ SIGNATURES = {
     "ncahip_last_error": [],
     "ncahip_limits": [_P, _P, _P],
     "ncahip_selftest": [_P, _P],
+    "ncahip_debug_force_generic": [_I],
     "ncahip_dynca_perceive_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
     "ncahip_cond_perceive_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
     "ncahip_dynca_step_fwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P],

@@ -33,6 +33,11 @@ def _w(t: torch.Tensor, name: str, like: torch.Tensor) -> torch.Tensor:
     return _dev(t.float(), name)
 
 
+def force_generic(on: bool) -> None:
+    """Test hook: route fused steps through the generic any-shape kernels (see ncahip.h)."""
+    lib().ncahip_debug_force_generic(1 if on else 0)
+
+
 def selftest(device=None) -> None:
     scratch = torch.zeros(1024, dtype=torch.int32, device=device or "cuda")
     check(lib().ncahip_selftest(scratch.data_ptr(), _stream()), "ncahip_selftest")
