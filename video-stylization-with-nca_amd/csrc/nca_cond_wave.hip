@@ -51,6 +51,23 @@ struct WCfg {
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 
+#ifdef NCA_STAMPS
+// Diagnostic build only: phase stamps per wave tile -> a.dbg[((wg*8+wave)*kStampTiles + tile)*8 + i].
+constexpr int kStampTiles = 8;
+#define NCA_STAMP(i)                                                                                   \
+    do {                                                                                               \
+        if (a.dbg && tile_no < kStampTiles) {                                                          \
+            unsigned long long t_;                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+            if (lane_in == 0) a.dbg[((size_t)(blockIdx.x * kWaves + (threadIdx.x >> 6)) * kStampTiles + tile_no) * 8 + (i)] = t_; \
+        }                                                                                              \
+    } while (0)
+#else
+#define NCA_STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ float wclamp(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
@@ -92,8 +109,9 @@ __device__ __forceinline__ void fill_image_w(float* __restrict__ dst, const floa
 // 3-cell halo is inside the image, no bounds logic at all.
 template <int CP, bool CHECK>
 __device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __restrict__ WS, float* __restrict__ PWR,
-                                          int b, int ty0, int tx0, int lane_in) {
+                                          int b, int ty0, int tx0, int lane_in, int tile_no) {
     using K = WCfg<CP>;
+    NCA_STAMP(0);
     constexpr int NT = WTH;
     const float* const W1L = WS + K::OFF_W1;
     const float* const W2L = WS + K::OFF_W2;
@@ -176,6 +194,7 @@ __device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __r
             gh[k] = gb[(unsigned)min(max(4 * k + q4 - gch0, 0), a.goal_ch - 1) * plane + hoff];
     }
 
+    NCA_STAMP(1);
     // ================= S1: alpha' (-inf outside the image == max_pool2d padding) ============
     wave_sync();  // the previous tile's LDS reads (epilogue) are ordered before these writes
     if (use_alive) {
@@ -208,6 +227,7 @@ __device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __r
         for (int k = 0; k < 4; ++k)
             if (l5 < 20) LIFE[(2 * k + hl) * RS + l5 + 2] = l2ok[k] ? 1.0f : 0.0f;
     }
+    NCA_STAMP(2);
     // ================= S3: pre-life mask of THIS step on halo 1; fire mask ===================
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -222,6 +242,7 @@ __device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __r
     if (!a.u) uu = nca_philox_cell(a.seed, a.step, cell);
     MK[lane] = (cin && wclamp(uu, 0.0f, 1.0f) < a.fire_rate) ? 1.0f : 0.0f;  // nca.py:171-174
     wave_sync();
+    NCA_STAMP(3);
     // ================= S4: z = x + goal * pre (nca.py:177) on halo 1; resolved copy for the residual
     if (l5 < 24) {
         const f32x4 lf = ld4(LIFE + (fr + 1) * RS + 4 + 4 * ff);
@@ -261,6 +282,7 @@ __device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __r
     }
     wave_sync();
 
+    NCA_STAMP(4);
     // ================= perception + UpdateNet on MFMA (identical mapping to nca_step_fwd.hip) ==
     const int g = q4;
     float P[NT][K::K1S];
@@ -289,6 +311,7 @@ __device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __r
             }
         }
     }
+    NCA_STAMP(5);
     f32x4 acc2[4][NT];
 #pragma unroll
     for (int m2 = 0; m2 < 4; ++m2) {
@@ -337,6 +360,7 @@ __device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __r
             }
         }
     }
+    NCA_STAMP(6);
     // ================= x' = x + rand_mask * out (nca.py:189); stays pending ===================
     float* const ob = a.x_out + (size_t)b * C * plane;
 #pragma unroll
@@ -358,6 +382,7 @@ __device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __r
                 }
         }
     }
+    NCA_STAMP(7);
 }
 
 template <int CP>
@@ -398,13 +423,14 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_wave_kernel(const 
     const int st_x = (W + STW - 1) / STW, st_y = (H + STH - 1) / STH;
     const int nst = a.B * st_x * st_y;
     const int halo = a.alive_ch >= 0 ? 3 : 1;
-    for (NcaTileWalk tw = nca_tile_walk(nst); tw.t < tw.end; tw.t += tw.stride) {
+    int tile_no = 0;
+    for (NcaTileWalk tw = nca_tile_walk(nst); tw.t < tw.end; tw.t += tw.stride, ++tile_no) {
         const int sxi = tw.t % st_x, syi = (tw.t / st_x) % st_y, b = tw.t / (st_x * st_y);
         const int ty0 = syi * STH + (wave >> 1) * WTH, tx0 = sxi * STW + (wave & 1) * WTW;
         if (ty0 >= H || tx0 >= W) continue;  // wave-uniform; no workgroup barrier below
         const bool inner = ty0 >= halo && ty0 + WTH + halo <= H && tx0 >= halo && tx0 + WTW + halo <= W;
-        if (inner) wave_tile<CP, false>(a, smem, PWR, b, ty0, tx0, lane);
-        else wave_tile<CP, true>(a, smem, PWR, b, ty0, tx0, lane);
+        if (inner) wave_tile<CP, false>(a, smem, PWR, b, ty0, tx0, lane, tile_no);
+        else wave_tile<CP, true>(a, smem, PWR, b, ty0, tx0, lane, tile_no);
     }
 }
 
@@ -435,8 +461,14 @@ hipError_t launch_cond_wave(const NcaCondArgs& a, hipStream_t st) {
 
 }  // namespace
 
+static unsigned long long* g_stamp_buffer = nullptr;
+void nca_debug_set_stamp_buffer(unsigned long long* p) { g_stamp_buffer = p; }
+extern "C" void nca_debug_set_stamp_buffer_c(void* p) { g_stamp_buffer = (unsigned long long*)p; }
+
 // W % 4 == 0 and 16-byte aligned x_in / goal: caller (nca_step_fwd.hip dispatch) guarantees it.
-hipError_t nca_launch_cond_step_fwd_wave(const NcaCondArgs& a, hipStream_t st) {
+hipError_t nca_launch_cond_step_fwd_wave(const NcaCondArgs& a_in, hipStream_t st) {
+    NcaCondArgs a = a_in;
+    a.dbg = g_stamp_buffer;
     if (a.C <= 12) return launch_cond_wave<12>(a, st);
     if (a.C <= 16) return launch_cond_wave<16>(a, st);
     return hipErrorInvalidValue;

@@ -25,6 +25,7 @@ struct NcaCondArgs {
     int B, C, H, W, hidden, goal_ch, alive_ch;
     float thr, fire_rate, lo, hi;
     uint64_t seed, step;
+    unsigned long long* dbg;  // diagnostic builds (-DNCA_STAMPS) only: per-wave phase time stamps
 };
 
 // fused steps (nca_step_fwd.hip); hipErrorInvalidValue when no instantiation covers the shape
@@ -32,6 +33,9 @@ hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st);
 hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st);
 // wave-private-tile variant (nca_cond_wave.hip); needs W % 4 == 0 and 16-byte aligned x_in / goal
 hipError_t nca_launch_cond_step_fwd_wave(const NcaCondArgs& a, hipStream_t st);
+
+// diagnostic build hook (-DNCA_STAMPS): buffer that receives s_memtime stamps, [wave][tile][8]
+void nca_debug_set_stamp_buffer(unsigned long long* p);
 
 // test hook: route every fused step through the generic (any-shape) kernels
 void nca_set_force_generic(bool on);
