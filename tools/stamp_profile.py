@@ -38,9 +38,10 @@ xp2, pre2 = ops.cond_step(xp, pre, goal, None, w, 3, step=2)
 torch.cuda.synchronize()
 L.nca_debug_set_stamp_buffer_c(None)
 s = buf.cpu().numpy().reshape(NW, NT, 8).astype(np.float64)
-names = ["issue loads", "wait a3 + S1/S2 (life)", "S3 (pn, philox)", "S4 (wait x/goal, z)", "perception", "MLP (MFMA)", "store", ]
-valid = s[:, :, 7] > 0
-d = np.diff(s, axis=2)
+names = ["goal loads + stage S1-S4", "perception pass 0", "issue next-tile loads (+philox)", "MLP pass 0 + perception/MLP pass 1", "store"]
+LAST = len(names)
+valid = s[:, :, LAST] > 0
+d = np.diff(s[:, :, :LAST + 1], axis=2)
 print(f"tiles stamped: {int(valid.sum())}; per-phase cycles (median / mean) over all stamped wave tiles")
 tot = 0
 for i, n in enumerate(names):
@@ -48,10 +49,7 @@ for i, n in enumerate(names):
     print(f"  {n:28s} {np.median(v):9.0f} {v.mean():9.0f}")
     tot += v.mean()
 print(f"  {'tile total':28s} {'':9s} {tot:9.0f}")
-gap = (s[:, 1:, 0] - s[:, :-1, 7])[valid[:, 1:] & valid[:, :-1]]
+gap = (s[:, 1:, 0] - s[:, :-1, LAST])[valid[:, 1:] & valid[:, :-1]]
 print(f"  between tiles (loop overhead)  {np.median(gap):9.0f} {gap.mean():9.0f}")
-per_wave = (s[:, :, 7].max(axis=1) - np.where(valid, s[:, :, 0], np.inf).min(axis=1))[valid.any(axis=1)]
+per_wave = (s[:, :, LAST].max(axis=1) - np.where(valid, s[:, :, 0], np.inf).min(axis=1))[valid.any(axis=1)]
 print(f"  wave lifetime in tiles: median {np.median(per_wave):.0f} cycles; tiles per wave {valid.sum(axis=1).mean():.2f}")
-t0 = np.where(valid, s[:, :, 0], np.inf).min()
-print(f"  first tile start spread: {np.percentile(np.where(valid[:, 0], s[:, 0, 0], np.nan)[valid[:,0]] - t0, [50, 90, 100])}")
-print(f"  kernel span (first stamp -> last stamp): {s[:, :, 7].max() - t0:.0f} cycles")

@@ -61,7 +61,7 @@ constexpr int kStampTiles = 8;
             __builtin_amdgcn_sched_barrier(0);                                                         \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
             __builtin_amdgcn_sched_barrier(0);                                                         \
-            if (lane_in == 0) a.dbg[((size_t)(blockIdx.x * kWaves + (threadIdx.x >> 6)) * kStampTiles + tile_no) * 8 + (i)] = t_; \
+            if (lane == 0) a.dbg[((size_t)(blockIdx.x * kWaves + (threadIdx.x >> 6)) * kStampTiles + tile_no) * 8 + (i)] = t_; \
         }                                                                                              \
     } while (0)
 #else
@@ -105,20 +105,100 @@ __device__ __forceinline__ void fill_image_w(float* __restrict__ dst, const floa
     }
 }
 
-// One wave tile: stage -> resolve masks -> perception -> MLP -> store.  CHECK=false: the tile's
-// 3-cell halo is inside the image, no bounds logic at all.
+// ---- per-wave tile bookkeeping ------------------------------------------------------------------
+struct WTile {
+    int b, ty0, tx0;
+    bool valid, inner;  // inner: the 3-cell (1-cell without alive channel) halo lies inside the image
+};
+
+// Registers that carry one tile's global loads from issue (before the previous tile's MFMA chain)
+// to staging (after it).
+template <int CP>
+struct TileRegs {
+    float a3v[5];           // alpha' halo 3
+    float prv[4];           // previous pre mask, halo 2
+    float uu;               // fire-mask uniform of the lane's cell
+    f32x4 xf[CP / 2], gf[CP / 2];  // state / goal interior 16-byte groups
+    float xh[CP / 4], gh[CP / 4];  // state / goal halo columns
+};
+
+// Lane geometry (all shifts of the lane id; recomputed where used, never carried across the MFMAs):
+//   alpha' halo 3 : item k -> row 2k+hl (<10), col l5 (<22)      image (ty0-3+row, tx0-3+col)
+//   pre    halo 2 : item k -> row 2k+hl (<8),  col l5 (<20)      image (ty0-2+row, tx0-2+col)
+//   interior f4   : item k -> channel 2k+hl, slot l5 (<24): halo-1 row l5>>2, 4-cell group l5&3
+//   halo columns  : item k -> channel 4k+q4, slot ci (<12): halo-1 row ci>>1, side ci&1
+template <int CP, bool STATE, bool GOAL>
+__device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t, int lane_in, TileRegs<CP>& R) {
+    const int C = a.C, H = a.H, W = a.W;
+    const unsigned plane = (unsigned)(H * W);
+    const int gch0 = C - a.goal_ch;
+    const bool pending = a.pre_in != nullptr, use_alive = a.alive_ch >= 0, has_goal = a.goal_ch > 0;
+    const float* const xb = a.x_in + (size_t)t.b * C * plane;
+    const float* const gb = has_goal ? a.goal + (size_t)t.b * a.goal_ch * plane : a.x_in;
+    const size_t cell0 = (size_t)t.b * plane;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int hl = lane >> 5, l5 = lane & 31, q4 = lane >> 4, ci = lane & 15;
+    const bool chk = !t.inner;
+    if (STATE && use_alive) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int gy = t.ty0 - 3 + 2 * k + hl, gx = t.tx0 - 3 + l5;
+            const bool ok = l5 < 22 && (!chk || (gy >= 0 && gy < H && gx >= 0 && gx < W));
+            R.a3v[k] = xb[(unsigned)a.alive_ch * plane + (ok ? (unsigned)(gy * W + gx) : 0u)];
+        }
+    }
+    if (STATE) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int gy = t.ty0 - 2 + 2 * k + hl, gx = t.tx0 - 2 + l5;
+            const bool ok = l5 < 20 && (!chk || (gy >= 0 && gy < H && gx >= 0 && gx < W));
+            R.prv[k] = 1.0f;
+            if (pending && use_alive) R.prv[k] = (float)a.pre_in[cell0 + (ok ? (unsigned)(gy * W + gx) : 0u)];
+        }
+    }
+    if (STATE) {
+        const int cgy = t.ty0 + q4, cgx = t.tx0 + ci;
+        const bool cin = !chk || (cgy < H && cgx < W);
+        const size_t cell = cell0 + (cin ? (unsigned)(cgy * W + cgx) : 0u);
+        R.uu = a.u ? a.u[cell] : nca_philox_cell(a.seed, a.step, cell);
+    }
+    {
+        const int fr = l5 >> 2, ff = l5 & 3, fgy = t.ty0 - 1 + fr, fgx = t.tx0 + 4 * ff;
+        const bool fok = l5 < 24 && (!chk || (fgy >= 0 && fgy < H && fgx + 3 < W));
+        const unsigned foff = fok ? (unsigned)(fgy * W + fgx) : 0u;
+        if (STATE) {
+#pragma unroll
+            for (int k = 0; k < CP / 2; ++k) R.xf[k] = ld4(xb + (unsigned)min(2 * k + hl, C - 1) * plane + foff);
+        }
+        if (GOAL && has_goal) {
+#pragma unroll
+            for (int k = 0; k < CP / 2; ++k)
+                R.gf[k] = ld4(gb + (unsigned)min(max(2 * k + hl - gch0, 0), a.goal_ch - 1) * plane + foff);
+        }
+    }
+    {
+        const int hr = ci >> 1, hgy = t.ty0 - 1 + hr, hgx = (ci & 1) ? t.tx0 + WTW : t.tx0 - 1;
+        const bool hok = ci < 12 && (!chk || (hgy >= 0 && hgy < H && hgx >= 0 && hgx < W));
+        const unsigned hoff = hok ? (unsigned)(hgy * W + hgx) : 0u;
+        if (STATE) {
+#pragma unroll
+            for (int k = 0; k < CP / 4; ++k) R.xh[k] = xb[(unsigned)min(4 * k + q4, C - 1) * plane + hoff];
+        }
+        if (GOAL && has_goal) {
+#pragma unroll
+            for (int k = 0; k < CP / 4; ++k)
+                R.gh[k] = gb[(unsigned)min(max(4 * k + q4 - gch0, 0), a.goal_ch - 1) * plane + hoff];
+        }
+    }
+}
+
+// Resolve the pending life mask, build z = x + goal*pre in LDS (halo 1), keep the resolved state for
+// the residual.  CHECK=false: no bounds logic.
 template <int CP, bool CHECK>
-__device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __restrict__ WS, float* __restrict__ PWR,
-                                          int b, int ty0, int tx0, int lane_in, int tile_no) {
+__device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t, float* __restrict__ PWR, int lane_in,
+                                           const TileRegs<CP>& R) {
     using K = WCfg<CP>;
-    NCA_STAMP(0);
-    constexpr int NT = WTH;
-    const float* const W1L = WS + K::OFF_W1;
-    const float* const W2L = WS + K::OFF_W2;
-    const float* const W3L = WS + K::OFF_W3;
-    const float* const B1L = WS + K::OFF_B1;
-    const float* const B2L = WS + K::OFF_B2;
-    const float* const WPL = WS + K::OFF_WP;
     float* const Z = PWR + K::PW_Z;
     float* const XR = PWR + K::PW_XR;
     float* const A3 = PWR + K::PW_A3;
@@ -129,80 +209,29 @@ __device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __r
 
     const int C = a.C, H = a.H, W = a.W;
     const unsigned plane = (unsigned)(H * W);
-    const int gch0 = C - a.goal_ch;
+    const int gch0 = C - a.goal_ch, ty0 = t.ty0, tx0 = t.tx0;
     const bool pending = a.pre_in != nullptr, use_alive = a.alive_ch >= 0, has_goal = a.goal_ch > 0;
-    const float* const xb = a.x_in + (size_t)b * C * plane;
-    const float* const gb = has_goal ? a.goal + (size_t)b * a.goal_ch * plane : a.x_in;
-    const size_t cell0 = (size_t)b * plane;
-
     int lane = lane_in;
-    asm volatile("" : "+v"(lane));  // staging coordinates are recomputed per tile, not kept live across the MFMAs
+    asm volatile("" : "+v"(lane));
     const int hl = lane >> 5, l5 = lane & 31, q4 = lane >> 4, ci = lane & 15;
 
-    // ================= issue every global load of the tile ==================================
-    // alpha' halo 3: rows ty0-3+r (r = 2k+hl < 10), cols tx0-3+q (q = l5 < 22)
-    float a3v[5];
-    bool a3ok[5];
-    if (use_alive) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int gy = ty0 - 3 + 2 * k + hl, gx = tx0 - 3 + l5;
-            a3ok[k] = l5 < 22 && (!CHECK || (gy >= 0 && gy < H && gx >= 0 && gx < W));
-            a3v[k] = xb[(unsigned)a.alive_ch * plane + (a3ok[k] ? (unsigned)(gy * W + gx) : 0u)];
-        }
-    }
-    // previous step's pre mask, halo 2: rows ty0-2+r (r = 2k+hl < 8), cols tx0-2+q (q = l5 < 20)
-    float prv[4];
+    // ---- S1: alpha' (-inf outside the image == max_pool2d padding) -----------------------------
+    wave_sync();  // the previous tile's LDS reads are ordered before these writes
     bool l2ok[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int gy = ty0 - 2 + 2 * k + hl, gx = tx0 - 2 + l5;
         l2ok[k] = l5 < 20 && (!CHECK || (gy >= 0 && gy < H && gx >= 0 && gx < W));
-        prv[k] = 1.0f;
-        if (pending && use_alive) prv[k] = (float)a.pre_in[cell0 + (l2ok[k] ? (unsigned)(gy * W + gx) : 0u)];
     }
-    // fire-mask uniform of this lane's cell (row q4, col ci)
-    const int cgy = ty0 + q4, cgx = tx0 + ci;
-    const bool cin = !CHECK || (cgy < H && cgx < W);
-    const size_t cell = cell0 + (cin ? (unsigned)(cgy * W + cgx) : 0u);
-    float uu = 0.0f;
-    if (a.u) uu = a.u[cell];
-    // state + goal, interior 16-byte groups: channel 2k+hl, position l5 < 24 -> row l5>>2 (halo-1 row), group l5&3
-    const int fr = l5 >> 2, ff = l5 & 3;
-    const int fgy = ty0 - 1 + fr, fgx = tx0 + 4 * ff;
-    const bool fok = l5 < 24 && (!CHECK || (fgy >= 0 && fgy < H && fgx + 3 < W));
-    const unsigned foff = fok ? (unsigned)(fgy * W + fgx) : 0u;
-    f32x4 xf[CP / 2], gf[CP / 2];
-#pragma unroll
-    for (int k = 0; k < CP / 2; ++k) xf[k] = ld4(xb + (unsigned)min(2 * k + hl, C - 1) * plane + foff);
-    if (has_goal) {
-#pragma unroll
-        for (int k = 0; k < CP / 2; ++k)
-            gf[k] = ld4(gb + (unsigned)min(max(2 * k + hl - gch0, 0), a.goal_ch - 1) * plane + foff);
-    }
-    // state + goal, halo columns: channel 4k+q4, slot ci < 12 -> row ci>>1, side ci&1
-    const int hr = ci >> 1, hside = ci & 1;
-    const int hgy = ty0 - 1 + hr, hgx = hside ? tx0 + WTW : tx0 - 1;
-    const bool hok = ci < 12 && (!CHECK || (hgy >= 0 && hgy < H && hgx >= 0 && hgx < W));
-    const unsigned hoff = hok ? (unsigned)(hgy * W + hgx) : 0u;
-    float xh[CP / 4], gh[CP / 4];
-#pragma unroll
-    for (int k = 0; k < CP / 4; ++k) xh[k] = xb[(unsigned)min(4 * k + q4, C - 1) * plane + hoff];
-    if (has_goal) {
-#pragma unroll
-        for (int k = 0; k < CP / 4; ++k)
-            gh[k] = gb[(unsigned)min(max(4 * k + q4 - gch0, 0), a.goal_ch - 1) * plane + hoff];
-    }
-
-    NCA_STAMP(1);
-    // ================= S1: alpha' (-inf outside the image == max_pool2d padding) ============
-    wave_sync();  // the previous tile's LDS reads (epilogue) are ordered before these writes
     if (use_alive) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k)
-            if (l5 < 22) A3[(2 * k + hl) * RS + l5 + 1] = a3ok[k] ? a3v[k] : NCA_NEG_INF;
+        for (int k = 0; k < 5; ++k) {
+            const int gy = ty0 - 3 + 2 * k + hl, gx = tx0 - 3 + l5;
+            const bool ok = !CHECK || (gy >= 0 && gy < H && gx >= 0 && gx < W);
+            if (l5 < 22) A3[(2 * k + hl) * RS + l5 + 1] = ok ? R.a3v[k] : NCA_NEG_INF;
+        }
         wave_sync();
-        // ============= S2: life = pre & post of the PREVIOUS step, resolved alpha (nca.py:191-194)
+        // ---- S2: life = pre & post of the PREVIOUS step, resolved alpha (nca.py:191-194) -------
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int r = 2 * k + hl;
@@ -212,7 +241,7 @@ __device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __r
                 life = 1.0f;
                 av = ac[0];
                 if (pending) {
-                    life = (prv[k] != 0.0f && max3x3(ac) > a.thr) ? 1.0f : 0.0f;
+                    life = (R.prv[k] != 0.0f && max3x3(ac) > a.thr) ? 1.0f : 0.0f;
                     av = wclamp(av * life, a.lo, a.hi);
                 }
             }
@@ -227,8 +256,7 @@ __device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __r
         for (int k = 0; k < 4; ++k)
             if (l5 < 20) LIFE[(2 * k + hl) * RS + l5 + 2] = l2ok[k] ? 1.0f : 0.0f;
     }
-    NCA_STAMP(2);
-    // ================= S3: pre-life mask of THIS step on halo 1; fire mask ===================
+    // ---- S3: pre-life mask of THIS step on halo 1; fire mask -------------------------------------
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int r = 2 * k + hl;  // halo-1 row, col q = l5 < 18
@@ -237,58 +265,69 @@ __device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __r
         float pn = 0.0f;
         if (in) pn = (!use_alive || max3x3(A2 + (r + 1) * RS + l5 + 3) > a.thr) ? 1.0f : 0.0f;
         if (l5 < 18) PN[r * RS + l5 + 3] = pn;
-        if (in && r >= 1 && r <= WTH && l5 >= 1 && l5 <= WTW) a.pre_out[cell0 + (unsigned)(gy * W + gx)] = (uint8_t)pn;
     }
-    if (!a.u) uu = nca_philox_cell(a.seed, a.step, cell);
-    MK[lane] = (cin && wclamp(uu, 0.0f, 1.0f) < a.fire_rate) ? 1.0f : 0.0f;  // nca.py:171-174
-    wave_sync();
-    NCA_STAMP(3);
-    // ================= S4: z = x + goal * pre (nca.py:177) on halo 1; resolved copy for the residual
+    {
+        const int cgy = ty0 + q4, cgx = tx0 + ci;
+        const bool cin = !CHECK || (cgy < H && cgx < W);
+        MK[lane] = (cin && wclamp(R.uu, 0.0f, 1.0f) < a.fire_rate) ? 1.0f : 0.0f;  // nca.py:171-174
+        wave_sync();
+        if (cin) a.pre_out[(size_t)t.b * plane + (unsigned)(cgy * W + cgx)] = (uint8_t)PN[(q4 + 1) * RS + ci + 4];
+    }
+    // ---- S4: z = x + goal * pre (nca.py:177) on halo 1; resolved state kept for the residual -----
     if (l5 < 24) {
+        const int fr = l5 >> 2, ff = l5 & 3;
+        const bool fok = !CHECK || (ty0 - 1 + fr >= 0 && ty0 - 1 + fr < H && tx0 + 4 * ff + 3 < W);
         const f32x4 lf = ld4(LIFE + (fr + 1) * RS + 4 + 4 * ff);
         const f32x4 pn = ld4(PN + fr * RS + 4 + 4 * ff);
         const bool inner = fr >= 1 && fr <= WTH;
 #pragma unroll
         for (int k = 0; k < CP / 2; ++k) {
             const int ch = 2 * k + hl;
-            f32x4 v = xf[k];
+            f32x4 v = R.xf[k];
             if (pending) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = wclamp(v[j] * lf[j], a.lo, a.hi);
             }
             if ((CHECK && !fok) || ch >= C) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (has_goal && ch >= gch0 && ch < C) {
-                if (inner) st4(XR + (ch - gch0) * XRS + (fr - 1) * WTW + 4 * ff, v);
-                if (!CHECK || fok) {
+            if (inner) st4(XR + ch * XRS + (fr - 1) * WTW + 4 * ff, v);
+            if (has_goal && ch >= gch0 && ch < C && fok) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaf(gf[k][j], pn[j], v[j]);
-                }
+                for (int j = 0; j < 4; ++j) v[j] = fmaf(R.gf[k][j], pn[j], v[j]);
             }
             st4(Z + ch * CS + fr * RS + 4 + 4 * ff, v);
         }
     }
     if (ci < 12) {
-        const int zq = hside ? WTW + 4 : 3;
+        const int hr = ci >> 1, zq = (ci & 1) ? WTW + 4 : 3;
+        const int hgy = ty0 - 1 + hr, hgx = (ci & 1) ? tx0 + WTW : tx0 - 1;
+        const bool hok = !CHECK || (hgy >= 0 && hgy < H && hgx >= 0 && hgx < W);
         const float lf = LIFE[(hr + 1) * RS + zq], pn = PN[hr * RS + zq];
 #pragma unroll
         for (int k = 0; k < CP / 4; ++k) {
             const int ch = 4 * k + q4;
-            float v = xh[k];
+            float v = R.xh[k];
             if (pending) v = wclamp(v * lf, a.lo, a.hi);
-            if ((CHECK && !hok) || ch >= C) v = 0.0f;
-            else if (has_goal && ch >= gch0) v = fmaf(gh[k], pn, v);
+            if (!hok || ch >= C) v = 0.0f;
+            else if (has_goal && ch >= gch0) v = fmaf(R.gh[k], pn, v);
             Z[ch * CS + hr * RS + zq] = v;
         }
     }
     wave_sync();
+}
 
-    NCA_STAMP(4);
-    // ================= perception + UpdateNet on MFMA (identical mapping to nca_step_fwd.hip) ==
-    const int g = q4;
-    float P[NT][K::K1S];
+// Learned depthwise perception (nca.py:99-107) from the LDS tile: P[n][3c'+f] for channel 4c'+g, cell (row n, col ci).
+template <int CP, int NT>
+__device__ __forceinline__ void perceive_tile(const float* __restrict__ WS, const float* __restrict__ PWR, int lane_in,
+                                              int n0, float (&P)[NT][3 * CP / 4]) {
+    using K = WCfg<CP>;
+    const float* const Z = PWR + K::PW_Z;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));  // per pass: re-read the 27 taps from LDS instead of holding 4x28 registers
+    const float* const WPL = WS + K::OFF_WP;
+    const int g = lane >> 4, ci = lane & 15;
 #pragma unroll
     for (int c4 = 0; c4 < CP / 4; ++c4) {
-        const float* const zc = Z + (4 * c4 + g) * CS + ci + 3;
+        const float* const zc = Z + (4 * c4 + g) * CS + n0 * RS + ci + 3;
         float wt[28];
 #pragma unroll
         for (int j4 = 0; j4 < 7; ++j4) {
@@ -311,7 +350,24 @@ __device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __r
             }
         }
     }
-    NCA_STAMP(5);
+}
+
+__device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_huge_valf()); }
+
+// UpdateNet (nca.py:40-46) 3C -> 64 -> 64 -> C on v_mfma_f32_16x16x4_f32, then x' = x + mask * out
+// (nca.py:189) written back in place into the resolved-state copy XR.
+template <int CP, int NT>
+__device__ __forceinline__ void mlp_tile(const NcaCondArgs& a, const float* __restrict__ WS, float* __restrict__ PWR,
+                                         int lane_in, int n0, const float (&P)[NT][3 * CP / 4]) {
+    using K = WCfg<CP>;
+    const float* const W1L = WS + K::OFF_W1;
+    const float* const W2L = WS + K::OFF_W2;
+    const float* const W3L = WS + K::OFF_W3;
+    const float* const B1L = WS + K::OFF_B1;
+    const float* const B2L = WS + K::OFF_B2;
+    float* const XR = PWR + K::PW_XR;
+    const float* const MK = PWR + K::PW_A3 + ZROWS * RS;
+    const int g = lane_in >> 4, ci = lane_in & 15;
     f32x4 acc2[4][NT];
 #pragma unroll
     for (int m2 = 0; m2 < 4; ++m2) {
@@ -339,7 +395,7 @@ __device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __r
             for (int m2 = 0; m2 < 4; ++m2) {
                 const float wa = w2m[(m2 * 16 + r) * 64];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc2[m2][n] = nca_mfma(wa, fmaxf(acc1[n][r], 0.0f), acc2[m2][n]);
+                for (int n = 0; n < NT; ++n) acc2[m2][n] = nca_mfma(wa, relu(acc1[n][r]), acc2[m2][n]);
             }
         }
     }
@@ -356,33 +412,46 @@ __device__ __forceinline__ void wave_tile(const NcaCondArgs& a, const float* __r
             for (int m3 = 0; m3 < K::M3T; ++m3) {
                 const float wa = W3L[(m3 * 16 + 4 * m + r) * 64 + lane_in];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc3[m3][n] = nca_mfma(wa, fmaxf(acc2[m][n][r], 0.0f), acc3[m3][n]);
+                for (int n = 0; n < NT; ++n) acc3[m3][n] = nca_mfma(wa, relu(acc2[m][n][r]), acc3[m3][n]);
             }
         }
     }
-    NCA_STAMP(6);
-    // ================= x' = x + rand_mask * out (nca.py:189); stays pending ===================
-    float* const ob = a.x_out + (size_t)b * C * plane;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        const int gy = ty0 + n, gx = tx0 + ci;
-        if (!CHECK || (gy < H && gx < W)) {
-            const float mk = MK[n * WTW + ci];
-            const unsigned off = (unsigned)(gy * W + gx);
+        const float mk = MK[(n0 + n) * WTW + ci];
 #pragma unroll
-            for (int m3 = 0; m3 < K::M3T; ++m3)
+        for (int m3 = 0; m3 < K::M3T; ++m3)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ch = 16 * m3 + 4 * g + r;
-                    if (ch < C) {
-                        const float xo = (has_goal && ch >= gch0) ? XR[(ch - gch0) * XRS + n * WTW + ci]
-                                                                  : Z[ch * CS + (n + 1) * RS + ci + 4];
-                        ob[(unsigned)ch * plane + off] = xo + mk * acc3[m3][n][r];
-                    }
+            for (int r = 0; r < 4; ++r) {
+                const int ch = 16 * m3 + 4 * g + r;
+                if (ch < CP) {  // same lane reads and rewrites the element: in place
+                    float* const p = XR + ch * XRS + (n0 + n) * WTW + ci;
+                    *p = fmaf(mk, acc3[m3][n][r], *p);
                 }
-        }
+            }
     }
-    NCA_STAMP(7);
+}
+
+// Pending state out: 16-byte stores, 4 per lane (item k -> channel 4k+q4, row (lane>>2)&3, group lane&3).
+template <int CP, bool CHECK>
+__device__ __forceinline__ void store_tile(const NcaCondArgs& a, const WTile& t, const float* __restrict__ PWR, int lane_in) {
+    using K = WCfg<CP>;
+    const float* const XR = PWR + K::PW_XR;
+    const int C = a.C, H = a.H, W = a.W;
+    const unsigned plane = (unsigned)(H * W);
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int q4 = lane >> 4, row = (lane >> 2) & 3, ff = lane & 3;
+    const int gy = t.ty0 + row, gx = t.tx0 + 4 * ff;
+    const bool ok = !CHECK || (gy < H && gx + 3 < W);
+    float* const ob = a.x_out + (size_t)t.b * C * plane + (ok ? (unsigned)(gy * W + gx) : 0u);
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < CP / 4; ++k) {
+        const int ch = 4 * k + q4;
+        const f32x4 v = ld4(XR + ch * XRS + row * WTW + 4 * ff);
+        if (ok && ch < C) st4(ob + (unsigned)ch * plane, v);
+    }
 }
 
 template <int CP>
@@ -392,6 +461,30 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_wave_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C = a.C, H = a.H, W = a.W, hid = a.hidden, K1 = 3 * C;
+
+    // ---- tile walk of this wave: super-tiles XCD-chunked, wave -> (row-of-4, column-half) ------
+    const int st_x = (W + STW - 1) / STW, st_y = (H + STH - 1) / STH;
+    const int halo = a.alive_ch >= 0 ? 3 : 1;
+    NcaTileWalk tw = nca_tile_walk(a.B * st_x * st_y);
+    auto next_tile = [&]() -> WTile {
+        WTile t{0, 0, 0, false, false};
+        while (tw.t < tw.end) {
+            const int sxi = tw.t % st_x, syi = (tw.t / st_x) % st_y;
+            t.b = tw.t / (st_x * st_y);
+            t.ty0 = syi * STH + (wave >> 1) * WTH;
+            t.tx0 = sxi * STW + (wave & 1) * WTW;
+            tw.t += tw.stride;
+            if (t.ty0 < H && t.tx0 < W) {
+                t.valid = true;
+                t.inner = t.ty0 >= halo && t.ty0 + WTH + halo <= H && t.tx0 >= halo && t.tx0 + WTW + halo <= W;
+                break;
+            }
+        }
+        return t;
+    };
+    WTile cur = next_tile();
+    TileRegs<CP> R;
+    if (cur.valid) issue_loads<CP, true, false>(a, cur, lane, R);  // first tile's loads fly while the weight image is built
 
     fill_image_w<4 * K::K1S * 64>(smem + K::OFF_W1, a.w1, tid, [&](int idx) -> long {
         const int l = idx & 63, s = (idx >> 6) % K::K1S, m = (idx >> 6) / K::K1S;
@@ -420,17 +513,32 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_wave_kernel(const 
     __syncthreads();  // the only workgroup barrier: weight image complete
 
     float* const PWR = smem + K::SHARED + wave * K::PW;
-    const int st_x = (W + STW - 1) / STW, st_y = (H + STH - 1) / STH;
-    const int nst = a.B * st_x * st_y;
-    const int halo = a.alive_ch >= 0 ? 3 : 1;
     int tile_no = 0;
-    for (NcaTileWalk tw = nca_tile_walk(nst); tw.t < tw.end; tw.t += tw.stride, ++tile_no) {
-        const int sxi = tw.t % st_x, syi = (tw.t / st_x) % st_y, b = tw.t / (st_x * st_y);
-        const int ty0 = syi * STH + (wave >> 1) * WTH, tx0 = sxi * STW + (wave & 1) * WTW;
-        if (ty0 >= H || tx0 >= W) continue;  // wave-uniform; no workgroup barrier below
-        const bool inner = ty0 >= halo && ty0 + WTH + halo <= H && tx0 >= halo && tx0 + WTW + halo <= W;
-        if (inner) wave_tile<CP, false>(a, smem, PWR, b, ty0, tx0, lane, tile_no);
-        else wave_tile<CP, true>(a, smem, PWR, b, ty0, tx0, lane, tile_no);
+    while (cur.valid) {
+        NCA_STAMP(0);
+        issue_loads<CP, false, true>(a, cur, lane, R);  // goal encoding: consumed last in staging (S4)
+        if (cur.inner) stage_tile<CP, false>(a, cur, PWR, lane, R);
+        else stage_tile<CP, true>(a, cur, PWR, lane, R);
+        NCA_STAMP(1);
+        const WTile nxt = next_tile();
+        constexpr int NT = 2;  // rows per MFMA pass: 2 independent accumulator chains already pace the pipe
+#pragma unroll
+        for (int pass = 0; pass < WTH / NT; ++pass) {
+            float P[NT][K::K1S];
+            perceive_tile<CP, NT>(smem, PWR, lane, pass * NT, P);
+            if (pass == 0) {
+                NCA_STAMP(2);
+                if (nxt.valid) issue_loads<CP, true, false>(a, nxt, lane, R);  // in flight across this tile's MFMA chains
+                NCA_STAMP(3);
+            }
+            mlp_tile<CP, NT>(a, smem, PWR, lane, pass * NT, P);
+        }
+        NCA_STAMP(4);
+        if (cur.inner) store_tile<CP, false>(a, cur, PWR, lane);
+        else store_tile<CP, true>(a, cur, PWR, lane);
+        NCA_STAMP(5);
+        cur = nxt;
+        ++tile_no;
     }
 }
 
