@@ -68,7 +68,9 @@ constexpr int kStampTiles = 8;
 #define NCA_STAMP(i) do { } while (0)
 #endif
 
-__device__ __forceinline__ float wclamp(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// clamp as one v_med3_f32 (lo <= hi; identical to fmin(fmax(v,lo),hi) for every non-NaN v)
+__device__ __forceinline__ float wclamp(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ float max3x3(const float* p) {
@@ -285,15 +287,13 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
             const int ch = 2 * k + hl;
             f32x4 v = R.xf[k];
             if (pending) {
+                v = v * lf;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = wclamp(v[j] * lf[j], a.lo, a.hi);
+                for (int j = 0; j < 4; ++j) v[j] = wclamp(v[j], a.lo, a.hi);
             }
             if ((CHECK && !fok) || ch >= C) v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (inner) st4(XR + ch * XRS + (fr - 1) * WTW + 4 * ff, v);
-            if (has_goal && ch >= gch0 && ch < C && fok) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaf(R.gf[k][j], pn[j], v[j]);
-            }
+            if (has_goal && ch >= gch0 && ch < C && fok) v = __builtin_elementwise_fma(R.gf[k], pn, v);
             st4(Z + ch * CS + fr * RS + 4 + 4 * ff, v);
         }
     }
@@ -334,28 +334,28 @@ __device__ __forceinline__ void perceive_tile(const float* __restrict__ WS, cons
             const f32x4 w4 = ld4(WPL + (4 * c4 + g) * K::WPS + 4 * j4);
             wt[4 * j4 + 0] = w4[0]; wt[4 * j4 + 1] = w4[1]; wt[4 * j4 + 2] = w4[2]; wt[4 * j4 + 3] = w4[3];
         }
+        static_assert(NT == 2, "row pairs: one v_pk_fma_f32 serves output rows n0 and n0+1");
+        // tap (dy,dx) of output rows (n0, n0+1) reads tile rows (dy, dy+1): one ds_read2_b32 -> an aligned pair
+        f32x2 nb[9];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            float nb[9];
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+            for (int dx = 0; dx < 3; ++dx) nb[3 * dy + dx] = f32x2{zc[dy * RS + dx], zc[(dy + 1) * RS + dx]};
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) nb[3 * dy + dx] = zc[(n + dy) * RS + dx];
+        for (int f = 0; f < 3; ++f) {
+            f32x2 acc = {0.0f, 0.0f};
 #pragma unroll
-            for (int f = 0; f < 3; ++f) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) acc = fmaf(wt[9 * f + t], nb[t], acc);
-                P[n][3 * c4 + f] = acc;
-            }
+            for (int t = 0; t < 9; ++t) acc = __builtin_elementwise_fma(f32x2{wt[9 * f + t], wt[9 * f + t]}, nb[t], acc);
+            P[0][3 * c4 + f] = acc[0];
+            P[1][3 * c4 + f] = acc[1];
         }
     }
 }
 
 __device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_huge_valf()); }
 
-// UpdateNet (nca.py:40-46) 3C -> 64 -> 64 -> C on v_mfma_f32_16x16x4_f32, then x' = x + mask * out
-// (nca.py:189) written back in place into the resolved-state copy XR.
+// UpdateNet (nca.py:40-46) 3C -> 64 -> 64 -> C on v_mfma_f32_16x16x4_f32 for rows n0..n0+NT-1, then
+// x' = x + mask * out (nca.py:189) written back in place into the resolved-state copy XR.
 template <int CP, int NT>
 __device__ __forceinline__ void mlp_tile(const NcaCondArgs& a, const float* __restrict__ WS, float* __restrict__ PWR,
                                          int lane_in, int n0, const float (&P)[NT][3 * CP / 4]) {
@@ -515,6 +515,9 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_wave_kernel(const 
     float* const PWR = smem + K::SHARED + wave * K::PW;
     int tile_no = 0;
     while (cur.valid) {
+        // issue priority: the non-MFMA phases of a wave outrank its SIMD partner's MFMA chain (which only needs
+        // one issue slot per 32 cycles), so staging finishes quickly and the pipe stays fed
+        __builtin_amdgcn_s_setprio(3);
         NCA_STAMP(0);
         issue_loads<CP, false, true>(a, cur, lane, R);  // goal encoding: consumed last in staging (S4)
         if (cur.inner) stage_tile<CP, false>(a, cur, PWR, lane, R);
@@ -531,7 +534,9 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_wave_kernel(const 
                 if (nxt.valid) issue_loads<CP, true, false>(a, nxt, lane, R);  // in flight across this tile's MFMA chains
                 NCA_STAMP(3);
             }
+            __builtin_amdgcn_s_setprio(0);
             mlp_tile<CP, NT>(a, smem, PWR, lane, pass * NT, P);
+            __builtin_amdgcn_s_setprio(3);
         }
         NCA_STAMP(4);
         if (cur.inner) store_tile<CP, false>(a, cur, PWR, lane);
@@ -540,6 +545,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_wave_kernel(const 
         cur = nxt;
         ++tile_no;
     }
+    __builtin_amdgcn_s_setprio(0);
 }
 
 template <int CP>
