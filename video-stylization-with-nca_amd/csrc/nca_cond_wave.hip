@@ -118,7 +118,7 @@ struct WTile {
 template <int CP>
 struct TileRegs {
     float a3v[5];           // alpha' halo 3
-    float prv[4];           // previous pre mask, halo 2
+    unsigned prv[4];        // previous pre mask bytes, halo 2 (raw: converting at load time would force a wait)
     float uu;               // fire-mask uniform of the lane's cell
     f32x4 xf[CP / 2], gf[CP / 2];  // state / goal interior 16-byte groups
     float xh[CP / 4], gh[CP / 4];  // state / goal halo columns
@@ -151,12 +151,13 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
         }
     }
     if (STATE) {
+        // always load (from a valid address when there is no pending mask): no branch, no wait at issue
+        const uint8_t* const pp = (pending && use_alive) ? a.pre_in + cell0 : reinterpret_cast<const uint8_t*>(xb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int gy = t.ty0 - 2 + 2 * k + hl, gx = t.tx0 - 2 + l5;
             const bool ok = l5 < 20 && (!chk || (gy >= 0 && gy < H && gx >= 0 && gx < W));
-            R.prv[k] = 1.0f;
-            if (pending && use_alive) R.prv[k] = (float)a.pre_in[cell0 + (ok ? (unsigned)(gy * W + gx) : 0u)];
+            R.prv[k] = pp[ok ? (unsigned)(gy * W + gx) : 0u];
         }
     }
     if (STATE) {
@@ -243,7 +244,7 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
                 life = 1.0f;
                 av = ac[0];
                 if (pending) {
-                    life = (R.prv[k] != 0.0f && max3x3(ac) > a.thr) ? 1.0f : 0.0f;
+                    life = (R.prv[k] != 0u && max3x3(ac) > a.thr) ? 1.0f : 0.0f;
                     av = wclamp(av * life, a.lo, a.hi);
                 }
             }
@@ -282,19 +283,24 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
         const f32x4 lf = ld4(LIFE + (fr + 1) * RS + 4 + 4 * ff);
         const f32x4 pn = ld4(PN + fr * RS + 4 + 4 * ff);
         const bool inner = fr >= 1 && fr <= WTH;
+        f32x4 v[CP / 2];
 #pragma unroll
-        for (int k = 0; k < CP / 2; ++k) {
+        for (int k = 0; k < CP / 2; ++k) {  // resolved state (prefetched long ago): no memory wait here
             const int ch = 2 * k + hl;
-            f32x4 v = R.xf[k];
+            v[k] = R.xf[k];
             if (pending) {
-                v = v * lf;
+                v[k] = v[k] * lf;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = wclamp(v[j], a.lo, a.hi);
+                for (int j = 0; j < 4; ++j) v[k][j] = wclamp(v[k][j], a.lo, a.hi);
             }
-            if ((CHECK && !fok) || ch >= C) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (inner) st4(XR + ch * XRS + (fr - 1) * WTW + 4 * ff, v);
-            if (has_goal && ch >= gch0 && ch < C && fok) v = __builtin_elementwise_fma(R.gf[k], pn, v);
-            st4(Z + ch * CS + fr * RS + 4 + 4 * ff, v);
+            if ((CHECK && !fok) || ch >= C) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (inner) st4(XR + ch * XRS + (fr - 1) * WTW + 4 * ff, v[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < CP / 2; ++k) {  // goal encoding (issued at the top of staging) consumed last
+            const int ch = 2 * k + hl;
+            if (has_goal && ch >= gch0 && ch < C && fok) v[k] = __builtin_elementwise_fma(R.gf[k], pn, v[k]);
+            st4(Z + ch * CS + fr * RS + 4 + 4 * ff, v[k]);
         }
     }
     if (ci < 12) {
@@ -538,6 +544,9 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_wave_kernel(const 
             mlp_tile<CP, NT>(a, smem, PWR, lane, pass * NT, P);
             __builtin_amdgcn_s_setprio(3);
         }
+        // The prefetch was issued a whole MFMA chain ago; telling the compiler so (an s_waitcnt it can see) keeps it
+        // from draining the goal loads of the next tile at that tile's first use of a prefetched register.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
         NCA_STAMP(4);
         if (cur.inner) store_tile<CP, false>(a, cur, PWR, lane);
         else store_tile<CP, true>(a, cur, PWR, lane);
