@@ -52,7 +52,7 @@ struct WCfg {
 };
 
 #ifdef NCA_STAMPS
-// Diagnostic build only: phase stamps per wave tile -> a.dbg[((wg*8+wave)*kStampTiles + tile)*8 + i].
+// Diagnostic build only: phase stamps per wave tile -> a.dbg[((wg*8+wave)*kStampTiles + tile)*16 + i].
 constexpr int kStampTiles = 8;
 #define NCA_STAMP(i)                                                                                   \
     do {                                                                                               \
@@ -61,7 +61,7 @@ constexpr int kStampTiles = 8;
             __builtin_amdgcn_sched_barrier(0);                                                         \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
             __builtin_amdgcn_sched_barrier(0);                                                         \
-            if (lane == 0) a.dbg[((size_t)(blockIdx.x * kWaves + (threadIdx.x >> 6)) * kStampTiles + tile_no) * 8 + (i)] = t_; \
+            if (lane == 0) a.dbg[((size_t)(blockIdx.x * kWaves + (threadIdx.x >> 6)) * kStampTiles + tile_no) * 16 + (i)] = t_; \
         }                                                                                              \
     } while (0)
 #else
@@ -200,7 +200,7 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
 // the residual.  CHECK=false: no bounds logic.
 template <int CP, bool CHECK>
 __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t, float* __restrict__ PWR, int lane_in,
-                                           const TileRegs<CP>& R) {
+                                           const TileRegs<CP>& R, int tile_no) {
     using K = WCfg<CP>;
     float* const Z = PWR + K::PW_Z;
     float* const XR = PWR + K::PW_XR;
@@ -218,6 +218,7 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
     asm volatile("" : "+v"(lane));
     const int hl = lane >> 5, l5 = lane & 31, q4 = lane >> 4, ci = lane & 15;
 
+    NCA_STAMP(8);
     // ---- S1: alpha' (-inf outside the image == max_pool2d padding) -----------------------------
     wave_sync();  // the previous tile's LDS reads are ordered before these writes
     bool l2ok[4];
@@ -234,6 +235,7 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
             if (l5 < 22) A3[(2 * k + hl) * RS + l5 + 1] = ok ? R.a3v[k] : NCA_NEG_INF;
         }
         wave_sync();
+        NCA_STAMP(9);
         // ---- S2: life = pre & post of the PREVIOUS step, resolved alpha (nca.py:191-194) -------
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -259,6 +261,7 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
         for (int k = 0; k < 4; ++k)
             if (l5 < 20) LIFE[(2 * k + hl) * RS + l5 + 2] = l2ok[k] ? 1.0f : 0.0f;
     }
+    NCA_STAMP(10);
     // ---- S3: pre-life mask of THIS step on halo 1; fire mask -------------------------------------
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -276,6 +279,7 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
         wave_sync();
         if (cin) a.pre_out[(size_t)t.b * plane + (unsigned)(cgy * W + cgx)] = (uint8_t)PN[(q4 + 1) * RS + ci + 4];
     }
+    NCA_STAMP(11);
     // ---- S4: z = x + goal * pre (nca.py:177) on halo 1; resolved state kept for the residual -----
     if (l5 < 24) {
         const int fr = l5 >> 2, ff = l5 & 3;
@@ -296,6 +300,7 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
             if ((CHECK && !fok) || ch >= C) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (inner) st4(XR + ch * XRS + (fr - 1) * WTW + 4 * ff, v[k]);
         }
+        NCA_STAMP(12);
 #pragma unroll
         for (int k = 0; k < CP / 2; ++k) {  // goal encoding (issued at the top of staging) consumed last
             const int ch = 2 * k + hl;
@@ -303,6 +308,7 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
             st4(Z + ch * CS + fr * RS + 4 + 4 * ff, v[k]);
         }
     }
+    NCA_STAMP(13);
     if (ci < 12) {
         const int hr = ci >> 1, zq = (ci & 1) ? WTW + 4 : 3;
         const int hgy = ty0 - 1 + hr, hgx = (ci & 1) ? tx0 + WTW : tx0 - 1;
@@ -526,8 +532,8 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_wave_kernel(const 
         __builtin_amdgcn_s_setprio(3);
         NCA_STAMP(0);
         issue_loads<CP, false, true>(a, cur, lane, R);  // goal encoding: consumed last in staging (S4)
-        if (cur.inner) stage_tile<CP, false>(a, cur, PWR, lane, R);
-        else stage_tile<CP, true>(a, cur, PWR, lane, R);
+        if (cur.inner) stage_tile<CP, false>(a, cur, PWR, lane, R, tile_no);
+        else stage_tile<CP, true>(a, cur, PWR, lane, R, tile_no);
         NCA_STAMP(1);
         const WTile nxt = next_tile();
         constexpr int NT = 2;  // rows per MFMA pass: 2 independent accumulator chains already pace the pipe
