@@ -18,6 +18,7 @@
 #ifndef NCAHIP_H
 #define NCAHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -142,6 +143,26 @@ int ncahip_cond_grow_fwd_f32(float *states, uint8_t *pre, int ring, int T, float
                              int alive_ch, float alive_thr, float fire_rate,
                              float clamp_lo, float clamp_hi, uint64_t seed, uint64_t step0,
                              ncahip_stream_t stream);
+
+/* Backward of ncahip_cond_grow_fwd_f32      autograd through nca.py:207-208 (conditioned_trainer.py:125-132)
+ *   Recomputation: needs only what the forward kept with ring = T+1 -- states [T+1 slots] (slot 0 the
+ *   input, slot k the pending output of step k-1) and pre [T+1 slots] -- plus the same goal / u (or seed,
+ *   step0) / weights.  g_final = dL/d x_final.  Writes dL/dx0 [B,C,H,W], dL/dgoal [B,goal_ch,H,W] (summed over
+ *   the T steps, nca.py:207-208 reuse the same encoding), and the weight gradients in the reference layouts
+ *   (g_wp [3C,9], g_w1 [hidden,3C], g_b1, g_w2 [hidden,hidden], g_b2, g_w3 [C,hidden]); masks carry no
+ *   gradient; clamp passes gradient on the closed interval (torch.clamp).  Deterministic (no float atomics).
+ *   Requires W % 4 == 0 and 16-byte aligned buffers.  `workspace`: ncahip_cond_grow_bwd_workspace() bytes. */
+size_t ncahip_cond_grow_bwd_workspace(int B, int C, int H, int W, int hidden);
+int ncahip_cond_grow_bwd_f32(const float *states, const uint8_t *pre, int T,
+                             const float *goal, int goal_ch, const float *u,
+                             const float *wp, const float *w1, const float *b1,
+                             const float *w2, const float *b2, const float *w3,
+                             int B, int C, int H, int W, int hidden,
+                             int alive_ch, float alive_thr, float fire_rate,
+                             float clamp_lo, float clamp_hi, uint64_t seed, uint64_t step0,
+                             const float *g_final, float *g_x0, float *g_goal,
+                             float *g_wp, float *g_w1, float *g_b1, float *g_w2, float *g_b2, float *g_w3,
+                             void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
 
 /* The [B,1,H,W] uniforms the kernels draw for (seed, step) when u == NULL (for tests/tools). */
 int ncahip_philox_uniform_f32(float *u, int B, int H, int W, uint64_t seed, uint64_t step,

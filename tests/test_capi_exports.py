@@ -15,7 +15,7 @@ def header_prototypes():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(?:int|const char \*)\s*(ncahip_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(?:int|size_t|const char \*)\s*(ncahip_\w+)\s*\(([^)]*)\)\s*;", src):
         args = m.group(2).strip()
         protos[m.group(1)] = 0 if args == "void" else len([a for a in args.split(",") if a.strip()])
     return protos

@@ -323,3 +323,72 @@ def test_cond_full_size_cfg2_vs_oracle(ops):
     ue = torch.stack([ops.philox_uniform(B, H, W, 5, 11 + t) for t in range(2)])
     b, _, _ = ops.cond_grow(x0.to(DEV), 2, goal.to(DEV), ue, w, 3)
     assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ backward (autograd through T steps)
+def _grad_close(got, ref, tol=2e-4):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    scale = max(float(ref.abs().max()), 1e-6)
+    return float((got - ref).abs().max()) / scale < tol
+
+
+def test_cond_grow_backward_golden_g8(ops):
+    """Gradients of <cot, grow(x0)> w.r.t. x0, goal encoding and every weight vs the reference's own autograd."""
+    g = load("g8_cond_grads")
+    prm = sd(g)
+    C, a = g["x0"].shape[1], int(g["alive_ch"])
+    x0, gpad, us, cot = T(g["x0"], DEV), T(g["gpad"], DEV), T(g["us"], DEV), T(g["cot"], DEV)
+    goal = gpad[:, C - 8:].contiguous()
+    w = cond_w(ops, prm, x0)
+    Tn = int(g["T"])
+    xT, states, pre = ops.cond_grow(x0, Tn, goal, us, w, a, keep_history=True)
+    assert rel_err(xT, T(g["xT"])) < REL_TOL
+    gr = ops.cond_grow_backward(states, pre, goal, us, w, cot, Tn, a)
+    assert _grad_close(gr["x0"], T(g["d_x0"]))
+    assert _grad_close(gr["goal"], T(g["d_gpad"])[:, C - 8:])
+    assert _grad_close(gr["wp"].view(3 * C, 1, 3, 3), T(g["grad.perception_net.weight"]))
+    assert _grad_close(gr["w1"], T(g["grad.update_net.out.0.weight"])[:, :, 0, 0])
+    assert _grad_close(gr["b1"], T(g["grad.update_net.out.0.bias"]))
+    assert _grad_close(gr["w2"], T(g["grad.update_net.out.2.weight"])[:, :, 0, 0])
+    assert _grad_close(gr["b2"], T(g["grad.update_net.out.2.bias"]))
+    assert _grad_close(gr["w3"], T(g["grad.update_net.out.4.weight"])[:, :, 0, 0])
+    # deterministic: bitwise identical on a second run
+    gr2 = ops.cond_grow_backward(states, pre, goal, us, w, cot, Tn, a)
+    for k in gr:
+        assert torch.equal(gr[k], gr2[k]), k
+
+
+@pytest.mark.parametrize("C,shape,gch,alive,Tn", [(16, (2, 32, 48), 12, 3, 3), (12, (1, 20, 36), 8, 3, 2), (16, (2, 16, 16), 16, -1, 2)])
+def test_cond_grow_backward_vs_oracle_autograd(ops, C, shape, gch, alive, Tn):
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(C + W)
+    prm = rand_cond_prm(C, seed=C + 1, out_scale=2.0)
+    x0 = torch.rand(B, C, H, W, generator=gen)
+    if alive >= 0:
+        x0[0, :, : H // 4] = 0.0
+        x0[-1, :, H // 2: H // 2 + 2, 4:8] *= 30.0
+    goal = torch.randn(B, gch, H, W, generator=gen)
+    us = torch.rand(Tn, B, 1, H, W, generator=gen)
+    cot = torch.randn(B, C, H, W, generator=gen)
+    xT, dx0, dg, grads = O.cond_grow_loss_grads(x0, O.cond_pad_goal(goal, C), list(us), prm, max(alive, 0), 0.1, 0.5, cot) \
+        if alive >= 0 else _oracle_noalive_grads(x0, goal, us, prm, cot, C)
+    w = cond_w(ops, prm, x0.to(DEV))
+    _, states, pre = ops.cond_grow(x0.to(DEV), Tn, goal.to(DEV), us.to(DEV), w, alive, keep_history=True)
+    gr = ops.cond_grow_backward(states, pre, goal.to(DEV), us.to(DEV), w, cot.to(DEV), Tn, alive)
+    assert _grad_close(gr["x0"], dx0)
+    assert _grad_close(gr["goal"], dg[:, C - gch:])
+    assert _grad_close(gr["wp"].view(3 * C, 1, 3, 3), grads["perception_net.weight"])
+    for k, n in (("w1", "update_net.out.0.weight"), ("w2", "update_net.out.2.weight"), ("w3", "update_net.out.4.weight")):
+        assert _grad_close(gr[k], grads[n][:, :, 0, 0]), k
+    assert _grad_close(gr["b1"], grads["update_net.out.0.bias"]) and _grad_close(gr["b2"], grads["update_net.out.2.bias"])
+
+
+def _oracle_noalive_grads(x0, goal, us, prm, cot, C):
+    x0 = x0.clone().requires_grad_(True)
+    g = O.cond_pad_goal(goal, C).clone().requires_grad_(True)
+    p = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+    x = x0
+    for u in us:
+        x = O.cond_step(x, g, u, p, 0, 0.1, 0.5, use_living_channel=False)
+    (x * cot).sum().backward()
+    return x.detach(), x0.grad, g.grad, {k: v.grad for k, v in p.items()}

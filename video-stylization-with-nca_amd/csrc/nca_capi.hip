@@ -186,6 +186,74 @@ int ncahip_cond_grow_fwd_f32(float* states, uint8_t* pre, int ring, int T, float
                                                alive_ch, alive_thr, clamp_lo, clamp_hi, st), "cond_grow finalize");
 }
 
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t ncahip_cond_grow_bwd_workspace(int B, int C, int H, int W, int hidden) {
+    if (!dims_ok(B, C, H, W) || hidden <= 0) return 0;
+    const size_t n = (size_t)B * C * H * W * sizeof(float);
+    return 4 * align256(n) + align256(3 * n) +
+           align256((size_t)nca_cond_bwd_nslab() * nca_cond_bwd_slab_floats(C, hidden) * sizeof(float)) +
+           align256((size_t)nca_cond_bwd_nblk(B, C, H, W) * 27 * sizeof(float));
+}
+
+int ncahip_cond_grow_bwd_f32(const float* states, const uint8_t* pre, int T, const float* goal, int goal_ch,
+                             const float* u, const float* wp, const float* w1, const float* b1, const float* w2,
+                             const float* b2, const float* w3, int B, int C, int H, int W, int hidden, int alive_ch,
+                             float alive_thr, float fire_rate, float clamp_lo, float clamp_hi, uint64_t seed,
+                             uint64_t step0, const float* g_final, float* g_x0, float* g_goal, float* g_wp, float* g_w1,
+                             float* g_b1, float* g_w2, float* g_b2, float* g_w3, void* workspace, size_t workspace_bytes,
+                             ncahip_stream_t stream) {
+    if (T < 1 || !states || !pre || !g_final || !g_x0 || !g_wp || !g_w1 || !g_b1 || !g_w2 || !g_b2 || !g_w3 || !workspace)
+        return fail(NCAHIP_EINVAL, "cond grow bwd: null pointer or T < 1");
+    if (int rc = check_cond(states, g_x0, pre, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch)) return rc;
+    if (goal_ch > 0 && !g_goal) return fail(NCAHIP_EINVAL, "cond grow bwd: g_goal required when goal_ch > 0");
+    if (W % 4 != 0 || ((uintptr_t)states | (uintptr_t)goal | (uintptr_t)g_final | (uintptr_t)g_x0 | (uintptr_t)workspace) % 16 != 0)
+        return fail(NCAHIP_ERANGE, "cond grow bwd: needs W %% 4 == 0 and 16-byte aligned buffers");
+    if (workspace_bytes < ncahip_cond_grow_bwd_workspace(B, C, H, W, hidden))
+        return fail(NCAHIP_EINVAL, "cond grow bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t slot = (size_t)B * C * H * W, pslot = (size_t)B * H * W, nb = slot * sizeof(float);
+    char* p = (char*)workspace;
+    float* gbuf[2] = {(float*)p, (float*)(p + align256(nb))};
+    p += 2 * align256(nb);
+    float* gx = (float*)p; p += align256(nb);
+    float* zbuf = (float*)p; p += align256(nb);
+    float* dP = (float*)p; p += align256(3 * nb);
+    const int nslab = nca_cond_bwd_nslab(), sf = nca_cond_bwd_slab_floats(C, hidden), nblk = nca_cond_bwd_nblk(B, C, H, W);
+    float* slabs = (float*)p; p += align256((size_t)nslab * sf * sizeof(float));
+    float* wpp = (float*)p;
+    hipError_t e = hipMemsetAsync(slabs, 0, (size_t)nslab * sf * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(wpp, 0, (size_t)nblk * 27 * sizeof(float), st);
+    if (e == hipSuccess && goal_ch > 0) e = hipMemsetAsync(g_goal, 0, (size_t)B * goal_ch * H * W * sizeof(float), st);
+    if (e != hipSuccess) return hip_result(e, "cond grow bwd memset");
+    const float* gcur = g_final;
+    for (int t = T - 1; t >= 0; --t) {
+        NcaCondBwdArgs ba{};
+        ba.f = NcaCondArgs{states + (size_t)t * slot, t == 0 ? nullptr : pre + (size_t)t * pslot, nullptr, nullptr, goal,
+                           u ? u + (size_t)t * pslot : nullptr, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch,
+                           alive_ch, alive_thr, fire_rate, clamp_lo, clamp_hi, seed, step0 + (uint64_t)t, nullptr};
+        ba.x_next = states + (size_t)(t + 1) * slot;
+        ba.pre_t = pre + (size_t)(t + 1) * pslot;
+        ba.g_next = gcur;
+        ba.g_out = t == 0 ? g_x0 : gbuf[t & 1];
+        ba.gx = gx; ba.dP = dP; ba.zbuf = zbuf; ba.dgoal = g_goal; ba.slabs = slabs; ba.wp_partials = wpp;
+        ba.nslab = nslab; ba.nblk = nblk;
+        if (int rc = hip_result(nca_launch_cond_step_bwd(ba, st), "cond_grow_bwd step")) return rc;
+        gcur = ba.g_out;
+    }
+    // slabs -> gradients (layout: w1 | w2 | w3 | b1 | b2)
+    float* red = gbuf[0];  // reuse: >= slab_floats
+    if (int rc = hip_result(nca_launch_reduce_rows(slabs, red, nslab, sf, st), "cond_grow_bwd reduce")) return rc;
+    const size_t o2 = (size_t)hidden * 3 * C, o3 = o2 + (size_t)hidden * hidden, ob1 = o3 + (size_t)C * hidden, ob2 = ob1 + hidden;
+    e = hipMemcpyAsync(g_w1, red, o2 * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(g_w2, red + o2, (size_t)hidden * hidden * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(g_w3, red + o3, (size_t)C * hidden * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(g_b1, red + ob1, hidden * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(g_b2, red + ob2, hidden * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return hip_result(e, "cond grow bwd copy");
+    return hip_result(nca_launch_reduce_wp(wpp, g_wp, B, C, H, W, st), "cond_grow_bwd reduce wp");
+}
+
 int ncahip_philox_uniform_f32(float* u, int B, int H, int W, uint64_t seed, uint64_t step, ncahip_stream_t stream) {
     if (!u || B <= 0 || H <= 0 || W <= 0) return fail(NCAHIP_EINVAL, "philox_uniform: bad argument");
     return hip_result(nca_launch_philox_uniform(u, B, H, W, seed, step, (hipStream_t)stream), "philox_uniform");

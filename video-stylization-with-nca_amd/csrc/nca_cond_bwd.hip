@@ -1,0 +1,605 @@
+// nca_cond_bwd.hip -- backward of one ConditionedNCA step (EncoderConditioning/nca.py:181-195 under
+// autograd, conditioned_trainer.py:125-132), gfx950, fp32.
+//
+// Recomputation design: only the pending states x'_t and the 1-byte pre masks are kept by
+// the forward pass.  Per step, two launches:
+//   A  cond_step_bwd_kernel   wave-private 4x16 tiles, same staging as the forward kernel (resolve s_t, pre_t,
+//      z_t in LDS).  The forward MLP is recomputed on MFMA with h1/h2 kept in registers; the incoming gradient
+//      is gated by life_t and the clamp pass-band (closed interval, as torch.clamp) -> dL/dx'_t; the data path
+//      runs back through W3^T, W2^T, W1^T on MFMA (accumulator tile == next B operand, as in the forward);
+//      weight gradients are MFMA products with the CELL axis as K: each 16-cell tile's activations are
+//      transposed through an 18-float-stride LDS buffer (conflict-free operand reads) and accumulated in 128
+//      persistent accumulator registers, flushed once per launch into this wave's slab (deterministic).
+//      Outputs dL/dperception [B,3C,H,W], dL/dx'_t and z_t.
+//   B  cond_step_bwd_stencil_kernel   HBM-bound: dL/ds_t = dL/dx'_t + depthwise-stencil^T(dL/dperception),
+//      dL/dgoal += dz * pre_t, per-block partials of the perception-weight gradient.
+// One wave per SIMD (the persistent accumulators need the registers); 4 waves / workgroup / CU.
+#include "nca_cond_tile.h"
+
+namespace {
+
+constexpr int kBwdWaves = 4, kBwdThreads = 256;
+constexpr int TBS = 18;  // transposition buffer row stride: bank(18*i + g) distinct over a 32-lane half
+
+template <int CP>
+struct BCfg {
+    using F = WCfg<CP>;
+    static constexpr int K1S = F::K1S;
+    static constexpr int MJ = (3 * CP + 15) / 16;           // 16-row tiles of the perception index
+    static constexpr int OFF_W3T = F::SHARED;               // [4 m][4 s][64]
+    static constexpr int OFF_W1T = OFF_W3T + 4 * 4 * 64;    // [MJ][16 s][64]
+    static constexpr int SHARED = OFF_W1T + MJ * 16 * 64;
+    static constexpr int PW_TB = F::PW;                     // 128 rows x 18
+    static constexpr int PW_A1 = PW_TB + 128 * TBS;         // alpha'_t halo 1: 6 x RS
+    static constexpr int PW = PW_A1 + ZROWS * RS;
+    static constexpr int LDS_FLOATS = SHARED + kBwdWaves * PW;
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+    static_assert(CP <= 16, "one 16-row output tile (M3T == 1)");
+};
+
+// slab layout (floats), runtime C / hidden: [w1 hid*3C | w2 hid*hid | w3 C*hid | b1 hid | b2 hid]
+__host__ __device__ inline int slab_off_w2(int C, int hid) { return hid * 3 * C; }
+__host__ __device__ inline int slab_off_w3(int C, int hid) { return slab_off_w2(C, hid) + hid * hid; }
+__host__ __device__ inline int slab_off_b1(int C, int hid) { return slab_off_w3(C, hid) + C * hid; }
+__host__ __device__ inline int slab_off_b2(int C, int hid) { return slab_off_b1(C, hid) + hid; }
+__host__ __device__ inline int slab_floats(int C, int hid) { return slab_off_b2(C, hid) + hid; }
+
+template <int CP>
+__global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const NcaCondBwdArgs ba) {
+    using K = BCfg<CP>;
+    using FK = WCfg<CP>;
+    constexpr int NT = 2;
+    const NcaCondArgs& a = ba.f;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = a.C, H = a.H, W = a.W, hid = a.hidden, K1 = 3 * C;
+    const unsigned plane = (unsigned)(H * W);
+    const int g = lane >> 4, ci = lane & 15;
+
+    // ---- forward A-operand images (identical to the forward kernel) + transposed images --------------------
+    fill_image_w<4 * FK::K1S * 64, kBwdThreads>(smem + FK::OFF_W1, a.w1, tid, [&](int idx) -> long {
+        const int l = idx & 63, s = (idx >> 6) % FK::K1S, m = (idx >> 6) / FK::K1S;
+        const int gg = l >> 4, o = 16 * m + (l & 15);
+        const int ch = 4 * (s / 3) + gg, f = s % 3;
+        return (ch < C && o < hid) ? (long)o * K1 + 3 * ch + f : -1;
+    });
+    fill_image_w<4 * 16 * 64, kBwdThreads>(smem + FK::OFF_W2, a.w2, tid, [&](int idx) -> long {
+        const int l = idx & 63, s = (idx >> 6) % 16, m = (idx >> 6) / 16;
+        const int gg = l >> 4, o = 16 * m + (l & 15);
+        const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
+        return (o < hid && k < hid) ? (long)o * hid + k : -1;
+    });
+    fill_image_w<FK::HID, kBwdThreads>(smem + FK::OFF_B1, a.b1, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
+    fill_image_w<FK::HID, kBwdThreads>(smem + FK::OFF_B2, a.b2, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
+    fill_image_w<CP * FK::WPS, kBwdThreads>(smem + FK::OFF_WP, a.wp, tid, [&](int idx) -> long {
+        const int ch = idx / FK::WPS, j = idx % FK::WPS;
+        return (ch < C && j < 27) ? (long)ch * 27 + j : -1;
+    });
+    // W3^T: lane (gg,i) of (m, s) holds W3[ch = 4gg+s][h2 = 16m+i]
+    fill_image_w<4 * 4 * 64, kBwdThreads>(smem + K::OFF_W3T, a.w3, tid, [&](int idx) -> long {
+        const int l = idx & 63, s = (idx >> 6) % 4, m = (idx >> 6) / 4;
+        const int ch = 4 * (l >> 4) + s, h2 = 16 * m + (l & 15);
+        return (ch < C && h2 < hid) ? (long)ch * hid + h2 : -1;
+    });
+    // W1^T: lane (gg,i) of (mj, s) holds W1[h1 = 16(s/4)+4gg+s%4][j = 16mj+i]
+    fill_image_w<K::MJ * 16 * 64, kBwdThreads>(smem + K::OFF_W1T, a.w1, tid, [&](int idx) -> long {
+        const int l = idx & 63, s = (idx >> 6) % 16, mj = (idx >> 6) / 16;
+        const int h1 = 16 * (s >> 2) + 4 * (l >> 4) + (s & 3), j = 16 * mj + (l & 15);
+        return (h1 < hid && j < K1) ? (long)h1 * K1 + j : -1;
+    });
+    __syncthreads();
+
+    const float* const W1L = smem + FK::OFF_W1;
+    const float* const W2L = smem + FK::OFF_W2;
+    const float* const B1L = smem + FK::OFF_B1;
+    const float* const B2L = smem + FK::OFF_B2;
+    const float* const W3T = smem + K::OFF_W3T;
+    const float* const W1T = smem + K::OFF_W1T;
+    float* const PWR = smem + K::SHARED + wave * K::PW;
+    float* const Z = PWR + FK::PW_Z;
+    float* const XR = PWR + FK::PW_XR;
+    float* const PN = PWR + FK::PW_A3;
+    const float* const MK = PWR + FK::PW_A3 + ZROWS * RS;
+    float* const TB = PWR + K::PW_TB;
+    float* const A1 = PWR + K::PW_A1;
+
+    // persistent weight-gradient accumulators (D = A * B^T with the cell axis as K)
+    f32x4 aW1[4][K::MJ], aW2[4][4], aW3[4];
+    float db1[4][4], db2[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        aW3[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { aW2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; db1[i][j] = 0.f; db2[i][j] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < K::MJ; ++j) aW1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- tile walk: super-tiles of 16 x 16 (4 waves stacked vertically) ------------------------------------
+    constexpr int BSTH = 16, BSTW = 16;
+    const int st_x = (W + BSTW - 1) / BSTW, st_y = (H + BSTH - 1) / BSTH;
+    const int halo = a.alive_ch >= 0 ? 3 : 1;
+    const bool use_alive = a.alive_ch >= 0;
+    for (NcaTileWalk tw = nca_tile_walk(a.B * st_x * st_y); tw.t < tw.end; tw.t += tw.stride) {
+        WTile t;
+        t.b = tw.t / (st_x * st_y);
+        t.ty0 = ((tw.t / st_x) % st_y) * BSTH + wave * WTH;
+        t.tx0 = (tw.t % st_x) * BSTW;
+        if (t.ty0 >= H || t.tx0 >= W) continue;
+        t.valid = true;
+        t.inner = t.ty0 >= halo && t.ty0 + WTH + halo <= H && t.tx0 >= halo && t.tx0 + WTW + halo <= W;
+        const int ty0 = t.ty0, tx0 = t.tx0;
+
+        // ---- forward staging: s_t (XR), pre_t (PN), z_t (Z), fire mask (MK) -------------------------------
+        TileRegs<CP> R;
+        issue_loads<CP, true, true>(a, t, lane, R);
+        if (t.inner) stage_tile<CP, false>(a, t, PWR, lane, R, 0);
+        else stage_tile<CP, true>(a, t, PWR, lane, R, 0);
+
+        // ---- pending x'_t: alpha halo 1 -> A1 (post mask), interior -> XR; incoming gradient -> TB --------
+        const float* const xn = ba.x_next + (size_t)t.b * C * plane;
+        const float* const gn = ba.g_next + (size_t)t.b * C * plane;
+        {
+            const int hl = lane >> 5, l5 = lane & 31;
+            if (use_alive) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int r = 2 * k + hl, gy = ty0 - 1 + r, gx = tx0 - 1 + l5;
+                    const bool ok = l5 < 18 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                    const float v = xn[(unsigned)a.alive_ch * plane + (ok ? (unsigned)(gy * W + gx) : 0u)];
+                    if (l5 < 18) A1[r * RS + l5 + 3] = ok ? v : NCA_NEG_INF;
+                }
+            }
+            const int row = (lane >> 2) & 3, ff = lane & 3, gy = ty0 + row, gx = tx0 + 4 * ff;
+            const bool ok = gy < H && gx + 3 < W;
+            const unsigned off = ok ? (unsigned)(gy * W + gx) : 0u;
+            f32x4 xv[CP / 4], gv[CP / 4];
+#pragma unroll
+            for (int k = 0; k < CP / 4; ++k) {
+                const unsigned ch = (unsigned)min(4 * k + g, C - 1);
+                xv[k] = ld4(xn + ch * plane + off);
+                gv[k] = ld4(gn + ch * plane + off);
+            }
+            // z_t interior out (kernel B needs it for the perception-weight gradient)
+            float* const zo = ba.zbuf + (size_t)t.b * C * plane + off;
+#pragma unroll
+            for (int k = 0; k < CP / 4; ++k) {
+                const int ch = 4 * k + g;
+                const f32x4 zv = ld4(Z + ch * CS + (row + 1) * RS + 4 + 4 * ff);
+                if (ok && ch < C) st4(zo + (unsigned)ch * plane, zv);
+            }
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < CP / 4; ++k) {
+                const int ch = 4 * k + g;
+                const bool live = ok && ch < C;
+                st4(XR + ch * XRS + row * WTW + 4 * ff, live ? xv[k] : f32x4{0.f, 0.f, 0.f, 0.f});
+                st4(TB + ch * XRS + row * WTW + 4 * ff, live ? gv[k] : f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+            wave_sync();
+        }
+
+#pragma unroll 1
+        for (int pass = 0; pass < WTH / NT; ++pass) {
+            const int n0 = pass * NT;
+            // ---- forward recompute: P, h1, h2 kept in registers ------------------------------------------
+            float P[NT][K::K1S];
+            perceive_tile<CP, NT>(smem, PWR, lane, n0, P);
+            f32x4 h1[4][NT], h2[4][NT];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 bias = ld4(B1L + 16 * m + 4 * g);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) h1[m][n] = bias;
+#pragma unroll
+                for (int s = 0; s < K::K1S; ++s) {
+                    const float wa = W1L[(m * K::K1S + s) * 64 + lane];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) h1[m][n] = nca_mfma(wa, P[n][s], h1[m][n]);
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h1[m][n][r] = relu(h1[m][n][r]);
+            }
+#pragma unroll
+            for (int m2 = 0; m2 < 4; ++m2) {
+                const f32x4 bias = ld4(B2L + 16 * m2 + 4 * g);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) h2[m2][n] = bias;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float wa = W2L[(m2 * 16 + 4 * m + r) * 64 + lane];
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) h2[m2][n] = nca_mfma(wa, h1[m][n][r], h2[m2][n]);
+                    }
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h2[m2][n][r] = relu(h2[m2][n][r]);
+            }
+            // ---- dL/dx'_t = G * 1[lo <= x'*life <= hi] * life (nca.py:191-194);  d out = . * fire mask ------
+            float dO[NT][4];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int row = n0 + n;
+                float life = PN[(row + 1) * RS + ci + 4];
+                if (use_alive) life = (life != 0.0f && max3x3(A1 + (row + 1) * RS + ci + 4) > a.thr) ? 1.0f : 0.0f;
+                const float mk = MK[row * WTW + ci];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = 4 * g + r;
+                    float* const xp = XR + ch * XRS + row * WTW + ci;
+                    const float y = *xp * life;
+                    const float gxv = (y >= a.lo && y <= a.hi) ? TB[ch * XRS + row * WTW + ci] * life : 0.0f;
+                    *xp = gxv;  // XR now carries dL/dx'_t for the 16-byte store pass
+                    dO[n][r] = gxv * mk;
+                }
+            }
+            // ---- data path: W3^T, W2^T, W1^T ---------------------------------------------------------------
+            f32x4 d2[4][NT], d1[4][NT], dp[K::MJ][NT];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) d2[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float wa = W3T[(m * 4 + s) * 64 + lane];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) d2[m][n] = nca_mfma(wa, dO[n][s], d2[m][n]);
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d2[m][n][r] = h2[m][n][r] > 0.0f ? d2[m][n][r] : 0.0f;
+            }
+            const int w2t_lane = (ci & 3) * 64 + (ci >> 2) * 16 + 4 * g;  // transposed read of the forward W2 image
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) d1[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mp = 0; mp < 4; ++mp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float wa = W2L[(mp * 16 + 4 * m) * 64 + w2t_lane + r];  // W2[h2 = 16mp+4g+r][h1 = 16m+ci]
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) d1[m][n] = nca_mfma(wa, d2[mp][n][r], d1[m][n]);
+                    }
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d1[m][n][r] = h1[m][n][r] > 0.0f ? d1[m][n][r] : 0.0f;
+            }
+#pragma unroll
+            for (int mj = 0; mj < K::MJ; ++mj) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) dp[mj][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mp = 0; mp < 4; ++mp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float wa = W1T[(mj * 16 + 4 * mp + r) * 64 + lane];
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) dp[mj][n] = nca_mfma(wa, d1[mp][n][r], dp[mj][n]);
+                    }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) { db1[m][r] += d1[m][n][r]; db2[m][r] += d2[m][n][r]; }
+
+            // ---- weight gradients: per 16-cell tile, transpose through TB (rows = channel index, 16 cells) ----
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                wave_sync();  // TB free (gradient tile consumed above / previous products done)
+                // dW3 = dO (16) x h2 (64):  rows 0..15 | 16..79
+#pragma unroll
+                for (int r = 0; r < 4; ++r) TB[(4 * g + r) * TBS + ci] = dO[n][r];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) TB[(16 + 16 * m + 4 * g + r) * TBS + ci] = h2[m][n][r];
+                wave_sync();
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float av = TB[ci * TBS + 4 * s + g];
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+                        aW3[nb] = nca_mfma(av, TB[(16 + 16 * nb + ci) * TBS + 4 * s + g], aW3[nb]);
+                }
+                wave_sync();
+                // dW2 = d2 (64) x h1 (64): rows 0..63 | 64..127
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        TB[(16 * m + 4 * g + r) * TBS + ci] = d2[m][n][r];
+                        TB[(64 + 16 * m + 4 * g + r) * TBS + ci] = h1[m][n][r];
+                    }
+                wave_sync();
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    float bv[4];
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) bv[nb] = TB[(64 + 16 * nb + ci) * TBS + 4 * s + g];
+#pragma unroll
+                    for (int ma = 0; ma < 4; ++ma) {
+                        const float av = TB[(16 * ma + ci) * TBS + 4 * s + g];
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) aW2[ma][nb] = nca_mfma(av, bv[nb], aW2[ma][nb]);
+                    }
+                }
+                wave_sync();
+                // dW1 = d1 (64) x P (3C, natural index j = 3c+f): rows 0..63 | 64..64+16*MJ
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) TB[(16 * m + 4 * g + r) * TBS + ci] = d1[m][n][r];
+#pragma unroll
+                for (int c4 = 0; c4 < CP / 4; ++c4)
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) TB[(64 + 3 * (4 * c4 + g) + f) * TBS + ci] = P[n][3 * c4 + f];
+                wave_sync();
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    float bv[K::MJ];
+#pragma unroll
+                    for (int nb = 0; nb < K::MJ; ++nb) bv[nb] = TB[(64 + 16 * nb + ci) * TBS + 4 * s + g];
+#pragma unroll
+                    for (int ma = 0; ma < 4; ++ma) {
+                        const float av = TB[(16 * ma + ci) * TBS + 4 * s + g];
+#pragma unroll
+                        for (int nb = 0; nb < K::MJ; ++nb) aW1[ma][nb] = nca_mfma(av, bv[nb], aW1[ma][nb]);
+                    }
+                }
+            }
+            // ---- dL/dperception out: [j][2 rows][16] via TB, 16-byte stores -----------------------------------
+            wave_sync();
+#pragma unroll
+            for (int mj = 0; mj < K::MJ; ++mj)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) TB[(16 * mj + 4 * g + r) * 36 + n * 16 + ci] = dp[mj][n][r];
+            wave_sync();
+            {
+                const int rr = (lane >> 2) & 1, ff = lane & 3, jl = lane >> 3;  // 8 rows of j per instruction
+                const int gy = ty0 + n0 + rr, gx = tx0 + 4 * ff;
+                const bool ok = gy < H && gx + 3 < W;
+                float* const po = ba.dP + (size_t)t.b * 3 * C * plane + (ok ? (unsigned)(gy * W + gx) : 0u);
+#pragma unroll
+                for (int k = 0; k < 2 * K::MJ; ++k) {
+                    const int j = 8 * k + jl;
+                    const f32x4 v = ld4(TB + j * 36 + rr * 16 + 4 * ff);
+                    if (ok && j < K1) st4(po + (unsigned)j * plane, v);
+                }
+            }
+        }
+        // ---- dL/dx'_t out (XR), 16-byte stores ---------------------------------------------------------------
+        wave_sync();
+        {
+            const int row = (lane >> 2) & 3, ff = lane & 3, gy = ty0 + row, gx = tx0 + 4 * ff;
+            const bool ok = gy < H && gx + 3 < W;
+            float* const go = ba.gx + (size_t)t.b * C * plane + (ok ? (unsigned)(gy * W + gx) : 0u);
+#pragma unroll
+            for (int k = 0; k < CP / 4; ++k) {
+                const int ch = 4 * k + g;
+                if (ok && ch < C) st4(go + (unsigned)ch * plane, ld4(XR + ch * XRS + row * WTW + 4 * ff));
+            }
+        }
+        wave_sync();
+    }
+
+    // ---- flush this wave's partial weight gradients into its slab (+=) -------------------------------------------
+    float* const slab = ba.slabs + (size_t)(blockIdx.x * kBwdWaves + wave) * slab_floats(C, hid);
+#pragma unroll
+    for (int ma = 0; ma < 4; ++ma)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = 16 * ma + 4 * g + r;
+            if (o < hid) {
+#pragma unroll
+                for (int nb = 0; nb < K::MJ; ++nb)
+                    if (16 * nb + ci < K1) slab[o * K1 + 16 * nb + ci] += aW1[ma][nb][r];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    if (16 * nb + ci < hid) slab[slab_off_w2(C, hid) + o * hid + 16 * nb + ci] += aW2[ma][nb][r];
+            }
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ch = 4 * g + r;
+        if (ch < C) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                if (16 * nb + ci < hid) slab[slab_off_w3(C, hid) + ch * hid + 16 * nb + ci] += aW3[nb][r];
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s1 = db1[m][r], s2 = db2[m][r];
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
+            const int o = 16 * m + 4 * g + r;
+            if (ci == 0 && o < hid) {
+                slab[slab_off_b1(C, hid) + o] += s1;
+                slab[slab_off_b2(C, hid) + o] += s2;
+            }
+        }
+}
+
+// Kernel B: dL/ds_t = dL/dx'_t + stencil^T(dL/dP);  dL/dgoal += dz * pre_t;  perception-weight partials.
+// One thread = 4 W-contiguous cells of one (b, c, row); a block never spans two channels.
+__global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCondBwdArgs ba) {
+    const NcaCondArgs& a = ba.f;
+    const int C = a.C, H = a.H, W = a.W;
+    const size_t plane = (size_t)H * W;
+    const int W4 = (W + 3) / 4;
+    const int per_plane = H * W4, blocks_per_plane = (per_plane + 255) / 256;
+    const int bc = blockIdx.x / blocks_per_plane, b = bc / C, c = bc % C;
+    const int id = (blockIdx.x % blocks_per_plane) * 256 + threadIdx.x;
+    const bool active = id < per_plane;
+    const int yy = active ? id / W4 : 0, x0 = active ? (id % W4) * 4 : 0;
+    const float* const wp = a.wp + (size_t)c * 27;
+    float wl[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) wl[i] = wp[i];
+    const float* const dPb = ba.dP + ((size_t)b * 3 * C + 3 * c) * plane;
+    const float* const zb = ba.zbuf + ((size_t)b * C + c) * plane;
+    float dz[4] = {0.f, 0.f, 0.f, 0.f}, wsum[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) wsum[i] = 0.f;
+    if (active) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int sy = yy + dy - 1;
+            if (sy < 0 || sy >= H) continue;
+            float zrow[6], prow[3][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int sx = x0 - 1 + j;
+                const bool in = sx >= 0 && sx < W;
+                zrow[j] = in ? zb[(size_t)sy * W + sx] : 0.0f;
+#pragma unroll
+                for (int f = 0; f < 3; ++f) prow[f][j] = in ? dPb[(size_t)f * plane + (size_t)sy * W + sx] : 0.0f;
+            }
+            // dz[q] += sum_f sum_dx Wp[f][2-dy'][2-dx] ... written as: source row sy = yy - (ty-1) -> ty = 1-(dy-1)
+            const int ty = 2 - dy;  // tap row of the forward filter that maps (sy) -> output row yy... transposed
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) dz[j] = fmaf(wl[9 * f + 3 * ty + (2 - dx)], prow[f][j + dx], dz[j]);
+            // perception-weight gradient: dWp[f][dy][dx] += dP[f][yy][x] * z[yy+dy-1][x+dx-1]; needs dP at (yy, x)
+            if (dy == 0) {}
+        }
+        // second sweep for dWp (dP at the centre row, z at the three rows)
+        float pc[3][4];
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pc[f][j] = (x0 + j < W) ? dPb[(size_t)f * plane + (size_t)yy * W + x0 + j] : 0.0f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int sy = yy + dy - 1;
+            if (sy < 0 || sy >= H) continue;
+            float zrow[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int sx = x0 - 1 + j;
+                zrow[j] = (sx >= 0 && sx < W) ? zb[(size_t)sy * W + sx] : 0.0f;
+            }
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wsum[9 * f + 3 * dy + dx] = fmaf(pc[f][j], zrow[j + dx], wsum[9 * f + 3 * dy + dx]);
+        }
+        const size_t off = (size_t)yy * W + x0;
+        const float* const gxp = ba.gx + ((size_t)b * C + c) * plane + off;
+        float* const go = ba.g_out + ((size_t)b * C + c) * plane + off;
+        const int gch0 = C - a.goal_ch;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (x0 + j < W) {
+                go[j] = gxp[j] + dz[j];
+                if (c >= gch0) {
+                    const float pre = a.alive_ch >= 0 ? (float)ba.pre_t[(size_t)b * plane + off + j] : 1.0f;
+                    ba.dgoal[((size_t)b * a.goal_ch + (c - gch0)) * plane + off + j] += dz[j] * pre;
+                }
+            }
+    }
+    // block reduction of the 27 perception-weight partials (fixed order: deterministic)
+    __shared__ float red[4][27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) {
+        float v = wsum[i];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        ba.wp_partials[(size_t)blockIdx.x * 27 + threadIdx.x] += v;
+    }
+}
+
+// dst[j] = sum_i src[i*m + j] (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int m) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    float acc = 0.0f;
+    for (int i = 0; i < n; ++i) acc += src[(size_t)i * m + j];
+    dst[j] = acc;
+}
+// perception-weight partials [B*C*bpp][27] -> grad [C][27]
+__global__ __launch_bounds__(64) void reduce_wp_kernel(const float* __restrict__ part, float* __restrict__ dst, int B, int C, int bpp) {
+    const int c = blockIdx.x, i = threadIdx.x;
+    if (i >= 27) return;
+    float acc = 0.0f;
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < bpp; ++k) acc += part[((size_t)(b * C + c) * bpp + k) * 27 + i];
+    dst[c * 27 + i] = acc;
+}
+
+template <int CP>
+hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
+    using K = BCfg<CP>;
+    auto kern = cond_step_bwd_kernel<CP>;
+    const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
+    static thread_local bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const NcaCondArgs& a = ba.f;
+    const int nst = a.B * ((a.W + 15) / 16) * ((a.H + 15) / 16);
+    const int grid = nst < ba.nslab / kBwdWaves ? nst : ba.nslab / kBwdWaves;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), lds, st, ba);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cond_step_bwd_stencil_kernel, dim3(ba.nblk), dim3(256), 0, st, ba);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+int nca_cond_bwd_slab_floats(int C, int hidden) { return slab_floats(C, hidden); }
+int nca_cond_bwd_nslab() {
+    int dev = 0, v = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+        cus = v;
+    return cus * kBwdWaves;
+}
+int nca_cond_bwd_nblk(int B, int C, int H, int W) { return B * C * ((H * ((W + 3) / 4) + 255) / 256); }
+
+// W % 4 == 0 and 16-byte aligned tensors required (checked by the C ABI).
+hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
+    if (ba.f.C <= 12) return launch_bwd<12>(ba, st);
+    if (ba.f.C <= 16) return launch_bwd<16>(ba, st);
+    return hipErrorInvalidValue;
+}
+
+hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((m + 255) / 256), dim3(256), 0, st, src, dst, n, m);
+    return hipGetLastError();
+}
+hipError_t nca_launch_reduce_wp(const float* part, float* dst, int B, int C, int H, int W, hipStream_t st) {
+    const int bpp = (H * ((W + 3) / 4) + 255) / 256;
+    hipLaunchKernelGGL(reduce_wp_kernel, dim3(C), dim3(64), 0, st, part, dst, B, C, bpp);
+    return hipGetLastError();
+}

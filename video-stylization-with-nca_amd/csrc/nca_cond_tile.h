@@ -1,0 +1,363 @@
+// nca_cond_tile.h -- device code shared by the wave-private ConditionedNCA kernels (forward:
+// nca_cond_wave.hip, backward: nca_cond_bwd.hip): LDS carve, tile walk, batched global loads,
+// pending-life-mask resolution and staging, perception.  See nca_cond_wave.hip for the design notes.
+#pragma once
+#include "nca_common.h"
+#include "nca_kernels.h"
+
+namespace {
+
+
+constexpr int kWaves = 8, kThreadsW = kWaves * 64;
+constexpr int WTH = 4, WTW = 16;  // wave tile
+constexpr int STH = 16, STW = 32; // super-tile of a workgroup: 4 x 2 wave tiles
+constexpr int RS = 24;            // LDS row stride of every per-wave 2-D array; image col tx0+c <-> index c+4
+constexpr int ZROWS = WTH + 2, CS = ZROWS * RS;  // 144 floats per channel (144 % 32 == 16)
+constexpr int XRS = 68;           // resolved-state copy: channel stride (4*68 % 32 == 16)
+static_assert(CS % 32 == 16 && (4 * XRS) % 32 == 16, "bank layout");
+
+template <int CP>
+struct WCfg {
+    static constexpr int HID = 64;
+    static constexpr int K1S = 3 * CP / 4;
+    static constexpr int M3T = (CP + 15) / 16;
+    static constexpr int WPS = 28;
+    // shared weight image (floats)
+    static constexpr int OFF_W1 = 0;
+    static constexpr int OFF_W2 = OFF_W1 + 4 * K1S * 64;
+    static constexpr int OFF_W3 = OFF_W2 + 4 * 16 * 64;
+    static constexpr int OFF_B1 = OFF_W3 + M3T * 16 * 64;
+    static constexpr int OFF_B2 = OFF_B1 + HID;
+    static constexpr int OFF_WP = OFF_B2 + HID;
+    static constexpr int SHARED = OFF_WP + CP * WPS;
+    // per-wave region (floats)
+    static constexpr int PW_Z = 0;
+    static constexpr int PW_XR = PW_Z + CP * CS;
+    static constexpr int PW_A3 = PW_XR + CP * XRS;       // alpha' rows ty0-3.. (10 rows); after the life mask is
+                                                         // resolved: rows 0-5 = PN, rows 6-9 = fire mask MK
+    static constexpr int PW_LIFE = PW_A3 + (WTH + 6) * RS;
+    static constexpr int PW_A2 = PW_LIFE + (WTH + 4) * RS;
+    static constexpr int PW = PW_A2 + (WTH + 4) * RS;
+    static constexpr int LDS_FLOATS = SHARED + kWaves * PW;
+    static_assert(CP % 4 == 0 && SHARED % 4 == 0 && PW % 4 == 0 && PW_XR % 4 == 0 && PW_A3 % 4 == 0, "16-byte carve");
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+};
+
+#ifdef NCA_STAMPS
+// Diagnostic build only: phase stamps per wave tile -> a.dbg[((wg*8+wave)*kStampTiles + tile)*16 + i].
+constexpr int kStampTiles = 8;
+#define NCA_STAMP(i)                                                                                   \
+    do {                                                                                               \
+        if (a.dbg && tile_no < kStampTiles) {                                                          \
+            unsigned long long t_;                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+            if (lane == 0) a.dbg[((size_t)(blockIdx.x * kWaves + (threadIdx.x >> 6)) * kStampTiles + tile_no) * 16 + (i)] = t_; \
+        }                                                                                              \
+    } while (0)
+#else
+#define NCA_STAMP(i) do { } while (0)
+#endif
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// clamp as one v_med3_f32 (lo <= hi; identical to fmin(fmax(v,lo),hi) for every non-NaN v)
+__device__ __forceinline__ float wclamp(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ float max3x3(const float* p) {
+    float m = fmaxf(fmaxf(p[-RS - 1], p[-RS]), p[-RS + 1]);
+    m = fmaxf(m, fmaxf(fmaxf(p[-1], p[0]), p[1]));
+    return fmaxf(m, fmaxf(fmaxf(p[RS - 1], p[RS]), p[RS + 1]));
+}
+// LDS hand-off between lanes of ONE wave: DS ops of a wave execute in order, so only the compiler
+// must be kept from moving accesses across this point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int N, int NTHR = kThreadsW, typename MapT>
+__device__ __forceinline__ void fill_image_w(float* __restrict__ dst, const float* __restrict__ src, int tid, MapT map) {
+    constexpr int U = 8;
+    constexpr int kThreadsW = NTHR;
+    for (int base = tid; base < N; base += kThreadsW * U) {
+        float v[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + kThreadsW * u;
+            const long o = idx < N ? map(idx) : -1;
+            ok[u] = o >= 0;
+            v[u] = src[ok[u] ? o : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + kThreadsW * u;
+            if (idx < N) dst[idx] = ok[u] ? v[u] : 0.0f;
+        }
+    }
+}
+
+// ---- per-wave tile bookkeeping ------------------------------------------------------------------
+struct WTile {
+    int b, ty0, tx0;
+    bool valid, inner;  // inner: the 3-cell (1-cell without alive channel) halo lies inside the image
+};
+
+// Registers that carry one tile's global loads from issue (before the previous tile's MFMA chain)
+// to staging (after it).
+template <int CP>
+struct TileRegs {
+    float a3v[5];           // alpha' halo 3
+    unsigned prv[4];        // previous pre mask bytes, halo 2 (raw: converting at load time would force a wait)
+    float uu;               // fire-mask uniform of the lane's cell
+    f32x4 xf[CP / 2], gf[CP / 2];  // state / goal interior 16-byte groups
+    float xh[CP / 4], gh[CP / 4];  // state / goal halo columns
+};
+
+// Lane geometry (all shifts of the lane id; recomputed where used, never carried across the MFMAs):
+//   alpha' halo 3 : item k -> row 2k+hl (<10), col l5 (<22)      image (ty0-3+row, tx0-3+col)
+//   pre    halo 2 : item k -> row 2k+hl (<8),  col l5 (<20)      image (ty0-2+row, tx0-2+col)
+//   interior f4   : item k -> channel 2k+hl, slot l5 (<24): halo-1 row l5>>2, 4-cell group l5&3
+//   halo columns  : item k -> channel 4k+q4, slot ci (<12): halo-1 row ci>>1, side ci&1
+template <int CP, bool STATE, bool GOAL>
+__device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t, int lane_in, TileRegs<CP>& R) {
+    const int C = a.C, H = a.H, W = a.W;
+    const unsigned plane = (unsigned)(H * W);
+    const int gch0 = C - a.goal_ch;
+    const bool pending = a.pre_in != nullptr, use_alive = a.alive_ch >= 0, has_goal = a.goal_ch > 0;
+    const float* const xb = a.x_in + (size_t)t.b * C * plane;
+    const float* const gb = has_goal ? a.goal + (size_t)t.b * a.goal_ch * plane : a.x_in;
+    const size_t cell0 = (size_t)t.b * plane;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int hl = lane >> 5, l5 = lane & 31, q4 = lane >> 4, ci = lane & 15;
+    const bool chk = !t.inner;
+    if (STATE && use_alive) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int gy = t.ty0 - 3 + 2 * k + hl, gx = t.tx0 - 3 + l5;
+            const bool ok = l5 < 22 && (!chk || (gy >= 0 && gy < H && gx >= 0 && gx < W));
+            R.a3v[k] = xb[(unsigned)a.alive_ch * plane + (ok ? (unsigned)(gy * W + gx) : 0u)];
+        }
+    }
+    if (STATE) {
+        // always load (from a valid address when there is no pending mask): no branch, no wait at issue
+        const uint8_t* const pp = (pending && use_alive) ? a.pre_in + cell0 : reinterpret_cast<const uint8_t*>(xb);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int gy = t.ty0 - 2 + 2 * k + hl, gx = t.tx0 - 2 + l5;
+            const bool ok = l5 < 20 && (!chk || (gy >= 0 && gy < H && gx >= 0 && gx < W));
+            R.prv[k] = pp[ok ? (unsigned)(gy * W + gx) : 0u];
+        }
+    }
+    if (STATE) {
+        const int cgy = t.ty0 + q4, cgx = t.tx0 + ci;
+        const bool cin = !chk || (cgy < H && cgx < W);
+        const size_t cell = cell0 + (cin ? (unsigned)(cgy * W + cgx) : 0u);
+        R.uu = a.u ? a.u[cell] : nca_philox_cell(a.seed, a.step, cell);
+    }
+    {
+        const int fr = l5 >> 2, ff = l5 & 3, fgy = t.ty0 - 1 + fr, fgx = t.tx0 + 4 * ff;
+        const bool fok = l5 < 24 && (!chk || (fgy >= 0 && fgy < H && fgx + 3 < W));
+        const unsigned foff = fok ? (unsigned)(fgy * W + fgx) : 0u;
+        if (STATE) {
+#pragma unroll
+            for (int k = 0; k < CP / 2; ++k) R.xf[k] = ld4(xb + (unsigned)min(2 * k + hl, C - 1) * plane + foff);
+        }
+        if (GOAL && has_goal) {
+#pragma unroll
+            for (int k = 0; k < CP / 2; ++k)
+                R.gf[k] = ld4(gb + (unsigned)min(max(2 * k + hl - gch0, 0), a.goal_ch - 1) * plane + foff);
+        }
+    }
+    {
+        const int hr = ci >> 1, hgy = t.ty0 - 1 + hr, hgx = (ci & 1) ? t.tx0 + WTW : t.tx0 - 1;
+        const bool hok = ci < 12 && (!chk || (hgy >= 0 && hgy < H && hgx >= 0 && hgx < W));
+        const unsigned hoff = hok ? (unsigned)(hgy * W + hgx) : 0u;
+        if (STATE) {
+#pragma unroll
+            for (int k = 0; k < CP / 4; ++k) R.xh[k] = xb[(unsigned)min(4 * k + q4, C - 1) * plane + hoff];
+        }
+        if (GOAL && has_goal) {
+#pragma unroll
+            for (int k = 0; k < CP / 4; ++k)
+                R.gh[k] = gb[(unsigned)min(max(4 * k + q4 - gch0, 0), a.goal_ch - 1) * plane + hoff];
+        }
+    }
+}
+
+// Resolve the pending life mask, build z = x + goal*pre in LDS (halo 1), keep the resolved state for
+// the residual.  CHECK=false: no bounds logic.
+template <int CP, bool CHECK>
+__device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t, float* __restrict__ PWR, int lane_in,
+                                           const TileRegs<CP>& R, int tile_no) {
+    using K = WCfg<CP>;
+    float* const Z = PWR + K::PW_Z;
+    float* const XR = PWR + K::PW_XR;
+    float* const A3 = PWR + K::PW_A3;
+    float* const PN = PWR + K::PW_A3;  // A3 is dead once the life mask is resolved
+    float* const LIFE = PWR + K::PW_LIFE;
+    float* const A2 = PWR + K::PW_A2;
+    float* const MK = PWR + K::PW_A3 + ZROWS * RS;  // 64 floats in A3 rows 6-8
+
+    const int C = a.C, H = a.H, W = a.W;
+    const unsigned plane = (unsigned)(H * W);
+    const int gch0 = C - a.goal_ch, ty0 = t.ty0, tx0 = t.tx0;
+    const bool pending = a.pre_in != nullptr, use_alive = a.alive_ch >= 0, has_goal = a.goal_ch > 0;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int hl = lane >> 5, l5 = lane & 31, q4 = lane >> 4, ci = lane & 15;
+
+    NCA_STAMP(8);
+    // ---- S1: alpha' (-inf outside the image == max_pool2d padding) -----------------------------
+    wave_sync();  // the previous tile's LDS reads are ordered before these writes
+    bool l2ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int gy = ty0 - 2 + 2 * k + hl, gx = tx0 - 2 + l5;
+        l2ok[k] = l5 < 20 && (!CHECK || (gy >= 0 && gy < H && gx >= 0 && gx < W));
+    }
+    if (use_alive) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int gy = ty0 - 3 + 2 * k + hl, gx = tx0 - 3 + l5;
+            const bool ok = !CHECK || (gy >= 0 && gy < H && gx >= 0 && gx < W);
+            if (l5 < 22) A3[(2 * k + hl) * RS + l5 + 1] = ok ? R.a3v[k] : NCA_NEG_INF;
+        }
+        wave_sync();
+        NCA_STAMP(9);
+        // ---- S2: life = pre & post of the PREVIOUS step, resolved alpha (nca.py:191-194) -------
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = 2 * k + hl;
+            const float* const ac = A3 + (r + 1) * RS + l5 + 2;
+            float life = 0.0f, av = NCA_NEG_INF;
+            if (l2ok[k]) {
+                life = 1.0f;
+                av = ac[0];
+                if (pending) {
+                    life = (R.prv[k] != 0u && max3x3(ac) > a.thr) ? 1.0f : 0.0f;
+                    av = wclamp(av * life, a.lo, a.hi);
+                }
+            }
+            if (l5 < 20) {
+                LIFE[r * RS + l5 + 2] = life;
+                A2[r * RS + l5 + 2] = av;
+            }
+        }
+        wave_sync();
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (l5 < 20) LIFE[(2 * k + hl) * RS + l5 + 2] = l2ok[k] ? 1.0f : 0.0f;
+    }
+    NCA_STAMP(10);
+    // ---- S3: pre-life mask of THIS step on halo 1; fire mask -------------------------------------
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int r = 2 * k + hl;  // halo-1 row, col q = l5 < 18
+        const int gy = ty0 - 1 + r, gx = tx0 - 1 + l5;
+        const bool in = l5 < 18 && (!CHECK || (gy >= 0 && gy < H && gx >= 0 && gx < W));
+        float pn = 0.0f;
+        if (in) pn = (!use_alive || max3x3(A2 + (r + 1) * RS + l5 + 3) > a.thr) ? 1.0f : 0.0f;
+        if (l5 < 18) PN[r * RS + l5 + 3] = pn;
+    }
+    {
+        const int cgy = ty0 + q4, cgx = tx0 + ci;
+        const bool cin = !CHECK || (cgy < H && cgx < W);
+        MK[lane] = (cin && wclamp(R.uu, 0.0f, 1.0f) < a.fire_rate) ? 1.0f : 0.0f;  // nca.py:171-174
+        wave_sync();
+        if (cin && a.pre_out) a.pre_out[(size_t)t.b * plane + (unsigned)(cgy * W + cgx)] = (uint8_t)PN[(q4 + 1) * RS + ci + 4];
+    }
+    NCA_STAMP(11);
+    // ---- S4: z = x + goal * pre (nca.py:177) on halo 1; resolved state kept for the residual -----
+    if (l5 < 24) {
+        const int fr = l5 >> 2, ff = l5 & 3;
+        const bool fok = !CHECK || (ty0 - 1 + fr >= 0 && ty0 - 1 + fr < H && tx0 + 4 * ff + 3 < W);
+        const f32x4 lf = ld4(LIFE + (fr + 1) * RS + 4 + 4 * ff);
+        const f32x4 pn = ld4(PN + fr * RS + 4 + 4 * ff);
+        const bool inner = fr >= 1 && fr <= WTH;
+        f32x4 v[CP / 2];
+#pragma unroll
+        for (int k = 0; k < CP / 2; ++k) {  // resolved state (prefetched long ago): no memory wait here
+            const int ch = 2 * k + hl;
+            v[k] = R.xf[k];
+            if (pending) {
+                v[k] = v[k] * lf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[k][j] = wclamp(v[k][j], a.lo, a.hi);
+            }
+            if ((CHECK && !fok) || ch >= C) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (inner) st4(XR + ch * XRS + (fr - 1) * WTW + 4 * ff, v[k]);
+        }
+        NCA_STAMP(12);
+#pragma unroll
+        for (int k = 0; k < CP / 2; ++k) {  // goal encoding (issued at the top of staging) consumed last
+            const int ch = 2 * k + hl;
+            if (has_goal && ch >= gch0 && ch < C && fok) v[k] = __builtin_elementwise_fma(R.gf[k], pn, v[k]);
+            st4(Z + ch * CS + fr * RS + 4 + 4 * ff, v[k]);
+        }
+    }
+    NCA_STAMP(13);
+    if (ci < 12) {
+        const int hr = ci >> 1, zq = (ci & 1) ? WTW + 4 : 3;
+        const int hgy = ty0 - 1 + hr, hgx = (ci & 1) ? tx0 + WTW : tx0 - 1;
+        const bool hok = !CHECK || (hgy >= 0 && hgy < H && hgx >= 0 && hgx < W);
+        const float lf = LIFE[(hr + 1) * RS + zq], pn = PN[hr * RS + zq];
+#pragma unroll
+        for (int k = 0; k < CP / 4; ++k) {
+            const int ch = 4 * k + q4;
+            float v = R.xh[k];
+            if (pending) v = wclamp(v * lf, a.lo, a.hi);
+            if (!hok || ch >= C) v = 0.0f;
+            else if (has_goal && ch >= gch0) v = fmaf(R.gh[k], pn, v);
+            Z[ch * CS + hr * RS + zq] = v;
+        }
+    }
+    wave_sync();
+}
+
+// Learned depthwise perception (nca.py:99-107) from the LDS tile: P[n][3c'+f] for channel 4c'+g, cell (row n, col ci).
+template <int CP, int NT>
+__device__ __forceinline__ void perceive_tile(const float* __restrict__ WS, const float* __restrict__ PWR, int lane_in,
+                                              int n0, float (&P)[NT][3 * CP / 4]) {
+    using K = WCfg<CP>;
+    const float* const Z = PWR + K::PW_Z;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));  // per pass: re-read the 27 taps from LDS instead of holding 4x28 registers
+    const float* const WPL = WS + K::OFF_WP;
+    const int g = lane >> 4, ci = lane & 15;
+#pragma unroll
+    for (int c4 = 0; c4 < CP / 4; ++c4) {
+        const float* const zc = Z + (4 * c4 + g) * CS + n0 * RS + ci + 3;
+        float wt[28];
+#pragma unroll
+        for (int j4 = 0; j4 < 7; ++j4) {
+            const f32x4 w4 = ld4(WPL + (4 * c4 + g) * K::WPS + 4 * j4);
+            wt[4 * j4 + 0] = w4[0]; wt[4 * j4 + 1] = w4[1]; wt[4 * j4 + 2] = w4[2]; wt[4 * j4 + 3] = w4[3];
+        }
+        static_assert(NT == 2, "row pairs: one v_pk_fma_f32 serves output rows n0 and n0+1");
+        // tap (dy,dx) of output rows (n0, n0+1) reads tile rows (dy, dy+1): one ds_read2_b32 -> an aligned pair
+        f32x2 nb[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) nb[3 * dy + dx] = f32x2{zc[dy * RS + dx], zc[(dy + 1) * RS + dx]};
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc = __builtin_elementwise_fma(f32x2{wt[9 * f + t], wt[9 * f + t]}, nb[t], acc);
+            P[0][3 * c4 + f] = acc[0];
+            P[1][3 * c4 + f] = acc[1];
+        }
+    }
+}
+
+
+__device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_huge_valf()); }
+
+}  // namespace

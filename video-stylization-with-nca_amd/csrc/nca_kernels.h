@@ -28,6 +28,29 @@ struct NcaCondArgs {
     unsigned long long* dbg;  // diagnostic builds (-DNCA_STAMPS) only: per-wave phase time stamps
 };
 
+// One backward step of the ConditionedNCA grow loop (nca_cond_bwd.hip).  f describes forward step t exactly as
+// it was launched (x_in = states[t], pre_in = pre[t] or null for t == 0, goal, u / seed+step, weights).
+struct NcaCondBwdArgs {
+    NcaCondArgs f;
+    const float* x_next;    // states[t+1] = pending x'_t                      [B,C,H,W]
+    const uint8_t* pre_t;   // pre[t+1]    = alive(s_t)                        [B,H,W]
+    const float* g_next;    // dL/d s_{t+1}                                    [B,C,H,W]
+    float* g_out;           // dL/d s_t  (written by the stencil kernel)        [B,C,H,W]
+    float* gx;              // scratch: direct-path gradient dL/dx'_t           [B,C,H,W]
+    float* dP;              // scratch: dL/d perception                         [B,3C,H,W]
+    float* zbuf;            // scratch: z_t = s_t + goal*pre_t                  [B,C,H,W]
+    float* dgoal;           // accumulated over steps                           [B,goal_ch,H,W]
+    float* slabs;           // per-wave weight-gradient partials, accumulated   [nslab, slab_floats]
+    float* wp_partials;     // per-block perception-weight partials             [nblk, 27] accumulated
+    int nslab, nblk;
+};
+int nca_cond_bwd_slab_floats(int C, int hidden);
+int nca_cond_bwd_nslab();
+int nca_cond_bwd_nblk(int B, int C, int H, int W);
+hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& a, hipStream_t st);
+hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st);
+hipError_t nca_launch_reduce_wp(const float* part, float* dst, int B, int C, int H, int W, hipStream_t st);
+
 // fused steps (nca_step_fwd.hip); hipErrorInvalidValue when no instantiation covers the shape
 hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st);
 hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st);

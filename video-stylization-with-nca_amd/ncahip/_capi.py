@@ -30,7 +30,11 @@ SIGNATURES = {
     "ncahip_cond_grow_fwd_f32": [_P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F,
                                  _F, _F, _F, _U64, _U64, _P],
     "ncahip_philox_uniform_f32": [_P, _I, _I, _I, _U64, _U64, _P],
+    "ncahip_cond_grow_bwd_workspace": [_I, _I, _I, _I, _I],
+    "ncahip_cond_grow_bwd_f32": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F,
+                                 _U64, _U64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P],
 }
+_RESTYPES = {"ncahip_last_error": c_char_p, "ncahip_cond_grow_bwd_workspace": ctypes.c_size_t}
 
 _lib = None
 
@@ -50,7 +54,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here == header and library out of sync
             fn.argtypes = argtypes
-            fn.restype = c_char_p if name == "ncahip_last_error" else c_int
+            fn.restype = _RESTYPES.get(name, c_int)
         _lib = L
     return _lib
 

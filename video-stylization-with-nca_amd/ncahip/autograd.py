@@ -1,0 +1,88 @@
+"""torch.autograd.Function wrappers: T fused NCA steps as ONE autograd node, backward by recomputation
+from the saved per-step states, so PyTorch-ROCm autograd, the optimiser
+and the style loss sit on top unchanged."""
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+def _needs_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+# ------------------------------------------------------------------------------------ ConditionedNCA
+class _CondGrow(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, goal, wp, w1, b1, w2, b2, w3, cfg):
+        T, us = cfg["T"], cfg["us"]
+        w = ops.CondWeights(wp, w1, b1, w2, b2, w3, x)
+        out, states, pre = ops.cond_grow(x, T, goal, us, w, cfg["alive_ch"], cfg["thr"], cfg["fire_rate"], cfg["lo"],
+                                         cfg["hi"], cfg["seed"], cfg["step0"], keep_history=True)
+        ctx.cfg, ctx.w = cfg, w
+        ctx.save_for_backward(states, pre, goal if goal is not None else x.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        states, pre, goal = ctx.saved_tensors
+        cfg, w = ctx.cfg, ctx.w
+        g = ops.cond_grow_backward(states, pre, goal if goal.numel() else None, cfg["us"], w, g_out.contiguous(),
+                                   cfg["T"], cfg["alive_ch"], cfg["thr"], cfg["fire_rate"], cfg["lo"], cfg["hi"],
+                                   cfg["seed"], cfg["step0"])
+        return (g["x0"], g["goal"], g["wp"].view_as(ctx.w.wp).reshape(-1, 1, 3, 3), g["w1"][:, :, None, None],
+                g["b1"], g["w2"][:, :, None, None], g["b2"], g["w3"][:, :, None, None], None)
+
+
+def cond_grow_autograd(model, x: torch.Tensor, goal: Optional[torch.Tensor], T: int) -> torch.Tensor:
+    if T == 0:
+        return x
+    x = x.float().contiguous()
+    u = model.update_net.out
+    params = (model.perception_net.weight, u[0].weight, u[0].bias, u[2].weight, u[2].bias, u[4].weight)
+    us = model._draw(x, T)
+    cfg = dict(T=T, us=us, alive_ch=model._alive_ch(), thr=model.alpha_living_threshold, fire_rate=model.cell_fire_rate,
+               lo=-10.0, hi=10.0, seed=model.mask_seed, step0=model._mask_step)
+    model._mask_step += T
+    if _needs_grad(x, goal, *params):
+        return _CondGrow.apply(x, goal, *params, cfg)
+    w = ops.CondWeights(*params, x)
+    out, _, _ = ops.cond_grow(x, T, goal, us, w, cfg["alive_ch"], cfg["thr"], cfg["fire_rate"], cfg["lo"], cfg["hi"],
+                              cfg["seed"], cfg["step0"])
+    return out
+
+
+# ------------------------------------------------------------------------------------ DyNCA
+class _DyncaNSteps(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cond, w1, b1, w2, b2, cfg):
+        w = ops.DyncaWeights(w1, b1, w2, b2, x)
+        out, states = ops.dynca_nsteps(x, cfg["T"], cond, cfg["us"], w, cfg["pad"], cfg["rate"], cfg["seed"],
+                                       cfg["step0"], keep_history=True)
+        ctx.cfg, ctx.w = cfg, w
+        ctx.save_for_backward(states, cond if cond is not None else x.new_empty(0))
+        return out.clone(), states if cfg["want_states"] else None
+
+    @staticmethod
+    def backward(ctx, g_out, g_states):
+        states, cond = ctx.saved_tensors
+        cfg = ctx.cfg
+        g = ops.dynca_nsteps_backward(states, cond if cond.numel() else None, cfg["us"], ctx.w, g_out.contiguous(),
+                                      g_states, cfg["T"], cfg["pad"], cfg["rate"], cfg["seed"], cfg["step0"])
+        return g["x0"], None, g["w1"][:, :, None, None], g["b1"], g["w2"][:, :, None, None], g["b2"], None  # no grad to cond (dynca.py:123)
+
+
+def dynca_nsteps_autograd(model, x, cond, T, update_rate, want_states=False):
+    x = x.float().contiguous()
+    params = (model.w1.weight, model.w1.bias, model.w2.weight, model.w2.bias)
+    us = model._draw(x, T)
+    cfg = dict(T=T, us=us, pad=model.padding_mode, rate=float(update_rate), seed=model.mask_seed, step0=model._mask_step,
+               want_states=want_states)
+    model._mask_step += T
+    if _needs_grad(x, *params):
+        return _DyncaNSteps.apply(x, cond, *params, cfg)
+    w = ops.DyncaWeights(*params, x)
+    out, states = ops.dynca_nsteps(x, T, cond, us, w, cfg["pad"], cfg["rate"], cfg["seed"], cfg["step0"],
+                                   keep_history=want_states)
+    return out, (states if want_states else None)
