@@ -192,7 +192,7 @@ size_t ncahip_cond_grow_bwd_workspace(int B, int C, int H, int W, int hidden) {
     if (!dims_ok(B, C, H, W) || hidden <= 0) return 0;
     const size_t n = (size_t)B * C * H * W * sizeof(float);
     return 4 * align256(n) + align256(3 * n) +
-           align256((size_t)nca_cond_bwd_nslab() * nca_cond_bwd_slab_floats(C, hidden) * sizeof(float)) +
+           align256((size_t)(nca_cond_bwd_nslab() + 1) * nca_cond_bwd_slab_floats(C, hidden) * sizeof(float)) +
            align256((size_t)nca_cond_bwd_nblk(B, C, H, W) * 27 * sizeof(float));
 }
 
@@ -220,7 +220,9 @@ int ncahip_cond_grow_bwd_f32(const float* states, const uint8_t* pre, int T, con
     float* zbuf = (float*)p; p += align256(nb);
     float* dP = (float*)p; p += align256(3 * nb);
     const int nslab = nca_cond_bwd_nslab(), sf = nca_cond_bwd_slab_floats(C, hidden), nblk = nca_cond_bwd_nblk(B, C, H, W);
-    float* slabs = (float*)p; p += align256((size_t)nslab * sf * sizeof(float));
+    float* slabs = (float*)p;
+    float* red = slabs + (size_t)nslab * sf;  // one extra slab: the reduced gradients
+    p += align256((size_t)(nslab + 1) * sf * sizeof(float));
     float* wpp = (float*)p;
     hipError_t e = hipMemsetAsync(slabs, 0, (size_t)nslab * sf * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(wpp, 0, (size_t)nblk * 27 * sizeof(float), st);
@@ -242,7 +244,6 @@ int ncahip_cond_grow_bwd_f32(const float* states, const uint8_t* pre, int T, con
         gcur = ba.g_out;
     }
     // slabs -> gradients (layout: w1 | w2 | w3 | b1 | b2)
-    float* red = gbuf[0];  // reuse: >= slab_floats
     if (int rc = hip_result(nca_launch_reduce_rows(slabs, red, nslab, sf, st), "cond_grow_bwd reduce")) return rc;
     const size_t o2 = (size_t)hidden * 3 * C, o3 = o2 + (size_t)hidden * hidden, ob1 = o3 + (size_t)C * hidden, ob2 = ob1 + hidden;
     e = hipMemcpyAsync(g_w1, red, o2 * sizeof(float), hipMemcpyDeviceToDevice, st);

@@ -180,6 +180,27 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             wave_sync();
         }
 
+        // ---- dL/dx'_t = G * 1[lo <= x'*life <= hi] * life (nca.py:191-194);  d out = . * fire mask.  All four
+        //      rows now: TB (the staged incoming gradient) is reused for the transposes inside the pass loop.
+        float dOall[WTH][4];
+#pragma unroll
+        for (int row = 0; row < WTH; ++row) {
+            float life = PN[(row + 1) * RS + ci + 4];
+            if (use_alive) life = (life != 0.0f && max3x3(A1 + (row + 1) * RS + ci + 4) > a.thr) ? 1.0f : 0.0f;
+            const float mk = MK[row * WTW + ci];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = 4 * g + r;
+                float gxv = 0.0f;
+                if (ch < CP) {  // XR / TB hold CP channel planes
+                    float* const xp = XR + ch * XRS + row * WTW + ci;
+                    const float y = *xp * life;
+                    if (ch < C && y >= a.lo && y <= a.hi) gxv = TB[ch * XRS + row * WTW + ci] * life;
+                    *xp = gxv;  // XR now carries dL/dx'_t for the 16-byte store pass
+                }
+                dOall[row][r] = gxv * mk;
+            }
+        }
 #pragma unroll 1
         for (int pass = 0; pass < WTH / NT; ++pass) {
             const int n0 = pass * NT;
@@ -221,24 +242,11 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
 #pragma unroll
                     for (int r = 0; r < 4; ++r) h2[m2][n][r] = relu(h2[m2][n][r]);
             }
-            // ---- dL/dx'_t = G * 1[lo <= x'*life <= hi] * life (nca.py:191-194);  d out = . * fire mask ------
             float dO[NT][4];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int row = n0 + n;
-                float life = PN[(row + 1) * RS + ci + 4];
-                if (use_alive) life = (life != 0.0f && max3x3(A1 + (row + 1) * RS + ci + 4) > a.thr) ? 1.0f : 0.0f;
-                const float mk = MK[row * WTW + ci];
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ch = 4 * g + r;
-                    float* const xp = XR + ch * XRS + row * WTW + ci;
-                    const float y = *xp * life;
-                    const float gxv = (y >= a.lo && y <= a.hi) ? TB[ch * XRS + row * WTW + ci] * life : 0.0f;
-                    *xp = gxv;  // XR now carries dL/dx'_t for the 16-byte store pass
-                    dO[n][r] = gxv * mk;
-                }
-            }
+                for (int r = 0; r < 4; ++r) dO[n][r] = pass ? dOall[NT + n][r] : dOall[n][r];
             // ---- data path: W3^T, W2^T, W1^T ---------------------------------------------------------------
             f32x4 d2[4][NT], d1[4][NT], dp[K::MJ][NT];
 #pragma unroll
