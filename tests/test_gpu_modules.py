@@ -1,0 +1,180 @@
+"""GPU tests of the drop-in module layer: the reference-shaped classes end to end on the HIP path,
+including autograd through grow() (the HIP backward kernels) against oracle autograd."""
+import json
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nca_oracle as O
+from util import REL_TOL, T, load, rel_err, sd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _cond_model(size=32, hidden=8, seed=0, out_scale=3.0):
+    from ncahip.nca import ConditionedNCA
+    torch.manual_seed(seed)
+    m = ConditionedNCA(target_shape=(3, size, size), num_hidden_channels=hidden, living_channel_dim=3)
+    with torch.no_grad():
+        for n, p in m.update_net.named_parameters():
+            if n.endswith("bias"):
+                p.uniform_(-0.1, 0.1)
+        m.update_net.out[4].weight.mul_(out_scale)
+    return m
+
+
+def _inject(model, us):
+    """Use known uniforms instead of the device RNG so the CPU oracle can replay the masks."""
+    it = iter(us)
+    model._draw = lambda x, steps: torch.stack([next(it).to(x.device) for _ in range(steps)])
+
+
+def test_conditioned_nca_grow_and_forward_match_oracle():
+    m = _cond_model()
+    prm = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    gen = torch.Generator().manual_seed(3)
+    x0, goal = torch.rand(2, 12, 32, 32, generator=gen), torch.rand(2, 3, 32, 32, generator=gen)
+    us = [torch.rand(2, 1, 32, 32, generator=gen) for _ in range(6)]
+    gpad = O.cond_pad_goal(O.image_encoder(goal, prm), 12)
+    ref = O.cond_grow(x0, gpad, us, prm, 3)
+    md = m.to(DEV)
+    _inject(md, us)
+    with torch.no_grad():
+        got = md.grow(x0.to(DEV), 6, goal.to(DEV))
+    assert rel_err(got, ref) < REL_TOL
+    # forward((x, goal_encoding)) -> (x'', goal_encoding): one exact step, padded encoding as the reference passes it
+    _inject(md, us[:1])
+    with torch.no_grad():
+        out, ge = md((x0.to(DEV), gpad.to(DEV)))
+    assert rel_err(out, O.cond_step(x0, gpad, us[0], prm, 3)) < REL_TOL and ge.shape == gpad.shape
+    assert torch.equal(md.alive(x0.to(DEV)).cpu(), O.cond_alive(x0, 3))
+    # update(): perception + UpdateNet only
+    pre = O.cond_alive(x0, 3)
+    upd = md.update(x0.to(DEV), gpad.to(DEV), pre.to(DEV))
+    assert rel_err(upd, O.cond_update_net(O.cond_perceive(x0 + gpad * pre, prm["perception_net.weight"]), prm)) < REL_TOL
+
+
+def test_conditioned_nca_autograd_through_grow():
+    """loss.backward() through grow(): every parameter gradient (incl. the encoder's, via dL/dgoal) and dL/dx0."""
+    m = _cond_model(size=16, seed=1)
+    prm = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    gen = torch.Generator().manual_seed(5)
+    x0, goal = torch.rand(2, 12, 16, 16, generator=gen), torch.rand(2, 3, 16, 16, generator=gen)
+    cot = torch.randn(2, 12, 16, 16, generator=gen)
+    us = [torch.rand(2, 1, 16, 16, generator=gen) for _ in range(4)]
+    # oracle autograd
+    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "embed" in k or k.startswith(("perception", "update")))
+         for k, v in prm.items()}
+    xr = x0.clone().requires_grad_(True)
+    gp = O.cond_pad_goal(O.image_encoder(goal, p), 12)
+    (O.cond_grow(xr, gp, us, p, 3) * cot).sum().backward()
+    md = m.to(DEV)
+    _inject(md, us)
+    xd = x0.to(DEV).requires_grad_(True)
+    out = md.grow(xd, 4, goal.to(DEV))
+    (out * cot.to(DEV)).sum().backward()
+    scale = lambda t: max(float(t.abs().max()), 1e-6)
+    assert float((xd.grad.cpu() - xr.grad).abs().max()) / scale(xr.grad) < 2e-4
+    checked = 0
+    for n, w in md.named_parameters():
+        if p[n].grad is None:
+            assert w.grad is None or float(w.grad.abs().max()) == 0.0, n
+            continue
+        assert w.grad is not None, n
+        assert float((w.grad.cpu() - p[n].grad).abs().max()) / scale(p[n].grad) < 2e-4, n
+        checked += 1
+    assert checked == 9   # perception, 3 weights + 2 biases of the update net, 2 weights + 1 bias of encoder.embed
+
+
+def test_dynca_module_matches_golden():
+    from ncahip.models.dynca import DyNCA
+    g = load("g3_dynca")
+    for c in json.loads(str(g["cases"])):
+        if c["C"] != 12:
+            continue
+        t = c["tag"]
+        d = DyNCA(12, 3, fc_dim=96, padding_mode=c["pad"], conditioning=c["cond"], edge_transform=c["transform"],
+                  device=torch.device(DEV))
+        with torch.no_grad():
+            for k in ("w1.weight", "w1.bias", "w2.weight", "w2.bias"):
+                dict(d.named_parameters())[k].copy_(T(g[f"{t}.{k}"]))
+        us = [u for u in T(g[f"{t}.us"], DEV)]
+        d._draw = lambda x, steps, it=iter(us): torch.stack([next(it) for _ in range(steps)])
+        cimg = T(g[f"{t}.cond_img"], DEV) if f"{t}.cond_img" in g else None
+        with torch.no_grad():
+            x, rgb = d(T(g[f"{t}.x0"], DEV), update_rate=0.5, cond_img=cimg)
+            assert rel_err(x, T(g[f"{t}.state_first"])) < REL_TOL, c
+            assert torch.equal(rgb, 2 * x[:, :3])
+            d._draw = lambda x, steps, it=iter(us): torch.stack([next(it) for _ in range(steps)])
+            xT, rgbT, mids = d.forward_nsteps(T(g[f"{t}.x0"], DEV), c["T"], cond_img=cimg, return_middle_feature=True)
+            assert rel_err(xT, T(g[f"{t}.state_last"])) < REL_TOL, c
+            assert len(mids) == c["T"] and torch.equal(mids[-1], rgbT)
+            assert rel_err(d.perceive_torch(T(g[f"{t}.x0"], DEV)), T(g[f"{t}.perc0"])) < 1e-5
+
+
+def test_dynca_extra_channels_module():
+    from ncahip.models.dynca_extra import DyNCA
+    g = load("g6_extra_channels")
+    d = DyNCA(13, 3, fc_dim=96, padding_mode="replicate", pos_emb="CPE", device=torch.device(DEV))
+    with torch.no_grad():
+        for k in ("w1.weight", "w1.bias", "w2.weight", "w2.bias"):
+            dict(d.named_parameters())[k].copy_(T(g[k]))
+    us = [u for u in T(g["us"], DEV)]
+    d._draw = lambda x, steps, it=iter(us): torch.stack([next(it) for _ in range(steps)])
+    with torch.no_grad():
+        xT, _ = d.forward_nsteps(T(g["x0"], DEV), 5)
+    assert rel_err(xT, T(g["states"])[-1]) < REL_TOL
+
+
+def test_mask_rng_modes():
+    m = _cond_model().to(DEV)
+    x0, goal = torch.rand(2, 12, 32, 32, device=DEV), torch.rand(2, 3, 32, 32, device=DEV)
+    with torch.no_grad():
+        torch.manual_seed(11); a = m.grow(x0, 3, goal)
+        torch.manual_seed(11); b = m.grow(x0, 3, goal)
+        assert torch.equal(a, b)                      # 'torch' mode: the device generator drives the masks (nca.py:172)
+        m.mask_rng, m.mask_seed = "philox", 77
+        m._mask_step = 0; c = m.grow(x0, 3, goal)
+        m._mask_step = 0; d = m.grow(x0, 3, goal)
+        assert torch.equal(c, d) and not torch.equal(a, c)
+        e = m.grow(x0, 3, goal)                       # the step counter advanced: fresh masks
+        assert not torch.equal(d, e)
+
+
+def test_trainer_iterations_on_gpu():
+    """Two outer iterations of ConditionedNCATrainer.train on the HIP path (overflow + pixel loss)."""
+    from ncahip.conditioned_trainer import ConditionedNCATrainer
+
+    class DS:
+        target_size = (3, 32, 32)
+
+        def __init__(self):
+            self.x = torch.rand(6, 3, 32, 32)
+
+        def __len__(self):
+            return 6
+
+        def __getitem__(self, i):
+            return self.x[i]
+
+    class PixLoss(torch.nn.Module):
+        def forward(self, d):
+            s = d["nca_state"]
+            l = (d["generated_images"] - d["target_images"]).pow(2).mean() + (s - s.clamp(-1, 1)).abs().mean()
+            return [l, {"pix": l.detach()}]
+
+    m = _cond_model(out_scale=1.0).to(DEV)
+    w0 = m.update_net.out[0].weight.detach().clone()
+    tr = ConditionedNCATrainer(m, DS(), None, nca_steps=[4, 8], lr=2e-3, pool_size=16, log_base_path="/tmp/ncahip_gpu_test",
+                               loss=PixLoss(), device=torch.device(DEV))
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    losses = []
+    orig = tr.train_batch
+    tr.train_batch = lambda b, t: (lambda r: (losses.append(r[1]), r)[1])(orig(b, t))
+    tr.train(batch_size=4, epochs=2)
+    assert len(losses) == 4 and all(np.isfinite(losses))
+    assert not torch.equal(m.update_net.out[0].weight.detach(), w0)            # the optimiser moved the weights
+    assert sum(tr.pool[i] is not None for i in range(16)) >= 4 and tr.pool._dense.is_cuda

@@ -1,0 +1,142 @@
+"""ConditionedNCATrainer inner-loop semantics (reference conditioned_trainer.py:101-181), pinned with scripted
+RNG on CPU.  The NCA is a stub whose grow() is the CPU oracle (tests may use oracle/): the trainer logic is
+host code and must not need a GPU."""
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import nca_oracle as O
+
+
+class StubNCA(nn.Module):
+    """Same surface the trainer touches: grow / generate_seed / alive / parameters."""
+
+    def __init__(self, C=8, size=12):
+        super().__init__()
+        self.num_channels, self.image_size, self.living_channel_dim = C, size, 3
+        self.scale = nn.Parameter(torch.tensor(0.5))
+        self.shift = nn.Parameter(torch.zeros(C))
+        self.unused = nn.Parameter(torch.ones(2))   # never gets a gradient
+        self.steps_seen = []
+
+    def generate_seed(self, n):
+        return O.cond_generate_seed(n, self.num_channels, 3, self.image_size)
+
+    def alive(self, x):
+        return O.cond_alive(x, 3, 0.1)
+
+    def grow(self, x, num_steps, goal):
+        self.steps_seen.append(num_steps)
+        return x * self.scale + self.shift[None, :, None, None] + 0.01 * goal.mean()
+
+
+class Targets:
+    target_size = (3, 12, 12)
+
+    def __init__(self, n=5):
+        self.data = torch.rand(n, 3, 12, 12)
+        self.asked = []
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, idx):
+        self.asked.append(list(idx))
+        return self.data[idx]
+
+
+class SimpleLoss(nn.Module):
+    def forward(self, d):
+        l = (d["generated_images"] - d["target_images"]).pow(2).mean() + 0.1 * d["nca_state"].abs().mean()
+        return [l, {"mse": l.detach()}]
+
+
+def make_trainer(pool_size=16):
+    from ncahip.conditioned_trainer import ConditionedNCATrainer
+    nca, ds = StubNCA(), Targets()
+    tr = ConditionedNCATrainer(nca, ds, None, nca_steps=[3, 6], lr=1e-2, pool_size=pool_size, log_base_path="/tmp/ncahip_test",
+                               loss=SimpleLoss(), device=torch.device("cpu"))
+    return tr, nca, ds
+
+
+def test_constructor_signature_matches_reference():
+    import inspect
+    from ncahip.conditioned_trainer import ConditionedNCATrainer
+    names = list(inspect.signature(ConditionedNCATrainer.__init__).parameters)[1:]
+    assert names[:16] == ["nca", "target_dataset", "target_style_image", "nca_steps", "lr", "pool_size", "num_damaged",
+                          "log_base_path", "damage_radius", "appearance_loss_type", "appearance_loss_weight",
+                          "content_loss_weight", "overflow_loss_weight", "device", "visualiser", "loss"]
+    tr, _, _ = make_trainer()
+    assert tr.min_steps == 3 and tr.max_steps == 6 and tr.rgb and tr.image_size == 12 and tr.pool_size == 16
+
+
+def test_sample_batch_reseeds_empty_and_dead():
+    tr, nca, _ = make_trainer()
+    alive = torch.rand(8, 12, 12) + 0.5
+    dead = torch.zeros(8, 12, 12)
+    tr.pool[[2, 5]] = torch.stack([alive, dead])
+    batch = tr.sample_batch([2, 5, 7], tr.pool)
+    seed = nca.generate_seed(1)[0]
+    assert torch.equal(batch[0], alive)           # alive sample kept
+    assert torch.equal(batch[1], seed)            # dead sample (no alpha > 0.1 anywhere) -> fresh seed
+    assert torch.equal(batch[2], seed)            # never-written slot -> fresh seed
+
+
+def test_train_iteration_semantics_scripted_rng():
+    tr, nca, ds = make_trainer()
+    random.seed(7); np.random.seed(7); torch.manual_seed(7)
+    # replay the reference's draws: idxs = random.sample(range(pool), B); T ~ randint(min,max) x2 (python `random`),
+    # target rows = np.random.choice(N, B)
+    random.seed(7); np.random.seed(7)
+    exp_idxs = random.sample(range(16), 4)
+    exp_T = [random.randint(3, 6), random.randint(3, 6)]
+    exp_targets = list(np.random.choice(5, 4, replace=True))
+    random.seed(7); np.random.seed(7)
+    w0 = nca.scale.item()
+    tr.train(batch_size=4, epochs=1)
+    assert nca.steps_seen == exp_T                               # two train_batch calls, T from python random
+    assert ds.asked == [exp_targets]                             # ONE target draw per iteration (reused for both calls)
+    assert sorted(i for i in range(16) if tr.pool[i] is not None) == sorted(exp_idxs)   # outputs written back
+    assert tr.lr_sched.last_epoch == 2                           # scheduler stepped once per train_batch
+    assert nca.scale.item() != w0 and nca.unused.grad is None
+
+
+def test_two_fresh_seeds_and_grad_normalisation():
+    tr, nca, _ = make_trainer()
+    seen = {}
+    orig = tr.train_batch
+
+    def spy(batch, targets):
+        seen.setdefault("first", batch.clone())
+        out = orig(batch, targets)
+        seen["norms"] = [float(p.grad.norm()) for p in nca.parameters() if p.grad is not None]
+        return out
+
+    tr.train_batch = spy
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    tr.train(batch_size=4, epochs=1)
+    seed = nca.generate_seed(2)
+    assert torch.equal(seen["first"][:2], seed)                  # batch[:2] = generate_seed(2) (conditioned_trainer.py:167)
+    assert all(abs(n - 1.0) < 1e-4 for n in seen["norms"])       # p.grad /= ||p.grad|| + 1e-10, per parameter
+
+
+def test_lr_milestone_hits_at_half_the_iterations():
+    tr, _, _ = make_trainer()
+    for _ in range(4999):
+        tr.optimizer.step(); tr.lr_sched.step()
+    assert abs(tr.optimizer.param_groups[0]["lr"] - 1e-2) < 1e-12
+    tr.optimizer.step(); tr.lr_sched.step()                     # 5000 scheduler steps = 2500 outer iterations
+    assert abs(tr.optimizer.param_groups[0]["lr"] - 3e-3) < 1e-12
+
+
+def test_overflow_loss_is_the_reference_formula():
+    from ncahip.loss import Loss
+    L = Loss(torch.device("cpu"), content_loss_weight=0.0, appearance_loss_weight=0.0, overflow_loss_weight=2.0)
+    s = torch.tensor([[-3.0, -1.0, 0.2, 1.0, 2.5]])
+    loss, log = L({"nca_state": s})
+    assert abs(float(loss) - 2.0 * (2.0 + 0 + 0 + 0 + 1.5) / 5) < 1e-7 and set(log) == {"overflow"}
+    with pytest.raises(NotImplementedError):
+        Loss(torch.device("cpu"), appearance_loss_type="OT", target_style_image=torch.rand(3, 8, 8))

@@ -237,3 +237,9 @@ def cond_grow_backward(states: torch.Tensor, pre: torch.Tensor, goal: Optional[t
                                          _p(g["b1"]), _p(g["w2"]), _p(g["b2"]), _p(g["w3"]), _p(ws), nbytes, _stream()),
           "cond_grow_bwd")
     return g
+
+
+def dynca_nsteps_backward(*args, **kwargs):
+    raise NotImplementedError(
+        "ncahip: the DyNCA backward kernels are not built yet (the ConditionedNCA backward is: cond_grow_backward); "
+        "run DyNCA under torch.no_grad() for now")
