@@ -66,6 +66,21 @@ def event_ms(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes/launch of a kernel from the committed PMC passes (profiles/*_traffic.json; collected with
+    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, tools/collect_traffic.py)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            for k, v in json.load(open(f)).items():
+                if kernel_substr in k:
+                    best = v["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+    return best
+
+
 def cpu_baseline(prm, x0, goal):
     """Oracle (kind 'port': the reference's PyTorch CPU op sequence) on a bounded sample."""
     from oracle import nca_oracle as O
@@ -201,12 +216,12 @@ def main():
                        "mask_rng": "in-kernel philox4x32-10", "alive_fraction_at_end": round(alive_frac, 4),
                        "alive_fraction_roofline_run": round(alive_frac_roof, 4),
                        "parallelism": f"pool-shard x{world} (no data-path collective)"},
-            "roofline": {"kernel": "cond_step_fwd_kernel<16,8,32,4>", "bound": "mfma", "achieved": tflops,
+            "roofline": {"kernel": "cond_step_fwd_wave_kernel<16>", "bound": "mfma", "achieved": tflops,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "launch_ms": ms_launch, "flops_per_cell": FLOPS_PER_CELL,
+                         "traffic": pmc_traffic("cond_step_fwd_wave_kernel"), "launch_ms": ms_launch, "flops_per_cell": FLOPS_PER_CELL,
                          "algorithmic_bytes_per_cell": BYTES_PER_CELL_STEP, "cells_per_launch": cells},
             "roofline_stencil": {"kernel": "dynca_perceive_kernel<vec4>", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
-                                 "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None, "launch_ms": ms_st,
+                                 "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": pmc_traffic("dynca_perceive_kernel"), "launch_ms": ms_st,
                                  "bytes_per_cell": STENCIL_BYTES_PER_CELL, "cells_per_launch": cells,
                                  "cells_per_s": cells / (ms_st * 1e-3)},
         }

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/<tag>_traffic.json.
+HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KiB and on gfx950
+FETCH_SIZE reports exactly half of a wide coalesced (16 B/lane) read stream (MI355X_MICROARCH.md, HBM)."""
+import csv, glob, json, sys
+from collections import defaultdict
+
+root, out = sys.argv[1], sys.argv[2]
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    per = defaultdict(float)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            per[(r["Kernel_Name"], r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+    for (k, _, c), v in per.items():
+        acc[k][c].append(v)
+res = {}
+for k, cs in acc.items():
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        fe, wr = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]), sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
+        res[k.split("(")[0][-70:]] = {"FETCH_SIZE_KiB": fe, "WRITE_SIZE_KiB": wr, "hbm_bytes_per_launch": (2 * fe + wr) * 1024,
+                                      "launches": len(cs["FETCH_SIZE"])}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
