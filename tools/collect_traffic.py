@@ -18,7 +18,9 @@ res = {}
 for k, cs in acc.items():
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         fe, wr = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]), sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
-        res[k.split("(")[0][-70:]] = {"FETCH_SIZE_KiB": fe, "WRITE_SIZE_KiB": wr, "hbm_bytes_per_launch": (2 * fe + wr) * 1024,
+        import re
+        m = re.search(r"(\w+_kernel\w*(?:<[^>]*>)?)", k)
+        res[m.group(1) if m else k[:80]] = {"FETCH_SIZE_KiB": fe, "WRITE_SIZE_KiB": wr, "hbm_bytes_per_launch": (2 * fe + wr) * 1024,
                                       "launches": len(cs["FETCH_SIZE"])}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
