@@ -93,6 +93,21 @@ int ncahip_dynca_nsteps_fwd_f32(float *states, int ring, int T, const float *con
                                 float update_rate, uint64_t seed, uint64_t step0,
                                 ncahip_stream_t stream);
 
+/* Backward of ONE DyNCA step (autograd through dynca.py:117-138; dynca.py:123: no gradient into cond).
+ *   In : x_t (the step's input state), the same cond / u (or seed, step) / weights, g_next = dL/dx_{t+1}.
+ *   Out: g_x = dL/dx_t (data path through W2^T, relu', W1^T on MFMA, then the adjoint of "F.pad(mode) + fixed 3x3
+ *        filters", plus the residual path), and the two operand pairs of the weight-gradient GEMMs, which the
+ *        caller evaluates with a library GEMM over all cells:
+ *            h_out  = relu(w1 y + b1)            [B,fc,H,W]     dW2 += (g_next*mask) h^T ,  db2 += sum(g_next*mask)
+ *            dh_out = dL/d(w1 y + b1)            [B,fc,H,W]     dW1 += dh y^T            ,  db1 += sum(dh)
+ *        (y = [ncahip_dynca_perceive_f32(x_t) | cond], mask = floor(u + rate)).  dy_scratch: [B,4C,H,W] floats. */
+int ncahip_dynca_step_bwd_f32(const float *x_t, const float *cond, const float *u,
+                              const float *w1, const float *b1, const float *w2, const float *b2,
+                              int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                              float update_rate, uint64_t seed, uint64_t step,
+                              const float *g_next, float *g_x, float *h_out, float *dh_out,
+                              float *dy_scratch, ncahip_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * ConditionedNCA fused step                 EncoderConditioning/nca.py:181-195
  *

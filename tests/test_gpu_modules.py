@@ -178,3 +178,34 @@ def test_trainer_iterations_on_gpu():
     assert len(losses) == 4 and all(np.isfinite(losses))
     assert not torch.equal(m.update_net.out[0].weight.detach(), w0)            # the optimiser moved the weights
     assert sum(tr.pool[i] is not None for i in range(16)) >= 4 and tr.pool._dense.is_cuda
+
+
+def test_dynca_autograd_through_module():
+    """loss.backward() through DyNCA.forward_nsteps incl. the rgb head and intermediate features."""
+    from ncahip.models.dynca import DyNCA
+    torch.manual_seed(2)
+    d = DyNCA(12, 3, fc_dim=96, padding_mode="circular", conditioning="edges", edge_transform="tanh", device=torch.device(DEV))
+    with torch.no_grad():
+        d.w2.weight.mul_(10.0); d.w1.bias.uniform_(-0.1, 0.1)
+    prm = {k: v.detach().cpu().clone() for k, v in d.state_dict().items() if k.startswith("w")}
+    gen = torch.Generator().manual_seed(9)
+    x0 = torch.rand(2, 12, 16, 24, generator=gen) - 0.5
+    cimg = torch.rand(2, 1, 16, 24, generator=gen) * 2 - 1
+    us = [torch.rand(2, 1, 16, 24, generator=gen) for _ in range(3)]
+    c1, c2 = torch.randn(2, 3, 16, 24, generator=gen), torch.randn(2, 3, 16, 24, generator=gen)
+    p = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+    xr = x0.clone().requires_grad_(True)
+    cond = O.edge_extractor(cimg, "tanh")
+    xs, x = [], xr
+    for u in us:
+        x = O.dynca_step(x, cond, u, p, "circular", 0.5); xs.append(x)
+    ((O.dynca_to_rgb(xs[-1], 3) * c1).sum() + (O.dynca_to_rgb(xs[0], 3) * c2).sum()).backward()
+    d._draw = lambda x, steps, it=iter(us): torch.stack([next(it).to(x.device) for _ in range(steps)])
+    xd = x0.to(DEV).requires_grad_(True)
+    out, rgb, mids = d.forward_nsteps(xd, 3, cond_img=cimg.to(DEV), return_middle_feature=True)
+    ((rgb * c1.to(DEV)).sum() + (mids[0] * c2.to(DEV)).sum()).backward()
+    sc = lambda t: max(float(t.abs().max()), 1e-6)
+    assert float((xd.grad.cpu() - xr.grad).abs().max()) / sc(xr.grad) < 2e-4
+    for k in ("w1.weight", "w1.bias", "w2.weight", "w2.bias"):
+        gk = dict(d.named_parameters())[k].grad.cpu()
+        assert float((gk - p[k].grad).abs().max()) / sc(p[k].grad) < 2e-4, k

@@ -392,3 +392,45 @@ def _oracle_noalive_grads(x0, goal, us, prm, cot, C):
         x = O.cond_step(x, g, u, p, 0, 0.1, 0.5, use_living_channel=False)
     (x * cot).sum().backward()
     return x.detach(), x0.grad, g.grad, {k: v.grad for k, v in p.items()}
+
+
+def test_dynca_nsteps_backward_golden_g8(ops):
+    """DyNCA gradients through 4 steps vs the reference's own autograd, all four F.pad modes."""
+    g = load("g8_dynca_grads")
+    Tn = int(g["T"])
+    for pad in O.PAD_MODES:
+        prm = {k: T(g[f"{pad}.{k}"]) for k in ("w1.weight", "w1.bias", "w2.weight", "w2.bias")}
+        x0 = T(g[f"{pad}.x0"], DEV)
+        cond = O.edge_extractor(T(g[f"{pad}.cond_img"]), "tanh").to(DEV)
+        us = T(g[f"{pad}.us"], DEV)
+        w = dyn_w(ops, prm, x0)
+        xT, states = ops.dynca_nsteps(x0, Tn, cond, us, w, pad, 0.5, keep_history=True)
+        assert rel_err(xT, T(g[f"{pad}.xT"])) < REL_TOL
+        gfin = T(g[f"{pad}.cot"], DEV).clone()
+        gfin[:, :3] += 2.0 * T(g[f"{pad}.cot_rgb"], DEV)           # rgb = 2 x[:, :c_out] head (dynca.py:140-141)
+        gr = ops.dynca_nsteps_backward(states, cond, us, w, gfin, None, Tn, pad, 0.5)
+        assert _grad_close(gr["x0"], T(g[f"{pad}.d_x0"])), pad
+        assert _grad_close(gr["w1"], T(g[f"{pad}.g.w1.weight"])[:, :, 0, 0]), pad
+        assert _grad_close(gr["b1"], T(g[f"{pad}.g.w1.bias"])), pad
+        assert _grad_close(gr["w2"], T(g[f"{pad}.g.w2.weight"])[:, :, 0, 0]), pad
+        assert _grad_close(gr["b2"], T(g[f"{pad}.g.w2.bias"])), pad
+
+
+@pytest.mark.parametrize("C,fc,cc,shape,pad", [(16, 128, 3, (2, 24, 40), "circular"), (12, 96, 0, (1, 9, 13), "reflect"),
+                                               (16, 128, 2, (2, 3, 2), "circular"), (8, 32, 1, (1, 1, 5), "replicate")])
+def test_dynca_backward_vs_oracle_autograd(ops, C, fc, cc, shape, pad):
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(C + W)
+    prm = rand_dynca_prm(C, fc, cc, seed=3, scale=3.0)
+    x0 = torch.rand(B, C, H, W, generator=gen) - 0.5
+    cond = torch.rand(B, cc, H, W, generator=gen) if cc else None
+    us = torch.rand(3, B, 1, H, W, generator=gen)
+    cot = torch.randn(B, C, H, W, generator=gen)
+    xT, dx0, grads = O.dynca_nsteps_loss_grads(x0, cond, list(us), prm, pad, 0.5, cot)
+    w = dyn_w(ops, prm, x0.to(DEV))
+    cd = None if cond is None else cond.to(DEV)
+    _, states = ops.dynca_nsteps(x0.to(DEV), 3, cd, us.to(DEV), w, pad, 0.5, keep_history=True)
+    gr = ops.dynca_nsteps_backward(states, cd, us.to(DEV), w, cot.to(DEV), None, 3, pad, 0.5)
+    assert _grad_close(gr["x0"], dx0)
+    assert _grad_close(gr["w1"], grads["w1.weight"][:, :, 0, 0]) and _grad_close(gr["b1"], grads["w1.bias"])
+    assert _grad_close(gr["w2"], grads["w2.weight"][:, :, 0, 0]) and _grad_close(gr["b2"], grads["w2.bias"])

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Timing of the training-shaped pass (BASELINE configs[2] shape family): grow with history + backward."""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "video-stylization-with-nca_amd")]
+import torch
+import bench
+from ncahip import ops
+
+def run(B, T, H=256, W=256, C=16, iters=3):
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(0)
+    prm = bench.make_weights(gen)
+    x = torch.rand(B, C, H, W, generator=gen).to(dev)
+    goal = (torch.randn(B, 12, H, W, generator=gen) * 0.5).to(dev)
+    cot = torch.randn(B, C, H, W, generator=gen).to(dev)
+    w = ops.CondWeights(prm["perception_net.weight"], prm["update_net.out.0.weight"], prm["update_net.out.0.bias"],
+                        prm["update_net.out.2.weight"], prm["update_net.out.2.bias"], prm["update_net.out.4.weight"], x)
+    def fwd():
+        return ops.cond_grow(x, T, goal, None, w, 3, seed=1, step0=0, keep_history=True)
+    out, states, pre = fwd()
+    g = ops.cond_grow_backward(states, pre, goal, None, w, cot, T, 3, seed=1, step0=0)
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    tf = tb = 0.0
+    for _ in range(iters):
+        e[0].record(); out, states, pre = fwd(); e[1].record()
+        g = ops.cond_grow_backward(states, pre, goal, None, w, cot, T, 3, seed=1, step0=0); e[2].record()
+        torch.cuda.synchronize()
+        tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
+    tf /= iters; tb /= iters
+    cells = B * H * W * T
+    print(json.dumps({"B": B, "T": T, "fwd_ms": tf, "bwd_ms": tb, "fwd_us_per_step": tf / T * 1e3, "bwd_us_per_step": tb / T * 1e3,
+                      "fwd_Gcells_s": cells / tf / 1e6, "fwd_bwd_Gcells_s": cells / (tf + tb) / 1e6,
+                      "bwd_over_fwd": tb / tf}))
+
+run(8, 32)
+run(32, 16)

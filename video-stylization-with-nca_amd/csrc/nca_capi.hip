@@ -186,6 +186,18 @@ int ncahip_cond_grow_fwd_f32(float* states, uint8_t* pre, int ring, int T, float
                                                alive_ch, alive_thr, clamp_lo, clamp_hi, st), "cond_grow finalize");
 }
 
+int ncahip_dynca_step_bwd_f32(const float* x_t, const float* cond, const float* u, const float* w1, const float* b1,
+                              const float* w2, const float* b2, int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                              float update_rate, uint64_t seed, uint64_t step, const float* g_next, float* g_x, float* h_out,
+                              float* dh_out, float* dy_scratch, ncahip_stream_t stream) {
+    if (!g_next || !g_x || !h_out || !dh_out || !dy_scratch) return fail(NCAHIP_EINVAL, "dynca step bwd: null pointer");
+    if (int rc = check_dynca(x_t, g_x, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
+    if (g_next == g_x) return fail(NCAHIP_EINVAL, "dynca step bwd: g_next and g_x must not alias");
+    NcaDyncaArgs a{x_t, nullptr, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step,
+                   g_next, h_out, dh_out, dy_scratch, g_x};
+    return hip_result(nca_launch_dynca_step_bwd(a, (hipStream_t)stream), "dynca_step_bwd");
+}
+
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 size_t ncahip_cond_grow_bwd_workspace(int B, int C, int H, int W, int hidden) {

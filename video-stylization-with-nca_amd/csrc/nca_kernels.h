@@ -12,6 +12,13 @@ struct NcaDyncaArgs {
     int B, C, H, W, fc, c_cond, pad_mode;
     float rate;
     uint64_t seed, step;
+    // backward variant only (nca_launch_dynca_step_bwd): dL/dx_{t+1} in, recomputed hidden layer / its gradient /
+    // dL/dperception out, dL/dx_t out (stencil-adjoint kernel)
+    const float* g_next;   // [B,C,H,W]
+    float* hbuf;           // relu(w1 y + b1)                [B,fc,H,W]
+    float* dhbuf;          // dL/d(pre-activation)           [B,fc,H,W]
+    float* dybuf;          // dL/dy, first 4C rows           [B,4C,H,W]
+    float* g_out;          // dL/dx_t                        [B,C,H,W]
 };
 
 struct NcaCondArgs {
@@ -54,6 +61,7 @@ hipError_t nca_launch_reduce_wp(const float* part, float* dst, int B, int C, int
 // fused steps (nca_step_fwd.hip); hipErrorInvalidValue when no instantiation covers the shape
 hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st);
 hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st);
+hipError_t nca_launch_dynca_step_bwd(const NcaDyncaArgs& a, hipStream_t st);
 // wave-private-tile variant (nca_cond_wave.hip); needs W % 4 == 0 and 16-byte aligned x_in / goal
 hipError_t nca_launch_cond_step_fwd_wave(const NcaCondArgs& a, hipStream_t st);
 

@@ -151,13 +151,23 @@ struct DyncaCfg {
     static constexpr int OFF_MK = OFF_Z + CP * CS;
     static constexpr int OFF_CN = OFF_MK + TH * TW;
     static constexpr int LDS_FLOATS = OFF_CN + (HAS_COND ? 4 * TH * TW : 0);
+    // backward variant: transposed A-operand images
+    static constexpr int MJ = (4 * CP + (HAS_COND ? 4 : 0) + 15) / 16;  // 16-row tiles of the perception index j
+    static constexpr int OFF_W2T = LDS_FLOATS;                        // [M1T][4][64]:  W2[ch=4gg+s][h=16m+i]
+    static constexpr int OFF_W1T = OFF_W2T + M1T * 4 * 64;            // [MJ][K2S][64]: W1[h=k(s,gg)][j=16mj+i]
+    static constexpr int LDS_FLOATS_BWD = OFF_W1T + MJ * K2S * 64;
     static_assert(FC % 16 == 0 && CP % 4 == 0 && TW % 16 == 0, "shape");
     static_assert(NTILES16 % (4 * NT) == 0, "tile must split evenly over 4 waves x NT");
     static_assert(OFF_Z % 4 == 0 && CS % 4 == 0 && TH * TW == kThreads, "16-byte carve; one cell per thread");
+    static_assert(LDS_FLOATS_BWD * 4 <= 160 * 1024, "LDS budget (backward)");
 };
 
-template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT, bool VEC>
-__global__ __launch_bounds__(kThreads, 2) void dynca_step_fwd_kernel(const NcaDyncaArgs a) {
+// BWD = true: the backward data path of the same step (autograd through dynca.py:117-138).  Recomputes the
+// hidden layer, then dh = (W2^T (G*mask)) * 1[h>0] and dL/dy = W1^T dh on MFMA (accumulator tile == next B
+// operand, as in the forward); writes relu(h), dh and dL/dy[:4C].  The two weight-gradient GEMMs
+// (dW2 = (G*mask) h^T, dW1 = dh y^T, K = all cells) are plain library GEMMs on those buffers.
+template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT, bool VEC, bool BWD = false>
+__global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(const NcaDyncaArgs a) {
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
     using Pos = TilePos<TH, TW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -192,6 +202,20 @@ __global__ __launch_bounds__(kThreads, 2) void dynca_step_fwd_kernel(const NcaDy
     });
     fill_image<FC>(B1L, a.b1, tid, [&](int idx) -> long { return idx < fc ? idx : -1; });
     fill_image<K::M2T * 16>(B2L, a.b2, tid, [&](int idx) -> long { return idx < C ? idx : -1; });
+    const float* const W2T = smem + K::OFF_W2T;
+    const float* const W1T = smem + K::OFF_W1T;
+    if (BWD) {
+        fill_image<K::M1T * 4 * 64>(smem + K::OFF_W2T, a.w2, tid, [&](int idx) -> long {
+            const int l = idx & 63, s = (idx >> 6) % 4, m = (idx >> 6) / 4;
+            const int ch = 4 * (l >> 4) + s, h = 16 * m + (l & 15);
+            return (ch < C && h < fc) ? (long)ch * fc + h : -1;
+        });
+        fill_image<K::MJ * K::K2S * 64>(smem + K::OFF_W1T, a.w1, tid, [&](int idx) -> long {
+            const int l = idx & 63, s = (idx >> 6) % K::K2S, mj = (idx >> 6) / K::K2S;
+            const int h = 16 * (s >> 2) + 4 * (l >> 4) + (s & 3), j = 16 * mj + (l & 15);
+            return (h < fc && j < K1) ? (long)h * K1 + j : -1;
+        });
+    }
 
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int ntiles = a.B * tiles_x * tiles_y;
@@ -272,57 +296,137 @@ __global__ __launch_bounds__(kThreads, 2) void dynca_step_fwd_kernel(const NcaDy
 #pragma unroll
                 for (int n = 0; n < NT; ++n) P[n][CP] = CN[g * TH * TW + r0[n] * TW + q0[n]];
             }
-            // ---- MLP on MFMA: layer 1 streamed tile-by-tile into layer 2 -----------------
-            f32x4 acc2[K::M2T][NT];
+            if constexpr (BWD) {
+                // ---- backward data path -----------------------------------------------------------------
+                float dO[NT][4];   // dL/d(out) = G * mask, accumulator layout (channel 4g+r, cell ci)
+                bool live[NT];
 #pragma unroll
-            for (int m2 = 0; m2 < K::M2T; ++m2) {
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(B2L + 16 * m2 + 4 * g);
+                for (int n = 0; n < NT; ++n) {
+                    const int gy = ty0 + r0[n], gx = tx0 + q0[n];
+                    live[n] = gy < H && gx < W;
+                    const float mk = MK[r0[n] * TW + q0[n]];
+                    const float* const gb = a.g_next + (size_t)b * C * plane + (live[n] ? (size_t)gy * W + gx : 0);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc2[m2][n] = bias;
-            }
-#pragma unroll 1
-            for (int m = 0; m < K::M1T; ++m) {
-                const float* const w1m = W1L + m * K::K1S * 64 + lane;
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(B1L + 16 * m + 4 * g);
-                f32x4 acc1[NT];
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc1[n] = bias;
-#pragma unroll
-                for (int s = 0; s < K::K1S; ++s) {
-                    const float wa = w1m[s * 64];
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) acc1[n] = nca_mfma(wa, P[n][s], acc1[n]);
-                }
-                const float* const w2m = W2L + (4 * m) * 64 + lane;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                    for (int m2 = 0; m2 < K::M2T; ++m2) {
-                        const float wa = w2m[(m2 * K::K2S + r) * 64];
-#pragma unroll
-                        for (int n = 0; n < NT; ++n)
-                            acc2[m2][n] = nca_mfma(wa, fmaxf(acc1[n][r], 0.0f), acc2[m2][n]);
+                    for (int r = 0; r < 4; ++r) {
+                        const int ch = 4 * g + r;
+                        const float gv = gb[(size_t)min(ch, C - 1) * plane];
+                        dO[n][r] = (live[n] && ch < C) ? gv * mk : 0.0f;
                     }
                 }
-            }
-            // ---- residual + stochastic mask (dynca.py:131-133) ---------------------------
+                f32x4 dY[K::MJ][NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int gy = ty0 + r0[n], gx = tx0 + q0[n];
-                if (gy < H && gx < W) {
-                    const float mk = MK[r0[n] * TW + q0[n]];
-                    float* const ob = a.x_out + (size_t)b * C * plane + (size_t)gy * W + gx;
+                for (int mj = 0; mj < K::MJ; ++mj)
 #pragma unroll
-                    for (int m2 = 0; m2 < K::M2T; ++m2)
+                    for (int n = 0; n < NT; ++n) dY[mj][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                for (int m = 0; m < K::M1T; ++m) {
+                    const float* const w1m = W1L + m * K::K1S * 64 + lane;
+                    const f32x4 bias = *reinterpret_cast<const f32x4*>(B1L + 16 * m + 4 * g);
+                    f32x4 acc1[NT], dacc[NT];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) { acc1[n] = bias; dacc[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                    for (int s = 0; s < K::K1S; ++s) {
+                        const float wa = w1m[s * 64];
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) acc1[n] = nca_mfma(wa, P[n][s], acc1[n]);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const float wa = W2T[(m * 4 + s) * 64 + lane];
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) dacc[n] = nca_mfma(wa, dO[n][s], dacc[n]);
+                    }
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const size_t cell = live[n] ? (size_t)(ty0 + r0[n]) * W + tx0 + q0[n] : 0;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int ch = 16 * m2 + 4 * g + r;
-                            if (ch < C) {
-                                const float xo = Z[ch * K::CS + (r0[n] + 1) * K::RS + q0[n] + 4];
-                                ob[ch * plane] = xo + acc2[m2][n][r] * mk;
+                            const int hid = 16 * m + 4 * g + r;
+                            const float hv = fmaxf(acc1[n][r], 0.0f);
+                            const float dv = acc1[n][r] > 0.0f ? dacc[n][r] : 0.0f;   // relu' = 0 at exactly 0
+                            dacc[n][r] = dv;
+                            if (live[n] && hid < fc) {
+                                a.hbuf[((size_t)b * fc + hid) * plane + cell] = hv;
+                                a.dhbuf[((size_t)b * fc + hid) * plane + cell] = dv;
                             }
                         }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int mj = 0; mj < K::MJ; ++mj) {
+                            const float wa = W1T[(mj * K::K2S + 4 * m + r) * 64 + lane];
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) dY[mj][n] = nca_mfma(wa, dacc[n][r], dY[mj][n]);
+                        }
                 }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    if (!live[n]) continue;
+                    const size_t cell = (size_t)(ty0 + r0[n]) * W + tx0 + q0[n];
+#pragma unroll
+                    for (int mj = 0; mj < K::MJ; ++mj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int j = 16 * mj + 4 * g + r;
+                            if (j < 4 * C) a.dybuf[((size_t)b * 4 * C + j) * plane + cell] = dY[mj][n][r];
+                        }
+                }
+            } else {
+                // ---- MLP on MFMA: layer 1 streamed tile-by-tile into layer 2 -----------------
+                f32x4 acc2[K::M2T][NT];
+    #pragma unroll
+                for (int m2 = 0; m2 < K::M2T; ++m2) {
+                    const f32x4 bias = *reinterpret_cast<const f32x4*>(B2L + 16 * m2 + 4 * g);
+    #pragma unroll
+                    for (int n = 0; n < NT; ++n) acc2[m2][n] = bias;
+                }
+    #pragma unroll 1
+                for (int m = 0; m < K::M1T; ++m) {
+                    const float* const w1m = W1L + m * K::K1S * 64 + lane;
+                    const f32x4 bias = *reinterpret_cast<const f32x4*>(B1L + 16 * m + 4 * g);
+                    f32x4 acc1[NT];
+    #pragma unroll
+                    for (int n = 0; n < NT; ++n) acc1[n] = bias;
+    #pragma unroll
+                    for (int s = 0; s < K::K1S; ++s) {
+                        const float wa = w1m[s * 64];
+    #pragma unroll
+                        for (int n = 0; n < NT; ++n) acc1[n] = nca_mfma(wa, P[n][s], acc1[n]);
+                    }
+                    const float* const w2m = W2L + (4 * m) * 64 + lane;
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+    #pragma unroll
+                        for (int m2 = 0; m2 < K::M2T; ++m2) {
+                            const float wa = w2m[(m2 * K::K2S + r) * 64];
+    #pragma unroll
+                            for (int n = 0; n < NT; ++n)
+                                acc2[m2][n] = nca_mfma(wa, fmaxf(acc1[n][r], 0.0f), acc2[m2][n]);
+                        }
+                    }
+                }
+                // ---- residual + stochastic mask (dynca.py:131-133) ---------------------------
+    #pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int gy = ty0 + r0[n], gx = tx0 + q0[n];
+                    if (gy < H && gx < W) {
+                        const float mk = MK[r0[n] * TW + q0[n]];
+                        float* const ob = a.x_out + (size_t)b * C * plane + (size_t)gy * W + gx;
+    #pragma unroll
+                        for (int m2 = 0; m2 < K::M2T; ++m2)
+    #pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int ch = 16 * m2 + 4 * g + r;
+                                if (ch < C) {
+                                    const float xo = Z[ch * K::CS + (r0[n] + 1) * K::RS + q0[n] + 4];
+                                    ob[ch * plane] = xo + acc2[m2][n][r] * mk;
+                                }
+                            }
+                    }
+                }
+
             }
         }
     }
@@ -727,6 +831,77 @@ hipError_t launch_dynca(const NcaDyncaArgs& a, hipStream_t st) {
     return vec ? launch_dynca_v<CP, FC, HAS_COND, true>(a, st) : launch_dynca_v<CP, FC, HAS_COND, false>(a, st);
 }
 
+template <int CP, int FC, bool HAS_COND>
+hipError_t launch_dynca_bwd(const NcaDyncaArgs& a, hipStream_t st) {
+    constexpr int TH = 8, TW = 32, NT = 4;
+    using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
+    const bool vec = (a.W % 4 == 0) && aligned16(a.x_in);
+    const size_t lds = (size_t)K::LDS_FLOATS_BWD * sizeof(float);
+    const int ntiles = a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+    const int grid = grid_for(ntiles, 1);
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = set_lds(kern, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, a);
+        return hipGetLastError();
+    };
+    return vec ? go(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, true, true>)
+               : go(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, false, true>);
+}
+
+// dL/dx_t = G + dy[0:C] + adj(Sx)(dy[C:2C]) + adj(Sy)(dy[2C:3C]) + adj(L)(dy[3C:4C]), where adj is the adjoint of
+// "F.pad(mode) then 3x3 cross-correlation" (dynca.py:83-86): a cell p collects w[t] * dy[q] from every (q, t) whose
+// padded source index pad(q + t) equals p.  Candidates q lie in p's 3x3 neighbourhood (wrapped for 'circular').
+__global__ __launch_bounds__(256) void dynca_step_bwd_stencil_kernel(const NcaDyncaArgs a) {
+    const int C = a.C, H = a.H, W = a.W, pad = a.pad_mode;
+    const size_t plane = (size_t)H * W;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)a.B * C * plane) return;
+    const int px = (int)(id % W), py = (int)((id / W) % H), c = (int)((id / plane) % C), b = (int)(id / (plane * C));
+    const float* const dy = a.dybuf + (size_t)b * 4 * C * plane;
+    const size_t off = (size_t)py * W + px;
+    float acc = a.g_next[id] + dy[(size_t)c * plane + off];
+    // per axis: for candidate offset iq in {-1,0,1} and tap t in {-1,0,1}: does pad(q + t) land on p ?
+    int qy[3], qx[3];
+    bool hy[3][3], hx[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int q = py + i - 1;
+        if (pad == NCA_PAD_CIRCULAR) q = ((q % H) + H) % H;
+        bool ok = q >= 0 && q < H;
+        for (int k = 0; k < i; ++k) ok = ok && !(qy[k] == q);   // wrapped duplicates when H < 3
+        qy[i] = ok ? q : -1;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) hy[i][t] = ok && nca_pad_index(q + t - 1, H, pad) == py;
+        q = px + i - 1;
+        if (pad == NCA_PAD_CIRCULAR) q = ((q % W) + W) % W;
+        ok = q >= 0 && q < W;
+        for (int k = 0; k < i; ++k) ok = ok && !(qx[k] == q);
+        qx[i] = ok ? q : -1;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) hx[i][t] = ok && nca_pad_index(q + t - 1, W, pad) == px;
+    }
+    const float SX[3][3] = {{-1.f, 0.f, 1.f}, {-2.f, 0.f, 2.f}, {-1.f, 0.f, 1.f}};
+    const float LP[3][3] = {{1.f, 2.f, 1.f}, {2.f, -12.f, 2.f}, {1.f, 2.f, 1.f}};
+#pragma unroll
+    for (int iy = 0; iy < 3; ++iy)
+#pragma unroll
+        for (int ix = 0; ix < 3; ++ix) {
+            if (qy[iy] < 0 || qx[ix] < 0) continue;
+            float wsx = 0.f, wsy = 0.f, wl = 0.f;
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx)
+                    if (hy[iy][ty] && hx[ix][tx]) { wsx += SX[ty][tx]; wsy += SX[tx][ty]; wl += LP[ty][tx]; }
+            const size_t qo = (size_t)qy[iy] * W + qx[ix];
+            acc = fmaf(wsx, dy[(size_t)(C + c) * plane + qo], acc);
+            acc = fmaf(wsy, dy[(size_t)(2 * C + c) * plane + qo], acc);
+            acc = fmaf(wl, dy[(size_t)(3 * C + c) * plane + qo], acc);
+        }
+    a.g_out[id] = acc;
+}
+
 template <int CP, bool VEC>
 hipError_t launch_cond_v(const NcaCondArgs& a, hipStream_t st) {
     constexpr int TH = 8, TW = 32, NT = 4;
@@ -762,6 +937,17 @@ hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st) {
     if (a.C <= 12 && a.fc <= 96) return hc ? launch_dynca<12, 96, true>(a, st) : launch_dynca<12, 96, false>(a, st);
     if (a.C <= 16 && a.fc <= 128) return hc ? launch_dynca<16, 128, true>(a, st) : launch_dynca<16, 128, false>(a, st);
     return hipErrorInvalidValue;
+}
+
+hipError_t nca_launch_dynca_step_bwd(const NcaDyncaArgs& a, hipStream_t st) {
+    const bool hc = a.c_cond > 0;
+    hipError_t e = hipErrorInvalidValue;
+    if (a.C <= 12 && a.fc <= 96) e = hc ? launch_dynca_bwd<12, 96, true>(a, st) : launch_dynca_bwd<12, 96, false>(a, st);
+    else if (a.C <= 16 && a.fc <= 128) e = hc ? launch_dynca_bwd<16, 128, true>(a, st) : launch_dynca_bwd<16, 128, false>(a, st);
+    if (e != hipSuccess) return e;
+    const size_t n = (size_t)a.B * a.C * a.H * a.W;
+    hipLaunchKernelGGL(dynca_step_bwd_stencil_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    return hipGetLastError();
 }
 
 hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st) {

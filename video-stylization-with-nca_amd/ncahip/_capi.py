@@ -23,6 +23,7 @@ SIGNATURES = {
     "ncahip_cond_perceive_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
     "ncahip_dynca_step_fwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P],
     "ncahip_dynca_nsteps_fwd_f32": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P],
+    "ncahip_dynca_step_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P, _P, _P, _P, _P, _P],
     "ncahip_cond_step_fwd_f32": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F,
                                  _F, _F, _U64, _U64, _P],
     "ncahip_cond_finalize_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P],

@@ -68,7 +68,10 @@ class _DyncaNSteps(torch.autograd.Function):
     def backward(ctx, g_out, g_states):
         states, cond = ctx.saved_tensors
         cfg = ctx.cfg
-        g = ops.dynca_nsteps_backward(states, cond if cond.numel() else None, cfg["us"], ctx.w, g_out.contiguous(),
+        gfin = g_out.contiguous()
+        if g_states is not None:                       # cotangents of intermediate states (return_middle_feature)
+            gfin = gfin + g_states[cfg["T"]]
+        g = ops.dynca_nsteps_backward(states, cond if cond.numel() else None, cfg["us"], ctx.w, gfin,
                                       g_states, cfg["T"], cfg["pad"], cfg["rate"], cfg["seed"], cfg["step0"])
         return g["x0"], None, g["w1"][:, :, None, None], g["b1"], g["w2"][:, :, None, None], g["b2"], None  # no grad to cond (dynca.py:123)
 

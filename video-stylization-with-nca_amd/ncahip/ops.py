@@ -239,7 +239,43 @@ def cond_grow_backward(states: torch.Tensor, pre: torch.Tensor, goal: Optional[t
     return g
 
 
-def dynca_nsteps_backward(*args, **kwargs):
-    raise NotImplementedError(
-        "ncahip: the DyNCA backward kernels are not built yet (the ConditionedNCA backward is: cond_grow_backward); "
-        "run DyNCA under torch.no_grad() for now")
+def dynca_nsteps_backward(states: torch.Tensor, cond: Optional[torch.Tensor], us: Optional[torch.Tensor], w: DyncaWeights,
+                          g_final: torch.Tensor, g_states: Optional[torch.Tensor], T: int, pad_mode: str = "replicate",
+                          update_rate: float = 0.5, seed: int = 0, step0: int = 0):
+    """Backward of dynca_nsteps (states = the keep_history=True buffer [T+1,B,C,H,W]).  Per step the HIP kernels
+    produce dL/dx_t and the GEMM operands (see ncahip_dynca_step_bwd_f32); the weight-gradient GEMMs with K = all
+    cells are evaluated by rocBLAS through torch.matmul.  g_states (optional, [T+1,...]) adds dL/dx_t cotangents of
+    intermediate states (forward_nsteps' return_middle_feature).  Returns dict x0, w1 [fc,4C+cc], b1, w2 [C,fc], b2."""
+    states, g = _dev(states, "states"), _dev(g_final, "g_final")
+    _, B, C, H, W = states.shape
+    c_cond = 0 if cond is None else cond.shape[1]
+    if cond is not None:
+        cond = _dev(cond, "cond")
+    if us is not None:
+        us = _dev(us, "us")
+    dev = states.device
+    fc, k1 = w.fc, 4 * C + c_cond
+    hbuf = torch.empty(B, fc, H, W, device=dev)
+    dhbuf = torch.empty(B, fc, H, W, device=dev)
+    dy = torch.empty(B, 4 * C, H, W, device=dev)
+    gw1, gb1 = torch.zeros(fc, k1, device=dev), torch.zeros(fc, device=dev)
+    gw2, gb2 = torch.zeros(C, fc, device=dev), torch.zeros(C, device=dev)
+    for t in range(T - 1, -1, -1):
+        x_t = states[t]
+        u_t = us[t].reshape(B, 1, H, W) if us is not None else philox_uniform(B, H, W, seed, step0 + t, dev)
+        gx = torch.empty_like(g)
+        check(lib().ncahip_dynca_step_bwd_f32(_p(x_t), _p(cond), _p(u_t), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C, H, W,
+                                              fc, c_cond, PAD_MODES[pad_mode], update_rate, seed, step0 + t, _p(g), _p(gx),
+                                              _p(hbuf), _p(dhbuf), _p(dy), _stream()), "dynca_step_bwd")
+        do = g * (u_t + update_rate).floor()
+        y = dynca_perceive(x_t, pad_mode)
+        if cond is not None:
+            y = torch.cat([y, cond], dim=1)
+        gw2 += torch.matmul(do.transpose(0, 1).reshape(C, -1), hbuf.transpose(0, 1).reshape(fc, -1).t())
+        gb2 += do.sum(dim=(0, 2, 3))
+        gw1 += torch.matmul(dhbuf.transpose(0, 1).reshape(fc, -1), y.transpose(0, 1).reshape(k1, -1).t())
+        gb1 += dhbuf.sum(dim=(0, 2, 3))
+        g = gx
+        if g_states is not None:
+            g = g + g_states[t]
+    return {"x0": g, "w1": gw1, "b1": gb1, "w2": gw2, "b2": gb2}
