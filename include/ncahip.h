@@ -45,8 +45,9 @@ const char *ncahip_last_error(void);
 /* Largest shapes the fused step kernels accept (C <= max_c, fc <= max_fc, hidden <= 64). */
 int ncahip_limits(int *max_c, int *max_fc, int *max_hidden);
 
-/* Test hook (process-wide): on != 0 routes every fused step through the generic any-shape kernels
- * instead of the aligned fast paths, so both can be checked against the oracle on the same inputs. */
+/* Test hook (process-wide) selecting which kernel family serves the fused steps, so every variant can be checked
+ * against the oracle on the same inputs: bit 0 = generic any-shape kernels instead of the aligned fast paths;
+ * bit 1 = symmetric wave-private ConditionedNCA kernel instead of the default producer/consumer one. */
 int ncahip_debug_force_generic(int on);
 
 /* Device-side check that the MFMA operand/accumulator lane maps the kernels assume hold on

@@ -67,7 +67,8 @@ int ncahip_version(void) { return NCAHIP_VERSION; }
 const char* ncahip_last_error(void) { return g_err; }
 
 int ncahip_debug_force_generic(int on) {
-    nca_set_force_generic(on != 0);
+    nca_set_force_generic((on & 1) != 0);    // bit 0: generic any-shape kernels
+    nca_set_cond_variant((on >> 1) & 1);     // bit 1: symmetric wave-private ConditionedNCA kernel instead of producer/consumer
     return 0;
 }
 

@@ -134,8 +134,9 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
         // ---- forward staging: s_t (XR), pre_t (PN), z_t (Z), fire mask (MK) -------------------------------
         TileRegs<CP> R;
         issue_loads<CP, true, true>(a, t, lane, R);
-        if (t.inner) stage_tile<CP, false>(a, t, PWR, lane, R, 0);
-        else stage_tile<CP, true>(a, t, PWR, lane, R, 0);
+        const TileLds L = wave_private_lds<CP>(PWR);
+        if (t.inner) stage_tile<CP, false>(a, t, L, lane, R, 0);
+        else stage_tile<CP, true>(a, t, L, lane, R, 0);
 
         // ---- pending x'_t: alpha halo 1 -> A1 (post mask), interior -> XR; incoming gradient -> TB --------
         const float* const xn = ba.x_next + (size_t)t.b * C * plane;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             const int n0 = pass * NT;
             // ---- forward recompute: P, h1, h2 kept in registers ------------------------------------------
             float P[NT][K::K1S];
-            perceive_tile<CP, NT>(smem, PWR, lane, n0, P);
+            perceive_tile<CP, NT>(smem, Z, lane, n0, P);
             f32x4 h1[4][NT], h2[4][NT];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {

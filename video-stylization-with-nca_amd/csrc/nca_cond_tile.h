@@ -20,11 +20,12 @@ template <int CP>
 struct WCfg {
     static constexpr int HID = 64;
     static constexpr int K1S = 3 * CP / 4;
+    static constexpr int K1S4 = (K1S + 3) / 4;   // k-steps of layer 1 in groups of 4 (16-byte A-operand reads)
     static constexpr int M3T = (CP + 15) / 16;
     static constexpr int WPS = 28;
     // shared weight image (floats)
     static constexpr int OFF_W1 = 0;
-    static constexpr int OFF_W2 = OFF_W1 + 4 * K1S * 64;
+    static constexpr int OFF_W2 = OFF_W1 + 4 * K1S4 * 4 * 64;
     static constexpr int OFF_W3 = OFF_W2 + 4 * 16 * 64;
     static constexpr int OFF_B1 = OFF_W3 + M3T * 16 * 64;
     static constexpr int OFF_B2 = OFF_B1 + HID;
@@ -98,6 +99,23 @@ __device__ __forceinline__ void fill_image_w(float* __restrict__ dst, const floa
             if (idx < N) dst[idx] = ok[u] ? v[u] : 0.0f;
         }
     }
+}
+
+// LDS arrays of one tile (all rows RS floats wide, image col tx0+c <-> index c+4; see WCfg for the sizes)
+struct TileLds {
+    float* Z;     // z = x + goal*pre, halo 1: [CP][6][RS]
+    float* XR;    // resolved state interior -> x' in place: [CP][XRS]
+    float* A3;    // alpha' halo 3 (10 rows); dead after the life mask is resolved
+    float* PN;    // pre-life mask of this step, halo 1 (6 rows); may alias A3
+    float* LIFE;  // life mask of the previous step, halo 2 (8 rows)
+    float* A2;    // resolved alpha, halo 2 (8 rows)
+    float* MK;    // fire mask, [4][16]
+};
+template <int CP>
+__device__ __forceinline__ TileLds wave_private_lds(float* PWR) {
+    using K = WCfg<CP>;
+    return TileLds{PWR + K::PW_Z, PWR + K::PW_XR, PWR + K::PW_A3, PWR + K::PW_A3, PWR + K::PW_LIFE, PWR + K::PW_A2,
+                   PWR + K::PW_A3 + ZROWS * RS};
 }
 
 // ---- per-wave tile bookkeeping ------------------------------------------------------------------
@@ -192,16 +210,15 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
 // Resolve the pending life mask, build z = x + goal*pre in LDS (halo 1), keep the resolved state for
 // the residual.  CHECK=false: no bounds logic.
 template <int CP, bool CHECK>
-__device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t, float* __restrict__ PWR, int lane_in,
+__device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t, const TileLds& L, int lane_in,
                                            const TileRegs<CP>& R, int tile_no) {
-    using K = WCfg<CP>;
-    float* const Z = PWR + K::PW_Z;
-    float* const XR = PWR + K::PW_XR;
-    float* const A3 = PWR + K::PW_A3;
-    float* const PN = PWR + K::PW_A3;  // A3 is dead once the life mask is resolved
-    float* const LIFE = PWR + K::PW_LIFE;
-    float* const A2 = PWR + K::PW_A2;
-    float* const MK = PWR + K::PW_A3 + ZROWS * RS;  // 64 floats in A3 rows 6-8
+    float* const Z = L.Z;
+    float* const XR = L.XR;
+    float* const A3 = L.A3;
+    float* const PN = L.PN;
+    float* const LIFE = L.LIFE;
+    float* const A2 = L.A2;
+    float* const MK = L.MK;
 
     const int C = a.C, H = a.H, W = a.W;
     const unsigned plane = (unsigned)(H * W);
@@ -322,10 +339,9 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
 
 // Learned depthwise perception (nca.py:99-107) from the LDS tile: P[n][3c'+f] for channel 4c'+g, cell (row n, col ci).
 template <int CP, int NT>
-__device__ __forceinline__ void perceive_tile(const float* __restrict__ WS, const float* __restrict__ PWR, int lane_in,
+__device__ __forceinline__ void perceive_tile(const float* __restrict__ WS, const float* __restrict__ Z, int lane_in,
                                               int n0, float (&P)[NT][3 * CP / 4]) {
     using K = WCfg<CP>;
-    const float* const Z = PWR + K::PW_Z;
     int lane = lane_in;
     asm volatile("" : "+v"(lane));  // per pass: re-read the 27 taps from LDS instead of holding 4x28 registers
     const float* const WPL = WS + K::OFF_WP;
@@ -340,12 +356,19 @@ __device__ __forceinline__ void perceive_tile(const float* __restrict__ WS, cons
             wt[4 * j4 + 0] = w4[0]; wt[4 * j4 + 1] = w4[1]; wt[4 * j4 + 2] = w4[2]; wt[4 * j4 + 3] = w4[3];
         }
         static_assert(NT == 2, "row pairs: one v_pk_fma_f32 serves output rows n0 and n0+1");
-        // tap (dy,dx) of output rows (n0, n0+1) reads tile rows (dy, dy+1): one ds_read2_b32 -> an aligned pair
+        // tap (dy,dx) of output rows (n0, n0+1) reads tile rows (dy, dy+1): ONE ds_read2_b32 lands them in an aligned
+        // register pair (the compiler otherwise assembles the pairs with v_mov's).  Inline-asm loads are not counted by
+        // hipcc, so they are waited for explicitly before use (guide 5.7, form (ii)).
+        const unsigned za = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)zc;
         f32x2 nb[9];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) nb[3 * dy + dx] = f32x2{zc[dy * RS + dx], zc[(dy + 1) * RS + dx]};
+#define NCA_RD2(i, o) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(nb[i]) : "v"(za), "n"(o), "n"((o) + RS))
+        NCA_RD2(0, 0); NCA_RD2(1, 1); NCA_RD2(2, 2);
+        NCA_RD2(3, RS); NCA_RD2(4, RS + 1); NCA_RD2(5, RS + 2);
+        NCA_RD2(6, 2 * RS); NCA_RD2(7, 2 * RS + 1); NCA_RD2(8, 2 * RS + 2);
+#undef NCA_RD2
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(nb[0]), "+v"(nb[1]), "+v"(nb[2]), "+v"(nb[3]), "+v"(nb[4]), "+v"(nb[5]), "+v"(nb[6]), "+v"(nb[7]), "+v"(nb[8])
+                     :: "memory");
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
             f32x2 acc = {0.0f, 0.0f};
@@ -354,10 +377,122 @@ __device__ __forceinline__ void perceive_tile(const float* __restrict__ WS, cons
             P[0][3 * c4 + f] = acc[0];
             P[1][3 * c4 + f] = acc[1];
         }
+        __builtin_amdgcn_sched_barrier(0);  // one channel group's 27 taps live at a time (else hipcc hoists all 4 x 28)
     }
 }
 
+// relu as ONE integer max on the bit pattern (sign bit set <=> negative int): no NaN-canonicalising pre-pass.
+__device__ __forceinline__ float relu(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
 
-__device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_huge_valf()); }
+// UpdateNet (nca.py:40-46) 3C -> 64 -> 64 -> C on v_mfma_f32_16x16x4_f32 for rows n0..n0+NT-1, then
+// x' = x + mask * out (nca.py:189) written back in place into the resolved-state copy XR.
+template <int CP, int NT>
+__device__ __forceinline__ void mlp_tile(const NcaCondArgs& a, const float* __restrict__ WS, float* __restrict__ XR,
+                                         const float* __restrict__ MK, int lane_in, int n0,
+                                         const float (&P)[NT][3 * CP / 4]) {
+    using K = WCfg<CP>;
+    int lane_o = lane_in;
+    asm volatile("" : "+v"(lane_o));  // nothing below is hoisted out of the tile loop and kept live through staging
+    // A-operand images in 16-byte form: element ((tile*S4 + s4)*64 + lane)*4 + j  <->  k-step 4*s4 + j
+    const f32x4* const W1V = reinterpret_cast<const f32x4*>(WS + K::OFF_W1) + lane_o;   // [4 m][K1S4][64]
+    const f32x4* const W2V = reinterpret_cast<const f32x4*>(WS + K::OFF_W2) + lane_o;   // [4 m2][4 m][64] (j = r)
+    const f32x4* const W3V = reinterpret_cast<const f32x4*>(WS + K::OFF_W3) + lane_o;   // [M3T][4 m][64]
+    const float* const B1L = WS + K::OFF_B1;
+    const float* const B2L = WS + K::OFF_B2;
+    const int g = lane_o >> 4, ci = lane_o & 15;
+    f32x4 acc2[4][NT];
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2) {
+        const f32x4 bias = ld4(B2L + 16 * m2 + 4 * g);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc2[m2][n] = bias;
+    }
+    // layer-1 operands of hidden tile m+1 are fetched while tile m computes; layer-2 operands of tile m are fetched
+    // at the top of tile m (its layer-1 chain covers their latency); layer-3 operands during the last tile
+    f32x4 a1[K::K1S4], a3[K::M3T][4];
+#pragma unroll
+    for (int q = 0; q < K::K1S4; ++q) a1[q] = W1V[q * 64];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f32x4 a1n[K::K1S4], a2[4];
+#pragma unroll
+        for (int m2 = 0; m2 < 4; ++m2) a2[m2] = W2V[(m2 * 4 + m) * 64];
+        if (m < 3) {
+#pragma unroll
+            for (int q = 0; q < K::K1S4; ++q) a1n[q] = W1V[((m + 1) * K::K1S4 + q) * 64];
+        } else {
+#pragma unroll
+            for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) a3[m3][mm] = W3V[(m3 * 4 + mm) * 64];
+        }
+        const f32x4 bias = ld4(B1L + 16 * m + 4 * g);
+        f32x4 acc1[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc1[n] = bias;
+#pragma unroll
+        for (int s = 0; s < K::K1S; ++s)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc1[n] = nca_mfma(a1[s >> 2][s & 3], P[n][s], acc1[n]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m2 = 0; m2 < 4; ++m2)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc2[m2][n] = nca_mfma(a2[m2][r], relu(acc1[n][r]), acc2[m2][n]);
+        if (m < 3) {
+#pragma unroll
+            for (int q = 0; q < K::K1S4; ++q) a1[q] = a1n[q];
+        }
+    }
+    f32x4 acc3[K::M3T][NT];
+#pragma unroll
+    for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc3[m3][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // out.4 has no bias
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc3[m3][n] = nca_mfma(a3[m3][m][r], relu(acc2[m][n][r]), acc3[m3][n]);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const float mk = MK[(n0 + n) * WTW + ci];
+#pragma unroll
+        for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = 16 * m3 + 4 * g + r;
+                if (ch < CP) {  // same lane reads and rewrites the element: in place
+                    float* const p = XR + ch * XRS + (n0 + n) * WTW + ci;
+                    *p = fmaf(mk, acc3[m3][n][r], *p);
+                }
+            }
+    }
+}
+
+// Pending state out: 16-byte stores, 4 per lane (item k -> channel 4k+q4, row (lane>>2)&3, group lane&3).
+template <int CP, bool CHECK>
+__device__ __forceinline__ void store_tile(const NcaCondArgs& a, const WTile& t, const float* __restrict__ XR, int lane_in) {
+    const int C = a.C, H = a.H, W = a.W;
+    const unsigned plane = (unsigned)(H * W);
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int q4 = lane >> 4, row = (lane >> 2) & 3, ff = lane & 3;
+    const int gy = t.ty0 + row, gx = t.tx0 + 4 * ff;
+    const bool ok = !CHECK || (gy < H && gx + 3 < W);
+    float* const ob = a.x_out + (size_t)t.b * C * plane + (ok ? (unsigned)(gy * W + gx) : 0u);
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < CP / 4; ++k) {
+        const int ch = 4 * k + q4;
+        const f32x4 v = ld4(XR + ch * XRS + row * WTW + 4 * ff);
+        if (ok && ch < C) st4(ob + (unsigned)ch * plane, v);
+    }
+}
+
 
 }  // namespace

@@ -15,106 +15,6 @@
 
 namespace {
 
-// UpdateNet (nca.py:40-46) 3C -> 64 -> 64 -> C on v_mfma_f32_16x16x4_f32 for rows n0..n0+NT-1, then
-// x' = x + mask * out (nca.py:189) written back in place into the resolved-state copy XR.
-template <int CP, int NT>
-__device__ __forceinline__ void mlp_tile(const NcaCondArgs& a, const float* __restrict__ WS, float* __restrict__ PWR,
-                                         int lane_in, int n0, const float (&P)[NT][3 * CP / 4]) {
-    using K = WCfg<CP>;
-    const float* const W1L = WS + K::OFF_W1;
-    const float* const W2L = WS + K::OFF_W2;
-    const float* const W3L = WS + K::OFF_W3;
-    const float* const B1L = WS + K::OFF_B1;
-    const float* const B2L = WS + K::OFF_B2;
-    float* const XR = PWR + K::PW_XR;
-    const float* const MK = PWR + K::PW_A3 + ZROWS * RS;
-    const int g = lane_in >> 4, ci = lane_in & 15;
-    f32x4 acc2[4][NT];
-#pragma unroll
-    for (int m2 = 0; m2 < 4; ++m2) {
-        const f32x4 bias = ld4(B2L + 16 * m2 + 4 * g);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc2[m2][n] = bias;
-    }
-#pragma unroll 1
-    for (int m = 0; m < 4; ++m) {
-        const float* const w1m = W1L + m * K::K1S * 64 + lane_in;
-        const f32x4 bias = ld4(B1L + 16 * m + 4 * g);
-        f32x4 acc1[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc1[n] = bias;
-#pragma unroll
-        for (int s = 0; s < K::K1S; ++s) {
-            const float wa = w1m[s * 64];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc1[n] = nca_mfma(wa, P[n][s], acc1[n]);
-        }
-        const float* const w2m = W2L + (4 * m) * 64 + lane_in;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int m2 = 0; m2 < 4; ++m2) {
-                const float wa = w2m[(m2 * 16 + r) * 64];
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc2[m2][n] = nca_mfma(wa, relu(acc1[n][r]), acc2[m2][n]);
-            }
-        }
-    }
-    f32x4 acc3[K::M3T][NT];
-#pragma unroll
-    for (int m3 = 0; m3 < K::M3T; ++m3)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc3[m3][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // out.4 has no bias
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int m3 = 0; m3 < K::M3T; ++m3) {
-                const float wa = W3L[(m3 * 16 + 4 * m + r) * 64 + lane_in];
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc3[m3][n] = nca_mfma(wa, relu(acc2[m][n][r]), acc3[m3][n]);
-            }
-        }
-    }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const float mk = MK[(n0 + n) * WTW + ci];
-#pragma unroll
-        for (int m3 = 0; m3 < K::M3T; ++m3)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ch = 16 * m3 + 4 * g + r;
-                if (ch < CP) {  // same lane reads and rewrites the element: in place
-                    float* const p = XR + ch * XRS + (n0 + n) * WTW + ci;
-                    *p = fmaf(mk, acc3[m3][n][r], *p);
-                }
-            }
-    }
-}
-
-// Pending state out: 16-byte stores, 4 per lane (item k -> channel 4k+q4, row (lane>>2)&3, group lane&3).
-template <int CP, bool CHECK>
-__device__ __forceinline__ void store_tile(const NcaCondArgs& a, const WTile& t, const float* __restrict__ PWR, int lane_in) {
-    using K = WCfg<CP>;
-    const float* const XR = PWR + K::PW_XR;
-    const int C = a.C, H = a.H, W = a.W;
-    const unsigned plane = (unsigned)(H * W);
-    int lane = lane_in;
-    asm volatile("" : "+v"(lane));
-    const int q4 = lane >> 4, row = (lane >> 2) & 3, ff = lane & 3;
-    const int gy = t.ty0 + row, gx = t.tx0 + 4 * ff;
-    const bool ok = !CHECK || (gy < H && gx + 3 < W);
-    float* const ob = a.x_out + (size_t)t.b * C * plane + (ok ? (unsigned)(gy * W + gx) : 0u);
-    wave_sync();
-#pragma unroll
-    for (int k = 0; k < CP / 4; ++k) {
-        const int ch = 4 * k + q4;
-        const f32x4 v = ld4(XR + ch * XRS + row * WTW + 4 * ff);
-        if (ok && ch < C) st4(ob + (unsigned)ch * plane, v);
-    }
-}
-
 template <int CP>
 __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_wave_kernel(const NcaCondArgs a) {
     using K = WCfg<CP>;
@@ -147,22 +47,23 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_wave_kernel(const 
     TileRegs<CP> R;
     if (cur.valid) issue_loads<CP, true, false>(a, cur, lane, R);  // first tile's loads fly while the weight image is built
 
-    fill_image_w<4 * K::K1S * 64>(smem + K::OFF_W1, a.w1, tid, [&](int idx) -> long {
-        const int l = idx & 63, s = (idx >> 6) % K::K1S, m = (idx >> 6) / K::K1S;
-        const int gg = l >> 4, o = 16 * m + (l & 15);
+    // 16-byte A-operand images: element ((tile*S4 + s4)*64 + lane)*4 + j holds the weight of k-step s = 4*s4 + j
+    fill_image_w<4 * K::K1S4 * 256>(smem + K::OFF_W1, a.w1, tid, [&](int idx) -> long {
+        const int j = idx & 3, l = (idx >> 2) & 63, q = (idx >> 8) % K::K1S4, m = (idx >> 8) / K::K1S4;
+        const int s = 4 * q + j, gg = l >> 4, o = 16 * m + (l & 15);
         const int ch = 4 * (s / 3) + gg, f = s % 3;  // k-step s = 3c'+f : channel 4c'+g, filter f
-        return (ch < C && o < hid) ? (long)o * K1 + 3 * ch + f : -1;  // out[3c+f], nca.py:99-107
+        return (s < K::K1S && ch < C && o < hid) ? (long)o * K1 + 3 * ch + f : -1;  // out[3c+f], nca.py:99-107
     });
     fill_image_w<4 * 16 * 64>(smem + K::OFF_W2, a.w2, tid, [&](int idx) -> long {
-        const int l = idx & 63, s = (idx >> 6) % 16, m = (idx >> 6) / 16;
-        const int gg = l >> 4, o = 16 * m + (l & 15);
-        const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
+        const int r = idx & 3, l = (idx >> 2) & 63, m = (idx >> 8) & 3, m2 = idx >> 10;   // [m2][m][lane][r]
+        const int gg = l >> 4, o = 16 * m2 + (l & 15);
+        const int k = 16 * m + 4 * gg + r;                                                // k-step 4m+r of tile m2
         return (o < hid && k < hid) ? (long)o * hid + k : -1;
     });
     fill_image_w<K::M3T * 16 * 64>(smem + K::OFF_W3, a.w3, tid, [&](int idx) -> long {
-        const int l = idx & 63, s = (idx >> 6) % 16, m = (idx >> 6) / 16;
-        const int gg = l >> 4, o = 16 * m + (l & 15);
-        const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
+        const int r = idx & 3, l = (idx >> 2) & 63, m = (idx >> 8) & 3, m3 = idx >> 10;   // [m3][m][lane][r]
+        const int gg = l >> 4, o = 16 * m3 + (l & 15);
+        const int k = 16 * m + 4 * gg + r;
         return (o < C && k < hid) ? (long)o * hid + k : -1;
     });
     fill_image_w<K::HID>(smem + K::OFF_B1, a.b1, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
@@ -174,6 +75,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_wave_kernel(const 
     __syncthreads();  // the only workgroup barrier: weight image complete
 
     float* const PWR = smem + K::SHARED + wave * K::PW;
+    const TileLds L = wave_private_lds<CP>(PWR);
     int tile_no = 0;
     while (cur.valid) {
         // issue priority: the non-MFMA phases of a wave outrank its SIMD partner's MFMA chain (which only needs
@@ -181,30 +83,30 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_wave_kernel(const 
         __builtin_amdgcn_s_setprio(3);
         NCA_STAMP(0);
         issue_loads<CP, false, true>(a, cur, lane, R);  // goal encoding: consumed last in staging (S4)
-        if (cur.inner) stage_tile<CP, false>(a, cur, PWR, lane, R, tile_no);
-        else stage_tile<CP, true>(a, cur, PWR, lane, R, tile_no);
+        if (cur.inner) stage_tile<CP, false>(a, cur, L, lane, R, tile_no);
+        else stage_tile<CP, true>(a, cur, L, lane, R, tile_no);
         NCA_STAMP(1);
         const WTile nxt = next_tile();
         constexpr int NT = 2;  // rows per MFMA pass: 2 independent accumulator chains already pace the pipe
-#pragma unroll
+#pragma unroll 1
         for (int pass = 0; pass < WTH / NT; ++pass) {
             float P[NT][K::K1S];
-            perceive_tile<CP, NT>(smem, PWR, lane, pass * NT, P);
+            perceive_tile<CP, NT>(smem, L.Z, lane, pass * NT, P);
             if (pass == 0) {
                 NCA_STAMP(2);
                 if (nxt.valid) issue_loads<CP, true, false>(a, nxt, lane, R);  // in flight across this tile's MFMA chains
                 NCA_STAMP(3);
             }
             __builtin_amdgcn_s_setprio(0);
-            mlp_tile<CP, NT>(a, smem, PWR, lane, pass * NT, P);
+            mlp_tile<CP, NT>(a, smem, L.XR, L.MK, lane, pass * NT, P);
             __builtin_amdgcn_s_setprio(3);
         }
         // The prefetch was issued a whole MFMA chain ago; telling the compiler so (an s_waitcnt it can see) keeps it
         // from draining the goal loads of the next tile at that tile's first use of a prefetched register.
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
         NCA_STAMP(4);
-        if (cur.inner) store_tile<CP, false>(a, cur, PWR, lane);
-        else store_tile<CP, true>(a, cur, PWR, lane);
+        if (cur.inner) store_tile<CP, false>(a, cur, L.XR, lane);
+        else store_tile<CP, true>(a, cur, L.XR, lane);
         NCA_STAMP(5);
         cur = nxt;
         ++tile_no;

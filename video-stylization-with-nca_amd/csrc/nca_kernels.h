@@ -64,6 +64,9 @@ hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st);
 hipError_t nca_launch_dynca_step_bwd(const NcaDyncaArgs& a, hipStream_t st);
 // wave-private-tile variant (nca_cond_wave.hip); needs W % 4 == 0 and 16-byte aligned x_in / goal
 hipError_t nca_launch_cond_step_fwd_wave(const NcaCondArgs& a, hipStream_t st);
+// producer/consumer wave-specialised variant (nca_cond_pc.hip); same preconditions
+hipError_t nca_launch_cond_step_fwd_pc(const NcaCondArgs& a, hipStream_t st);
+void nca_set_cond_variant(int v);  // 0 = producer/consumer (default), 1 = symmetric wave-private
 
 // diagnostic build hook (-DNCA_STAMPS): buffer that receives s_memtime stamps, [wave][tile][8]
 void nca_debug_set_stamp_buffer(unsigned long long* p);

@@ -929,7 +929,9 @@ hipError_t launch_cond(const NcaCondArgs& a, hipStream_t st) {
 }  // namespace
 
 static bool g_force_generic = getenv("NCAHIP_FORCE_GENERIC") != nullptr;
+static int g_cond_variant = getenv("NCAHIP_COND_VARIANT") ? atoi(getenv("NCAHIP_COND_VARIANT")) : 0;
 void nca_set_force_generic(bool on) { g_force_generic = on; }
+void nca_set_cond_variant(int v) { g_cond_variant = v; }
 
 // ---- dispatch: smallest instantiation that covers (C, fc); padding lanes carry zero weights ---
 hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st) {
@@ -952,7 +954,7 @@ hipError_t nca_launch_dynca_step_bwd(const NcaDyncaArgs& a, hipStream_t st) {
 
 hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st) {
     if (!g_force_generic && a.C <= 16 && (a.W % 4 == 0) && aligned16(a.x_in) && (a.goal == nullptr || aligned16(a.goal)))
-        return nca_launch_cond_step_fwd_wave(a, st);
+        return g_cond_variant == 1 ? nca_launch_cond_step_fwd_wave(a, st) : nca_launch_cond_step_fwd_pc(a, st);
     if (a.C <= 12) return launch_cond<12>(a, st);
     if (a.C <= 16) return launch_cond<16>(a, st);
     return hipErrorInvalidValue;

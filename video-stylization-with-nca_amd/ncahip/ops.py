@@ -33,9 +33,10 @@ def _w(t: torch.Tensor, name: str, like: torch.Tensor) -> torch.Tensor:
     return _dev(t.float(), name)
 
 
-def force_generic(on: bool) -> None:
-    """Test hook: route fused steps through the generic any-shape kernels (see ncahip.h)."""
-    lib().ncahip_debug_force_generic(1 if on else 0)
+def force_generic(on) -> None:
+    """Test hook (see ncahip.h): True/1 = generic any-shape kernels, 2 = symmetric wave-private ConditionedNCA
+    kernel, False/0 = defaults."""
+    lib().ncahip_debug_force_generic(int(on))
 
 
 def selftest(device=None) -> None:
