@@ -34,5 +34,29 @@ def run(B, T, H=256, W=256, C=16, iters=3):
                       "fwd_Gcells_s": cells / tf / 1e6, "fwd_bwd_Gcells_s": cells / (tf + tb) / 1e6,
                       "bwd_over_fwd": tb / tf}))
 
-run(8, 32)
-run(32, 16)
+pass
+pass
+
+
+def run_dynca(B=8, C=16, fc=128, cc=3, H=256, W=256, T=32, pad="circular"):
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(0)
+    k1 = 4 * C + cc
+    w = ops.DyncaWeights(torch.randn(fc, k1, generator=gen) * (0.5 / k1 ** 0.5), torch.randn(fc, generator=gen) * 0.1,
+                         torch.randn(C, fc, generator=gen) * (0.02 / fc ** 0.5), torch.zeros(C), torch.zeros(1, device=dev))
+    x = (torch.rand(B, C, H, W, generator=gen) - 0.5).to(dev)
+    cond = (torch.rand(B, cc, H, W, generator=gen) * 2 - 1).to(dev) if cc else None
+    ops.dynca_nsteps(x, T, cond, None, w, pad, 0.5, seed=1)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        ops.dynca_nsteps(x, T, cond, None, w, pad, 0.5, seed=1)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    flops = 2 * (27 * C + fc * (5 * C + cc))
+    print(json.dumps({"dynca": True, "B": B, "C": C, "fc": fc, "us_per_step": ms / T * 1e3, "Gcells_s": B * H * W * T / ms / 1e6,
+                      "TFLOPs": B * H * W * T * flops / ms / 1e9, "frac_f32_mfma": B * H * W * T * flops / ms / 1e9 / 157.3}))
+
+run_dynca()
+run_dynca(C=12, fc=96)

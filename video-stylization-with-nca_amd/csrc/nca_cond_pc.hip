@@ -28,40 +28,43 @@ struct PCfg {
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 
-template <int CP>
+template <int CP, bool EXACT>
 __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const NcaCondArgs a) {
     using K = WCfg<CP>;
     using PK = PCfg<CP>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int C = a.C, H = a.H, W = a.W, hid = a.hidden, K1 = 3 * C;
+    const int C = EXACT ? CP : a.C, H = a.H, W = a.W, hid = EXACT ? 64 : a.hidden, K1 = 3 * C;
     const bool producer = wave >= 4;
     const int pair = wave & 3;
 
-    // 16-byte A-operand images (same layouts as nca_cond_wave.hip)
-    fill_image_w<4 * K::K1S4 * 256>(smem + K::OFF_W1, a.w1, tid, [&](int idx) -> long {
+    // 16-byte A-operand images (same layouts as nca_cond_wave.hip), built by the four consumer waves while the
+    // producers already stage the first tile
+    if (!producer) {
+    fill_image_w<4 * K::K1S4 * 256, 256>(smem + K::OFF_W1, a.w1, tid, [&](int idx) -> long {
         const int j = idx & 3, l = (idx >> 2) & 63, q = (idx >> 8) % K::K1S4, m = (idx >> 8) / K::K1S4;
         const int s = 4 * q + j, gg = l >> 4, o = 16 * m + (l & 15);
         const int ch = 4 * (s / 3) + gg, f = s % 3;
         return (s < K::K1S && ch < C && o < hid) ? (long)o * K1 + 3 * ch + f : -1;
     });
-    fill_image_w<4 * 16 * 64>(smem + K::OFF_W2, a.w2, tid, [&](int idx) -> long {
+    fill_image_w<4 * 16 * 64, 256>(smem + K::OFF_W2, a.w2, tid, [&](int idx) -> long {
         const int r = idx & 3, l = (idx >> 2) & 63, m = (idx >> 8) & 3, m2 = idx >> 10;
         const int gg = l >> 4, o = 16 * m2 + (l & 15), k = 16 * m + 4 * gg + r;
         return (o < hid && k < hid) ? (long)o * hid + k : -1;
     });
-    fill_image_w<K::M3T * 16 * 64>(smem + K::OFF_W3, a.w3, tid, [&](int idx) -> long {
+    fill_image_w<K::M3T * 16 * 64, 256>(smem + K::OFF_W3, a.w3, tid, [&](int idx) -> long {
         const int r = idx & 3, l = (idx >> 2) & 63, m = (idx >> 8) & 3, m3 = idx >> 10;
         const int gg = l >> 4, o = 16 * m3 + (l & 15), k = 16 * m + 4 * gg + r;
         return (o < C && k < hid) ? (long)o * hid + k : -1;
     });
-    fill_image_w<K::HID>(smem + K::OFF_B1, a.b1, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
-    fill_image_w<K::HID>(smem + K::OFF_B2, a.b2, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
-    fill_image_w<CP * K::WPS>(smem + K::OFF_WP, a.wp, tid, [&](int idx) -> long {
+    fill_image_w<K::HID, 256>(smem + K::OFF_B1, a.b1, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
+    fill_image_w<K::HID, 256>(smem + K::OFF_B2, a.b2, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
+    fill_image_w<CP * K::WPS, 256>(smem + K::OFF_WP, a.wp, tid, [&](int idx) -> long {
         const int ch = idx / K::WPS, j = idx % K::WPS;
         return (ch < C && j < 27) ? (long)ch * 27 + j : -1;
     });
+    }
 
     float* const PR = smem + K::SHARED + pair * PK::PAIR;
     auto lds_of = [&](int which) -> TileLds {
@@ -75,24 +78,44 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
     const int st_x = (W + PSTW - 1) / PSTW, st_y = (H + PSTH - 1) / PSTH;
     const int halo = a.alive_ch >= 0 ? 3 : 1;
     NcaTileWalk tw = nca_tile_walk(a.B * st_x * st_y);
-    auto tile_at = [&](int t) -> WTile {
+    // super-tile coordinates advance incrementally (no integer division per tile)
+    struct Pos { int t, sx, sy, b; };
+    auto advance = [&](Pos p) -> Pos {
+        p.t += tw.stride;
+        p.sx += tw.stride;
+        while (p.sx >= st_x) {
+            p.sx -= st_x;
+            if (++p.sy == st_y) { p.sy = 0; ++p.b; }
+        }
+        return p;
+    };
+    auto tile_of = [&](const Pos& p) -> WTile {
         WTile w{0, 0, 0, false, false};
-        if (t < tw.end) {
-            w.b = t / (st_x * st_y);
-            w.ty0 = ((t / st_x) % st_y) * PSTH + pair * WTH;
-            w.tx0 = (t % st_x) * PSTW;
+        if (p.t < tw.end) {
+            w.b = p.b;
+            w.ty0 = p.sy * PSTH + pair * WTH;
+            w.tx0 = p.sx * PSTW;
             w.valid = w.ty0 < H && w.tx0 < W;
             w.inner = w.ty0 >= halo && w.ty0 + WTH + halo <= H && w.tx0 >= halo && w.tx0 + WTW + halo <= W;
         }
         return w;
     };
+    int tile_no = 0;
     auto produce = [&](const WTile& t, int which) {
         if (!t.valid) return;
         TileRegs<CP> R;
-        issue_loads<CP, true, true>(a, t, lane, R);
         const TileLds L = lds_of(which);
-        if (t.inner) stage_tile<CP, false>(a, t, L, lane, R, 0);
-        else stage_tile<CP, true>(a, t, L, lane, R, 0);
+        NCA_STAMP(4);
+        if (t.inner) {
+            issue_loads<CP, true, true, 0, EXACT>(a, t, lane, R);
+            NCA_STAMP(5);
+            stage_tile<CP, false, EXACT>(a, t, L, lane, R, tile_no);
+        } else {
+            issue_loads<CP, true, true, 1, EXACT>(a, t, lane, R);
+            NCA_STAMP(5);
+            stage_tile<CP, true, EXACT>(a, t, L, lane, R, tile_no);
+        }
+        NCA_STAMP(6);
     };
     auto consume = [&](const WTile& t, int which) {
         if (!t.valid) return;
@@ -101,33 +124,47 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
 #pragma unroll 1
         for (int pass = 0; pass < WTH / NT; ++pass) {
             float P[NT][K::K1S];
+            if (pass == 0) NCA_STAMP(4);
             perceive_tile<CP, NT>(smem, L.Z, lane, pass * NT, P);
+            if (pass == 0) NCA_STAMP(5);
             mlp_tile<CP, NT>(a, smem, L.XR, L.MK, lane, pass * NT, P);
+            if (pass == 0) NCA_STAMP(6);
         }
-        if (t.inner) store_tile<CP, false>(a, t, L.XR, lane);
-        else store_tile<CP, true>(a, t, L.XR, lane);
+        NCA_STAMP(7);
+        if (t.inner) store_tile<CP, false, EXACT>(a, t, L.XR, lane);
+        else store_tile<CP, true, EXACT>(a, t, L.XR, lane);
+        NCA_STAMP(8);
     };
 
-    int t = tw.t, which = 0;
-    WTile cur = tile_at(t);
+    int which = 0;
+    Pos pos{tw.t, tw.t % st_x, (tw.t / st_x) % st_y, tw.t / (st_x * st_y)};   // one division per kernel
+    WTile cur = tile_of(pos);
+    // At equal priority the (older) consumer waves win every arbitration and the producer only issues in the gaps of
+    // their MFMA stream -- it becomes the long pole and the consumers idle at the barrier.  Its instructions are few:
+    // let them go first.
+    if (producer) __builtin_amdgcn_s_setprio(3);
     if (producer) produce(cur, 0);   // overlaps the tail of the weight-image fill of the other waves
     __syncthreads();                  // weight image + first tile ready
-    while (t < tw.end) {              // uniform over the workgroup
-        const int tn = t + tw.stride;
-        const WTile nxt = tile_at(tn);
+    while (pos.t < tw.end) {          // uniform over the workgroup
+        const Pos pn = advance(pos);
+        const WTile nxt = tile_of(pn);
+        NCA_STAMP(0);
         if (producer) produce(nxt, which ^ 1);
         else consume(cur, which);
+        NCA_STAMP(1);
         __syncthreads();              // tile buffers change hands
+        NCA_STAMP(2);
         cur = nxt;
-        t = tn;
+        pos = pn;
         which ^= 1;
+        ++tile_no;
     }
 }
 
-template <int CP>
+template <int CP, bool EXACT>
 hipError_t launch_cond_pc(const NcaCondArgs& a, hipStream_t st) {
     using PK = PCfg<CP>;
-    auto kern = cond_step_fwd_pc_kernel<CP>;
+    auto kern = cond_step_fwd_pc_kernel<CP, EXACT>;
     const size_t lds = (size_t)PK::LDS_FLOATS * sizeof(float);
     static thread_local bool attr_done = false;
     if (!attr_done) {
@@ -152,8 +189,16 @@ hipError_t launch_cond_pc(const NcaCondArgs& a, hipStream_t st) {
 }  // namespace
 
 // W % 4 == 0 and 16-byte aligned x_in / goal: caller (nca_step_fwd.hip dispatch) guarantees it.
-hipError_t nca_launch_cond_step_fwd_pc(const NcaCondArgs& a, hipStream_t st) {
-    if (a.C <= 12) return launch_cond_pc<12>(a, st);
-    if (a.C <= 16) return launch_cond_pc<16>(a, st);
+extern "C" void nca_debug_set_stamp_buffer_pc(void* p);
+static unsigned long long* g_stamp_pc = nullptr;
+extern "C" void nca_debug_set_stamp_buffer_pc(void* p) { g_stamp_pc = (unsigned long long*)p; }
+hipError_t nca_launch_cond_step_fwd_pc(const NcaCondArgs& a_in, hipStream_t st) {
+    NcaCondArgs a = a_in;
+    a.dbg = g_stamp_pc;
+    const bool h64 = a.hidden == 64;
+    if (a.C == 12 && h64) return launch_cond_pc<12, true>(a, st);
+    if (a.C == 16 && h64) return launch_cond_pc<16, true>(a, st);
+    if (a.C <= 12) return launch_cond_pc<12, false>(a, st);
+    if (a.C <= 16) return launch_cond_pc<16, false>(a, st);
     return hipErrorInvalidValue;
 }

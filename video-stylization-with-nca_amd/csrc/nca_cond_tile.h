@@ -46,7 +46,7 @@ struct WCfg {
 
 #ifdef NCA_STAMPS
 // Diagnostic build only: phase stamps per wave tile -> a.dbg[((wg*8+wave)*kStampTiles + tile)*16 + i].
-constexpr int kStampTiles = 8;
+constexpr int kStampTiles = 8;  // stamped tiles per wave (buffer: [wg*8+wave][kStampTiles][16])
 #define NCA_STAMP(i)                                                                                   \
     do {                                                                                               \
         if (a.dbg && tile_no < kStampTiles) {                                                          \
@@ -140,9 +140,11 @@ struct TileRegs {
 //   pre    halo 2 : item k -> row 2k+hl (<8),  col l5 (<20)      image (ty0-2+row, tx0-2+col)
 //   interior f4   : item k -> channel 2k+hl, slot l5 (<24): halo-1 row l5>>2, 4-cell group l5&3
 //   halo columns  : item k -> channel 4k+q4, slot ci (<12): halo-1 row ci>>1, side ci&1
-template <int CP, bool STATE, bool GOAL>
+// CHK: -1 = decide from t.inner at run time, 0 = interior tile (no bounds logic), 1 = border tile.
+// EXACT: the launch guarantees a.C == CP (no channel-padding guards).
+template <int CP, bool STATE, bool GOAL, int CHK = -1, bool EXACT = false>
 __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t, int lane_in, TileRegs<CP>& R) {
-    const int C = a.C, H = a.H, W = a.W;
+    const int C = EXACT ? CP : a.C, H = a.H, W = a.W;
     const unsigned plane = (unsigned)(H * W);
     const int gch0 = C - a.goal_ch;
     const bool pending = a.pre_in != nullptr, use_alive = a.alive_ch >= 0, has_goal = a.goal_ch > 0;
@@ -152,7 +154,7 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     const int hl = lane >> 5, l5 = lane & 31, q4 = lane >> 4, ci = lane & 15;
-    const bool chk = !t.inner;
+    const bool chk = CHK < 0 ? !t.inner : (CHK != 0);
     if (STATE && use_alive) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
@@ -209,7 +211,7 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
 
 // Resolve the pending life mask, build z = x + goal*pre in LDS (halo 1), keep the resolved state for
 // the residual.  CHECK=false: no bounds logic.
-template <int CP, bool CHECK>
+template <int CP, bool CHECK, bool EXACT = false>
 __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t, const TileLds& L, int lane_in,
                                            const TileRegs<CP>& R, int tile_no) {
     float* const Z = L.Z;
@@ -220,7 +222,7 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
     float* const A2 = L.A2;
     float* const MK = L.MK;
 
-    const int C = a.C, H = a.H, W = a.W;
+    const int C = EXACT ? CP : a.C, H = a.H, W = a.W;
     const unsigned plane = (unsigned)(H * W);
     const int gch0 = C - a.goal_ch, ty0 = t.ty0, tx0 = t.tx0;
     const bool pending = a.pre_in != nullptr, use_alive = a.alive_ch >= 0, has_goal = a.goal_ch > 0;
@@ -475,9 +477,9 @@ __device__ __forceinline__ void mlp_tile(const NcaCondArgs& a, const float* __re
 }
 
 // Pending state out: 16-byte stores, 4 per lane (item k -> channel 4k+q4, row (lane>>2)&3, group lane&3).
-template <int CP, bool CHECK>
+template <int CP, bool CHECK, bool EXACT = false>
 __device__ __forceinline__ void store_tile(const NcaCondArgs& a, const WTile& t, const float* __restrict__ XR, int lane_in) {
-    const int C = a.C, H = a.H, W = a.W;
+    const int C = EXACT ? CP : a.C, H = a.H, W = a.W;
     const unsigned plane = (unsigned)(H * W);
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
