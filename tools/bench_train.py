@@ -34,8 +34,7 @@ def run(B, T, H=256, W=256, C=16, iters=3):
                       "fwd_Gcells_s": cells / tf / 1e6, "fwd_bwd_Gcells_s": cells / (tf + tb) / 1e6,
                       "bwd_over_fwd": tb / tf}))
 
-pass
-pass
+run(8, 16)
 
 
 def run_dynca(B=8, C=16, fc=128, cc=3, H=256, W=256, T=32, pad="circular"):

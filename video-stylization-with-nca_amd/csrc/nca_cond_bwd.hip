@@ -19,7 +19,7 @@
 namespace {
 
 constexpr int kBwdWaves = 4, kBwdThreads = 256;
-constexpr int TBS = 18;  // transposition buffer row stride: bank(18*i + g) distinct over a 32-lane half
+constexpr int TBS = 148;  // transposition buffer: [16 cells][TBS rows]; 148 % 32 == 20 -> conflict-free ds_write_b128 per cell
 
 template <int CP>
 struct BCfg {
@@ -29,8 +29,8 @@ struct BCfg {
     static constexpr int OFF_W3T = F::SHARED;               // [4 m][4 s][64]
     static constexpr int OFF_W1T = OFF_W3T + 4 * 4 * 64;    // [MJ][16 s][64]
     static constexpr int SHARED = OFF_W1T + MJ * 16 * 64;
-    static constexpr int PW_TB = F::PW;                     // 128 rows x 18
-    static constexpr int PW_A1 = PW_TB + 128 * TBS;         // alpha'_t halo 1: 6 x RS
+    static constexpr int PW_TB = F::PW;                     // 16 cells x 148 (>= 128 activation rows)
+    static constexpr int PW_A1 = PW_TB + 16 * TBS;          // alpha'_t halo 1: 6 x RS
     static constexpr int PW = PW_A1 + ZROWS * RS;
     static constexpr int LDS_FLOATS = SHARED + kBwdWaves * PW;
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
@@ -303,66 +303,62 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
 #pragma unroll
                     for (int n = 0; n < NT; ++n) { db1[m][r] += d1[m][n][r]; db2[m][r] += d2[m][n][r]; }
 
-            // ---- weight gradients: per 16-cell tile, transpose through TB (rows = channel index, 16 cells) ----
+            // ---- weight gradients: per 16-cell tile, through the cell-major buffer TB[cell][row] ---------------------
+            //      lane (g,ci) writes its 4 accumulator rows of a tile with ONE 16-byte store; operand fragments
+            //      A[i][k=g] = TB[4s+g][rowA+i], B[k=g][j] = TB[4s+g][rowB+j] are 16 consecutive floats per lane group.
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
+                float* const tw_ = TB + ci * TBS + 4 * g;            // this lane's cell row, accumulator-row offset
+                const float* const tr_ = TB + g * TBS + ci;           // operand reads: cell 4s+g -> + 4*s*TBS
                 wave_sync();  // TB free (gradient tile consumed above / previous products done)
-                // dW3 = dO (16) x h2 (64):  rows 0..15 | 16..79
+                // dW3 = dO (rows 0..15) x h2 (rows 16..79)
+                st4(tw_, f32x4{dO[n][0], dO[n][1], dO[n][2], dO[n][3]});
 #pragma unroll
-                for (int r = 0; r < 4; ++r) TB[(4 * g + r) * TBS + ci] = dO[n][r];
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) TB[(16 + 16 * m + 4 * g + r) * TBS + ci] = h2[m][n][r];
+                for (int m = 0; m < 4; ++m) st4(tw_ + 16 + 16 * m, h2[m][n]);
                 wave_sync();
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const float av = TB[ci * TBS + 4 * s + g];
+                    const float av = tr_[4 * s * TBS];
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
-                        aW3[nb] = nca_mfma(av, TB[(16 + 16 * nb + ci) * TBS + 4 * s + g], aW3[nb]);
+                    for (int nb = 0; nb < 4; ++nb) aW3[nb] = nca_mfma(av, tr_[4 * s * TBS + 16 + 16 * nb], aW3[nb]);
                 }
                 wave_sync();
-                // dW2 = d2 (64) x h1 (64): rows 0..63 | 64..127
+                // dW2 = d2 (rows 0..63) x h1 (rows 64..127)
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        TB[(16 * m + 4 * g + r) * TBS + ci] = d2[m][n][r];
-                        TB[(64 + 16 * m + 4 * g + r) * TBS + ci] = h1[m][n][r];
-                    }
+                for (int m = 0; m < 4; ++m) {
+                    st4(tw_ + 16 * m, d2[m][n]);
+                    st4(tw_ + 64 + 16 * m, h1[m][n]);
+                }
                 wave_sync();
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     float bv[4];
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) bv[nb] = TB[(64 + 16 * nb + ci) * TBS + 4 * s + g];
+                    for (int nb = 0; nb < 4; ++nb) bv[nb] = tr_[4 * s * TBS + 64 + 16 * nb];
 #pragma unroll
                     for (int ma = 0; ma < 4; ++ma) {
-                        const float av = TB[(16 * ma + ci) * TBS + 4 * s + g];
+                        const float av = tr_[4 * s * TBS + 16 * ma];
 #pragma unroll
                         for (int nb = 0; nb < 4; ++nb) aW2[ma][nb] = nca_mfma(av, bv[nb], aW2[ma][nb]);
                     }
                 }
                 wave_sync();
-                // dW1 = d1 (64) x P (3C, natural index j = 3c+f): rows 0..63 | 64..64+16*MJ
+                // dW1 = d1 (rows 0..63) x P (rows 64.., natural perception index j = 3c+f)
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) TB[(16 * m + 4 * g + r) * TBS + ci] = d1[m][n][r];
+                for (int m = 0; m < 4; ++m) st4(tw_ + 16 * m, d1[m][n]);
 #pragma unroll
                 for (int c4 = 0; c4 < CP / 4; ++c4)
 #pragma unroll
-                    for (int f = 0; f < 3; ++f) TB[(64 + 3 * (4 * c4 + g) + f) * TBS + ci] = P[n][3 * c4 + f];
+                    for (int f = 0; f < 3; ++f) TB[ci * TBS + 64 + 3 * (4 * c4 + g) + f] = P[n][3 * c4 + f];
                 wave_sync();
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     float bv[K::MJ];
 #pragma unroll
-                    for (int nb = 0; nb < K::MJ; ++nb) bv[nb] = TB[(64 + 16 * nb + ci) * TBS + 4 * s + g];
+                    for (int nb = 0; nb < K::MJ; ++nb) bv[nb] = tr_[4 * s * TBS + 64 + 16 * nb];
 #pragma unroll
                     for (int ma = 0; ma < 4; ++ma) {
-                        const float av = TB[(16 * ma + ci) * TBS + 4 * s + g];
+                        const float av = tr_[4 * s * TBS + 16 * ma];
 #pragma unroll
                         for (int nb = 0; nb < K::MJ; ++nb) aW1[ma][nb] = nca_mfma(av, bv[nb], aW1[ma][nb]);
                     }
@@ -446,102 +442,118 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
 }
 
 // Kernel B: dL/ds_t = dL/dx'_t + stencil^T(dL/dP);  dL/dgoal += dz * pre_t;  perception-weight partials.
-// One thread = 4 W-contiguous cells of one (b, c, row); a block never spans two channels.
+// One thread = 4 W-contiguous cells x a strip of SROWS rows of one (b, c) plane, walked top to bottom with a
+// three-row sliding window held in registers: every row of z / dL/dP is loaded once per thread (16-byte loads,
+// left/right neighbours by wavefront shuffle with a scalar fallback at row/wave edges), and the 27 perception-weight
+// sums are reduced across the block once per strip.  A block never spans two channels.
+constexpr int SROWS = 8;
+struct Row6 { float v[6]; };   // columns x0-1 .. x0+4
+
+__device__ __forceinline__ Row6 load_row6(const float* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r) {
+    Row6 r;
+    const bool in = y >= 0 && y < H;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* row = plane + (size_t)(in ? y : 0) * W;
+    if (in) c = *reinterpret_cast<const float4*>(row + x0);
+    float l = __shfl_up(c.w, 1), rr = __shfl_down(c.x, 1);
+    if (!has_l) l = (in && x0 > 0) ? row[x0 - 1] : 0.0f;
+    if (!has_r) rr = (in && x0 + 4 < W) ? row[x0 + 4] : 0.0f;
+    r.v[0] = l; r.v[1] = c.x; r.v[2] = c.y; r.v[3] = c.z; r.v[4] = c.w; r.v[5] = rr;
+    return r;
+}
+
 __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCondBwdArgs ba) {
     const NcaCondArgs& a = ba.f;
     const int C = a.C, H = a.H, W = a.W;
     const size_t plane = (size_t)H * W;
-    const int W4 = (W + 3) / 4;
-    const int per_plane = H * W4, blocks_per_plane = (per_plane + 255) / 256;
+    const int W4 = W / 4, strips = (H + SROWS - 1) / SROWS;
+    const int per_plane = strips * W4, blocks_per_plane = (per_plane + 255) / 256;
     const int bc = blockIdx.x / blocks_per_plane, b = bc / C, c = bc % C;
     const int id = (blockIdx.x % blocks_per_plane) * 256 + threadIdx.x;
     const bool active = id < per_plane;
-    const int yy = active ? id / W4 : 0, x0 = active ? (id % W4) * 4 : 0;
-    const float* const wp = a.wp + (size_t)c * 27;
+    const int ida = active ? id : per_plane - 1;      // inactive lanes shadow the last item (they still shuffle)
+    const int x0 = (ida % W4) * 4, y0 = (ida / W4) * SROWS;
+    const int lane = threadIdx.x & 63;
+    const bool has_l = x0 > 0 && lane > 0, has_r = x0 + 4 < W && lane < 63 && id + 1 < per_plane;
     float wl[27];
 #pragma unroll
-    for (int i = 0; i < 27; ++i) wl[i] = wp[i];
-    const float* const dPb = ba.dP + ((size_t)b * 3 * C + 3 * c) * plane;
+    for (int i = 0; i < 27; ++i) wl[i] = a.wp[(size_t)c * 27 + i];
     const float* const zb = ba.zbuf + ((size_t)b * C + c) * plane;
-    float dz[4] = {0.f, 0.f, 0.f, 0.f}, wsum[27];
+    const float* const p0 = ba.dP + ((size_t)b * 3 * C + 3 * c) * plane;
+    float wsum[27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) wsum[i] = 0.f;
-    if (active) {
+    const int gch0 = C - a.goal_ch;
+    // window rows: index 0 = y-1, 1 = y, 2 = y+1
+    Row6 zw[3], pw[3][3];
+    zw[0] = load_row6(zb, H, W, y0 - 1, x0, has_l, has_r);
+    zw[1] = load_row6(zb, H, W, y0, x0, has_l, has_r);
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int sy = yy + dy - 1;
-            if (sy < 0 || sy >= H) continue;
-            float zrow[6], prow[3][6];
+    for (int f = 0; f < 3; ++f) {
+        pw[f][0] = load_row6(p0 + (size_t)f * plane, H, W, y0 - 1, x0, has_l, has_r);
+        pw[f][1] = load_row6(p0 + (size_t)f * plane, H, W, y0, x0, has_l, has_r);
+    }
+#pragma unroll 1
+    for (int k = 0; k < SROWS; ++k) {
+        const int y = y0 + k;
+        zw[2] = load_row6(zb, H, W, y + 1, x0, has_l, has_r);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int sx = x0 - 1 + j;
-                const bool in = sx >= 0 && sx < W;
-                zrow[j] = in ? zb[(size_t)sy * W + sx] : 0.0f;
-#pragma unroll
-                for (int f = 0; f < 3; ++f) prow[f][j] = in ? dPb[(size_t)f * plane + (size_t)sy * W + sx] : 0.0f;
-            }
-            // dz[q] += sum_f sum_dx Wp[f][2-dy'][2-dx] ... written as: source row sy = yy - (ty-1) -> ty = 1-(dy-1)
-            const int ty = 2 - dy;  // tap row of the forward filter that maps (sy) -> output row yy... transposed
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                    for (int f = 0; f < 3; ++f) dz[j] = fmaf(wl[9 * f + 3 * ty + (2 - dx)], prow[f][j + dx], dz[j]);
-            // perception-weight gradient: dWp[f][dy][dx] += dP[f][yy][x] * z[yy+dy-1][x+dx-1]; needs dP at (yy, x)
-            if (dy == 0) {}
-        }
-        // second sweep for dWp (dP at the centre row, z at the three rows)
-        float pc[3][4];
-#pragma unroll
-        for (int f = 0; f < 3; ++f)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pc[f][j] = (x0 + j < W) ? dPb[(size_t)f * plane + (size_t)yy * W + x0 + j] : 0.0f;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int sy = yy + dy - 1;
-            if (sy < 0 || sy >= H) continue;
-            float zrow[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int sx = x0 - 1 + j;
-                zrow[j] = (sx >= 0 && sx < W) ? zb[(size_t)sy * W + sx] : 0.0f;
-            }
+        for (int f = 0; f < 3; ++f) pw[f][2] = load_row6(p0 + (size_t)f * plane, H, W, y + 1, x0, has_l, has_r);
+        if (active && y < H) {
+            // dz[x] = sum_f sum_{ty,tx} Wp[f][ty][tx] * dP[f][y-(ty-1)][x-(tx-1)]      (transpose of the zero-padded correlation)
+            float dz[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int f = 0; f < 3; ++f)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
+                for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) wsum[9 * f + 3 * dy + dx] = fmaf(pc[f][j], zrow[j + dx], wsum[9 * f + 3 * dy + dx]);
-        }
-        const size_t off = (size_t)yy * W + x0;
-        const float* const gxp = ba.gx + ((size_t)b * C + c) * plane + off;
-        float* const go = ba.g_out + ((size_t)b * C + c) * plane + off;
-        const int gch0 = C - a.goal_ch;
+                    for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (x0 + j < W) {
-                go[j] = gxp[j] + dz[j];
-                if (c >= gch0) {
-                    const float pre = a.alive_ch >= 0 ? (float)ba.pre_t[(size_t)b * plane + off + j] : 1.0f;
-                    ba.dgoal[((size_t)b * a.goal_ch + (c - gch0)) * plane + off + j] += dz[j] * pre;
+                        for (int j = 0; j < 4; ++j)
+                            dz[j] = fmaf(wl[9 * f + 3 * ty + tx], pw[f][2 - ty].v[j + 2 - tx], dz[j]);
+            // dWp[f][ty][tx] += dP[f][y][x] * z[y+ty-1][x+tx-1]
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            wsum[9 * f + 3 * ty + tx] = fmaf(pw[f][1].v[j + 1], zw[ty].v[j + tx], wsum[9 * f + 3 * ty + tx]);
+            const size_t off = (size_t)y * W + x0;
+            const float4 gx = *reinterpret_cast<const float4*>(ba.gx + ((size_t)b * C + c) * plane + off);
+            *reinterpret_cast<float4*>(ba.g_out + ((size_t)b * C + c) * plane + off) =
+                make_float4(gx.x + dz[0], gx.y + dz[1], gx.z + dz[2], gx.w + dz[3]);
+            if (c >= gch0) {
+                float pre[4] = {1.f, 1.f, 1.f, 1.f};
+                if (a.alive_ch >= 0) {
+                    const uchar4 pb = *reinterpret_cast<const uchar4*>(ba.pre_t + (size_t)b * plane + off);
+                    pre[0] = pb.x; pre[1] = pb.y; pre[2] = pb.z; pre[3] = pb.w;
                 }
+                float4* const dg = reinterpret_cast<float4*>(ba.dgoal + ((size_t)b * a.goal_ch + (c - gch0)) * plane + off);
+                float4 o = *dg;
+                o.x += dz[0] * pre[0]; o.y += dz[1] * pre[1]; o.z += dz[2] * pre[2]; o.w += dz[3] * pre[3];
+                *dg = o;
             }
+        }
+        zw[0] = zw[1]; zw[1] = zw[2];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) { pw[f][0] = pw[f][1]; pw[f][1] = pw[f][2]; }
     }
-    // block reduction of the 27 perception-weight partials (fixed order: deterministic)
+    // block reduction of the 27 partial sums, fixed order (deterministic)
     __shared__ float red[4][27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) {
-        float v = wsum[i];
+        float v = active ? wsum[i] : 0.0f;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+        if (lane == 0) red[threadIdx.x >> 6][i] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 27) {
-        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        ba.wp_partials[(size_t)blockIdx.x * 27 + threadIdx.x] += v;
-    }
+    if (threadIdx.x < 27)
+        ba.wp_partials[(size_t)blockIdx.x * 27 + threadIdx.x] +=
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // dst[j] = sum_i src[i*m + j] (fixed order -> deterministic)
@@ -594,7 +606,7 @@ int nca_cond_bwd_nslab() {
         cus = v;
     return cus * kBwdWaves;
 }
-int nca_cond_bwd_nblk(int B, int C, int H, int W) { return B * C * ((H * ((W + 3) / 4) + 255) / 256); }
+int nca_cond_bwd_nblk(int B, int C, int H, int W) { return B * C * ((((H + SROWS - 1) / SROWS) * (W / 4) + 255) / 256); }
 
 // W % 4 == 0 and 16-byte aligned tensors required (checked by the C ABI).
 hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
@@ -608,7 +620,7 @@ hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hi
     return hipGetLastError();
 }
 hipError_t nca_launch_reduce_wp(const float* part, float* dst, int B, int C, int H, int W, hipStream_t st) {
-    const int bpp = (H * ((W + 3) / 4) + 255) / 256;
+    const int bpp = (((H + SROWS - 1) / SROWS) * (W / 4) + 255) / 256;
     hipLaunchKernelGGL(reduce_wp_kernel, dim3(C), dim3(64), 0, st, part, dst, B, C, bpp);
     return hipGetLastError();
 }
