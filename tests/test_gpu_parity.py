@@ -253,7 +253,9 @@ def test_cond_grow_golden_g2(ops, tag):
 
 
 @pytest.mark.parametrize("C,shape,gch,alive", [(12, (2, 32, 32), 8, 3), (16, (2, 48, 80), 12, 3), (16, (1, 21, 35), 16, 3),
-                                               (10, (2, 16, 16), 6, 3), (16, (2, 24, 24), 12, -1), (5, (1, 3, 3), 1, 4)])
+                                               (10, (2, 16, 16), 6, 3), (16, (2, 24, 24), 12, -1), (5, (1, 3, 3), 1, 4),
+                                               (16, (3, 1, 4), 12, 3), (16, (1, 5, 20), 12, 3), (12, (2, 17, 8), 8, 3),
+                                               (16, (1, 4, 36), 0, 3)])
 def test_cond_free_running_vs_oracle(ops, C, shape, gch, alive):
     """16 free-running steps vs the oracle.  Alive thresholds make trajectories chaotic near
     alpha==0.1, so cells are compared away from flipped masks; the flip rate itself is bounded."""

@@ -1,0 +1,26 @@
+#!/bin/bash
+# One GPU-box pass: parity suite, bench line, rocprof kernel stats, FETCH/WRITE PMC passes (separate runs).
+# usage (from the repo root, through gpurun):  bash tools/gpu_round.sh <tag>     -> gpurun_out/<tag>_*
+set -o pipefail
+tag=${1:-r1}
+out=gpurun_out
+mkdir -p $out
+export TMPDIR=/tmp
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $out/${tag}_pytest.log 2>&1 || { tail -30 $out/${tag}_pytest.log; exit 1; }
+tail -2 $out/${tag}_pytest.log
+timeout -k 10 400 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err || { tail -20 $out/${tag}_bench.err; exit 1; }
+cat $out/${tag}_bench.json
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/${tag}_prof -o stats --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_prof.log 2>&1 || { tail -20 $out/${tag}_prof.log; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $out/${tag}_pmc_f -o f --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/${tag}_pmcf.log 2>&1 || { tail -20 $out/${tag}_pmcf.log; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $out/${tag}_pmc_w -o w --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/${tag}_pmcw.log 2>&1 || { tail -20 $out/${tag}_pmcw.log; exit 1; }
+mkdir -p $out/${tag}_pmc && cp -r $out/${tag}_pmc_f $out/${tag}_pmc_w $out/${tag}_pmc/
+python tools/collect_traffic.py $out/${tag}_pmc $out/${tag}_traffic.json > /dev/null
+python - <<PY
+import csv, glob
+f = glob.glob("$out/${tag}_prof/**/*kernel_stats.csv", recursive=True)
+rows = list(csv.DictReader(open(f[0])))
+with open("$out/${tag}_kernel_stats.txt", "w") as o:
+    for r in rows[:14]:
+        line = "%-90s calls %6s avg_ns %12s pct %6s" % (r["Name"][:90], r["Calls"], r["AverageNs"], r["Percentage"])
+        print(line); o.write(line + "\n")
+PY

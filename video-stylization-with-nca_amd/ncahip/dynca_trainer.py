@@ -1,0 +1,76 @@
+"""DyNCA training loop with a dense device-resident pool (reference: ConditioneDyNCA/experiments.py:158-159,
+194-304; twins in ExtraChannels/experiments.py and fit_*_motion.py).  The reference keeps this loop inline in its
+scripts; this class carries exactly the part SURVEY.md section 8 row a15 puts on the path:
+
+    pool  = model.seed(pool_size, size)                       one [pool,C,H,W] tensor on the device (:158-159)
+    every iteration i:
+        reseed numpy / torch RNGs with i + 424                (:196-198)
+        batch_idx = np.random.choice(pool, B, replace=False)  (:210)
+        states    = pool[batch_idx]; every `inject_seed_step` iterations slot 0 <- model.seed(1)  (:213-216)
+        T ~ np.random.randint(min_steps, max_steps)           (:224)
+        states, rgb = model.forward_nsteps(states, T, cond_img=...)   (:226)   <- fused HIP steps, one autograd node
+        loss(input_dict).backward(); p.grad /= ||p.grad|| + 1e-8 per parameter (:254-263); Adam; MultiStepLR(gamma 0.5)
+        pool[batch_idx] = states                              (:269 writes back states[:, :12]; generalised to c_in)
+
+The loss is supplied by the caller (the reference's appearance / motion losses need VGG / MSOE weights that are not
+obtainable offline).  With torch.distributed initialised each rank owns pool_size/world slots and gradients are
+all-reduced through one flat bucket before the normalisation (ncahip.dist).
+"""
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import dist as ncadist
+
+
+class DyNCATrainer:
+    def __init__(self, model, loss_fn: Callable, pool_size: int = 256, size=(128, 128), batch_size: int = 4,
+                 nca_steps: Sequence[int] = (32, 128), lr: float = 1e-3, lr_decay_step: Sequence[int] = (1000, 2000),
+                 inject_seed_step: int = 8, device: Optional[torch.device] = None, reseed_offset: int = 424):
+        self.model, self.loss_fn = model, loss_fn
+        self.device = device if device is not None else next(model.parameters()).device
+        self.size, self.batch_size = size, batch_size
+        self.min_steps, self.max_steps = nca_steps
+        self.inject_seed_step, self.reseed_offset = inject_seed_step, reseed_offset
+        self.pool_size = ncadist.shard_size(pool_size)
+        with torch.no_grad():
+            self.pool = model.seed(self.pool_size, size=size).to(self.device)
+        self.optimizer = torch.optim.Adam(model.parameters(), lr=lr)
+        self.lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, list(lr_decay_step), 0.5)
+        self.iteration = 0
+
+    def step(self, cond_img: Optional[torch.Tensor] = None, extra: Optional[dict] = None):
+        """One training iteration; returns (loss value as a 0-d tensor, T)."""
+        i = self.iteration
+        np.random.seed(i + self.reseed_offset)
+        torch.manual_seed(i + self.reseed_offset)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed_all(i + self.reseed_offset)
+        with torch.no_grad():
+            batch_idx = np.random.choice(self.pool_size, self.batch_size, replace=False)
+            idx = torch.as_tensor(batch_idx, device=self.pool.device)
+            states = self.pool.index_select(0, idx)
+            if i % self.inject_seed_step == 0:
+                states[:1] = self.model.seed(1, size=self.size).to(states.device)[:1]
+        step_n = int(np.random.randint(self.min_steps, self.max_steps))
+        kw = {} if cond_img is None else {"cond_img": cond_img}
+        states_after, rgb = self.model.forward_nsteps(states, step_n, **kw)
+        input_dict = {"generated_image_list": [rgb], "nca_state": states_after, "step_n": step_n}
+        if extra:
+            input_dict.update(extra)
+        loss = self.loss_fn(input_dict)
+        loss = loss[0] if isinstance(loss, (tuple, list)) else loss
+        self.optimizer.zero_grad()
+        loss.backward()
+        with torch.no_grad():
+            params = [p for p in self.model.parameters() if p.requires_grad]
+            ncadist.allreduce_mean_grads(params)
+            for p in params:
+                if p.grad is not None:
+                    p.grad /= (p.grad.norm() + 1e-8)
+            self.optimizer.step()
+            self.lr_scheduler.step()
+            self.pool.index_copy_(0, idx, states_after.detach()[:, : self.pool.shape[1]])
+        self.iteration += 1
+        return loss.detach(), step_n
