@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-kernel phase stamps of the producer/consumer kernel (light stamps build, `make stamps`):
+entry -> first barrier (weight image / first tile) -> loop -> end, per workgroup, against the event-timed launch."""
+import ctypes, os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "video-stylization-with-nca_amd")
+os.environ["NCAHIP_LIB"] = os.path.join(PKG, "libncahip_stamps.so")
+sys.path[:0] = [ROOT, PKG]
+import bench
+from ncahip import ops
+B, C, H, W = bench.B, bench.C, bench.H, bench.W
+dev = "cuda"
+gen = torch.Generator().manual_seed(0)
+prm = bench.make_weights(gen)
+x = torch.rand(B, C, H, W, generator=gen).to(dev)
+goal = (torch.randn(B, 12, H, W, generator=gen) * 0.5).to(dev)
+w = ops.CondWeights(prm["perception_net.weight"], prm["update_net.out.0.weight"], prm["update_net.out.0.bias"],
+                    prm["update_net.out.2.weight"], prm["update_net.out.2.bias"], prm["update_net.out.4.weight"], x)
+L = ops.lib()
+L.nca_debug_set_stamp_buffer_pc.argtypes = [ctypes.c_void_p]
+NWG = 256
+buf = torch.zeros(NWG * 8 * 8 * 16 + NWG * 8 * 8, dtype=torch.int64, device=dev)
+def run(tag, seed=0):
+    buf.zero_()
+    xp, pre = ops.cond_step(x, None, goal, None, w, 3)
+    for _ in range(5):
+        xp2, pre2 = ops.cond_step(xp, pre, goal, None, w, 3, step=1)
+    torch.cuda.synchronize()
+    L.nca_debug_set_stamp_buffer_pc(buf.data_ptr())
+    xp2, pre2 = ops.cond_step(xp, pre, goal, None, w, 3, step=2, seed=seed)
+    torch.cuda.synchronize()
+    L.nca_debug_set_stamp_buffer_pc(None)
+    k = buf[NWG * 8 * 8 * 16:].cpu().numpy().reshape(NWG, 8, 8).astype(np.float64)
+    v = k[:, 0:4]
+    print(f"{tag:34s} startup {np.median(v[..., 2] - v[..., 0]):7.0f}   loop {np.median(v[..., 3] - v[..., 2]):8.0f} = {np.median(v[..., 3] - v[..., 2]) / 8:7.0f} per tile   whole {np.median(v[..., 3] - v[..., 0]):8.0f} cycles")
+
+run("normal")
+run("idle producers", 0xD1A6)
+run("idle consumers", 0xD1A7)
+run("consumer: no perception", 0xD1A8)
+run("consumer: no MLP", 0xD1A9)

@@ -12,12 +12,17 @@
 
 namespace {
 
+#ifndef NCA_NT_STORE
+#define NCA_NT_STORE 1
+#endif
+constexpr bool kNtStore = NCA_NT_STORE != 0;
+
 template <int CP>
 struct PCfg {
     using F = WCfg<CP>;
     static constexpr int BUF_Z = 0;
     static constexpr int BUF_XR = BUF_Z + CP * CS;
-    static constexpr int BUF_MK = BUF_XR + CP * XRS;
+    static constexpr int BUF_MK = BUF_XR + 16 * F::M3T * XRS;       // 16*M3T rows: mlp_tile_regs updates whole MFMA row tiles
     static constexpr int BUF = BUF_MK + WTH * WTW;                 // one tile buffer (floats)
     static constexpr int SCR_A3 = 2 * BUF;                         // producer scratch, not double-buffered
     static constexpr int SCR_LIFE = SCR_A3 + (WTH + 6) * RS;
@@ -38,6 +43,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
     const int C = EXACT ? CP : a.C, H = a.H, W = a.W, hid = EXACT ? 64 : a.hidden, K1 = 3 * C;
     const bool producer = wave >= 4;
     const int pair = wave & 3;
+    NCA_KSTAMP(0);
 
     // 16-byte A-operand images (same layouts as nca_cond_wave.hip), built by the four consumer waves while the
     // producers already stage the first tile
@@ -117,6 +123,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
         }
         NCA_STAMP(6);
     };
+    MlpRegs<CP> Wr;
     auto consume = [&](const WTile& t, int which) {
         if (!t.valid) return;
         const TileLds L = lds_of(which);
@@ -125,39 +132,88 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
         for (int pass = 0; pass < WTH / NT; ++pass) {
             float P[NT][K::K1S];
             if (pass == 0) NCA_STAMP(4);
+#ifdef NCA_STAMPS
+            // diagnostic knobs (stamps build only): 0xD1A8 = no perception, 0xD1A9 = no MLP
+            if (a.seed == 0xD1A8ull) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int s_ = 0; s_ < K::K1S; ++s_) P[n][s_] = L.Z[lane + n];
+            } else
+#endif
             perceive_tile<CP, NT>(smem, L.Z, lane, pass * NT, P);
             if (pass == 0) NCA_STAMP(5);
-            mlp_tile<CP, NT>(a, smem, L.XR, L.MK, lane, pass * NT, P);
+#ifdef NCA_STAMPS
+            if (a.seed == 0xD1A9ull) {
+                float acc_ = 0.0f;
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int s_ = 0; s_ < K::K1S; ++s_) acc_ += P[n][s_];
+                L.XR[lane] = acc_;
+            } else
+#endif
+            mlp_tile_regs<CP, NT>(Wr, L.XR, L.MK, lane, pass * NT, P);
             if (pass == 0) NCA_STAMP(6);
         }
         NCA_STAMP(7);
-        if (t.inner) store_tile<CP, false, EXACT>(a, t, L.XR, lane);
-        else store_tile<CP, true, EXACT>(a, t, L.XR, lane);
+        if (t.inner) store_tile<CP, false, EXACT, kNtStore>(a, t, L.XR, lane);
+        else store_tile<CP, true, EXACT, kNtStore>(a, t, L.XR, lane);
         NCA_STAMP(8);
     };
 
     int which = 0;
     Pos pos{tw.t, tw.t % st_x, (tw.t / st_x) % st_y, tw.t / (st_x * st_y)};   // one division per kernel
     WTile cur = tile_of(pos);
-    // At equal priority the (older) consumer waves win every arbitration and the producer only issues in the gaps of
-    // their MFMA stream -- it becomes the long pole and the consumers idle at the barrier.  Its instructions are few:
-    // let them go first.
-    if (producer) __builtin_amdgcn_s_setprio(3);
-    if (producer) produce(cur, 0);   // overlaps the tail of the weight-image fill of the other waves
-    __syncthreads();                  // weight image + first tile ready
-    while (pos.t < tw.end) {          // uniform over the workgroup
-        const Pos pn = advance(pos);
-        const WTile nxt = tile_of(pn);
-        NCA_STAMP(0);
-        if (producer) produce(nxt, which ^ 1);
-        else consume(cur, which);
-        NCA_STAMP(1);
-        __syncthreads();              // tile buffers change hands
-        NCA_STAMP(2);
-        cur = nxt;
-        pos = pn;
-        which ^= 1;
-        ++tile_no;
+    // The two roles run separate loops with the same barrier count (all branches are wave-uniform): the consumer's
+    // 128 weight registers are then not live in the producer's code and vice versa.
+    if (producer) {
+        // At equal priority the (older) consumer waves win every arbitration and the producer only issues in the gaps
+        // of their MFMA stream; its instructions are few: let them go first.
+        __builtin_amdgcn_s_setprio(3);
+        produce(cur, 0);              // overlaps the weight-image fill of the consumer waves
+        NCA_KSTAMP(1);
+        __syncthreads();              // weight image + first tile ready
+        NCA_KSTAMP(2);
+        while (pos.t < tw.end) {      // uniform over the workgroup
+            const Pos pn = advance(pos);
+            const WTile nxt = tile_of(pn);
+            NCA_STAMP(0);
+#ifdef NCA_STAMPS
+            if (a.seed != 0xD1A6ull)  // diagnostic knob (stamps build only): idle producers
+#endif
+            produce(nxt, which ^ 1);
+            NCA_STAMP(1);
+            __syncthreads();          // tile buffers change hands
+            NCA_STAMP(2);
+            cur = nxt;
+            pos = pn;
+            which ^= 1;
+            ++tile_no;
+        }
+        NCA_KSTAMP(3);
+    } else {
+        NCA_KSTAMP(1);
+        __syncthreads();
+        NCA_KSTAMP(2);
+        mlp_load_regs<CP>(smem, lane, Wr);
+        while (pos.t < tw.end) {
+            const Pos pn = advance(pos);
+            const WTile nxt = tile_of(pn);
+            NCA_STAMP(0);
+#ifdef NCA_STAMPS
+            if (a.seed != 0xD1A7ull)  // diagnostic knob: idle consumers
+#endif
+            consume(cur, which);
+            NCA_STAMP(1);
+            __syncthreads();
+            NCA_STAMP(2);
+            cur = nxt;
+            pos = pn;
+            which ^= 1;
+            ++tile_no;
+        }
+        NCA_KSTAMP(3);
     }
 }
 

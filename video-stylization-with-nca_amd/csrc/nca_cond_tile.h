@@ -44,7 +44,20 @@ struct WCfg {
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 
-#ifdef NCA_STAMPS
+#if defined(NCA_STAMPS)
+// per-kernel stamps (cheap: entry / loop start / loop end), region behind the per-tile stamps
+#define NCA_KSTAMP(i)                                                                                  \
+    do {                                                                                               \
+        if (a.dbg) {                                                                                   \
+            unsigned long long t_;                                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+            if ((threadIdx.x & 63) == 0) a.dbg[(size_t)gridDim.x * kWaves * 8 * 16 + (size_t)(blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8 + (i)] = t_; \
+        }                                                                                              \
+    } while (0)
+#else
+#define NCA_KSTAMP(i) do { } while (0)
+#endif
+#if defined(NCA_STAMPS) && NCA_STAMPS >= 2
 // Diagnostic build only: phase stamps per wave tile -> a.dbg[((wg*8+wave)*kStampTiles + tile)*16 + i].
 constexpr int kStampTiles = 8;  // stamped tiles per wave (buffer: [wg*8+wave][kStampTiles][16])
 #define NCA_STAMP(i)                                                                                   \
@@ -476,8 +489,130 @@ __device__ __forceinline__ void mlp_tile(const NcaCondArgs& a, const float* __re
     }
 }
 
+// Register-resident A operands of the whole UpdateNet for one lane: 4*K1S4 + 16 + 4*M3T 16-byte values (128 VGPRs at
+// CP=16).  A wave that only consumes tiles (nca_cond_pc.hip) loads them once per launch; its MFMA stream then contains no
+// LDS reads at all -- with in-order issue every ds_read that lands next to its use stalls the matrix pipe for the full
+// LDS latency (measured: 44.6 instead of 34.6 cycles per MFMA with LDS-fed operands).
+template <int CP>
+struct MlpRegs {
+    using K = WCfg<CP>;
+    f32x4 w1[4][K::K1S4], w2[4][4], w3[K::M3T][4], b1[4], b2[4];
+};
+template <int CP>
+__device__ __forceinline__ void mlp_load_regs(const float* __restrict__ WS, int lane, MlpRegs<CP>& R) {
+    using K = WCfg<CP>;
+    const f32x4* const W1V = reinterpret_cast<const f32x4*>(WS + K::OFF_W1) + lane;
+    const f32x4* const W2V = reinterpret_cast<const f32x4*>(WS + K::OFF_W2) + lane;
+    const f32x4* const W3V = reinterpret_cast<const f32x4*>(WS + K::OFF_W3) + lane;
+    const int g = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int q = 0; q < K::K1S4; ++q) R.w1[m][q] = W1V[(m * K::K1S4 + q) * 64];
+#pragma unroll
+        for (int m2 = 0; m2 < 4; ++m2) R.w2[m2][m] = W2V[(m2 * 4 + m) * 64];
+#pragma unroll
+        for (int m3 = 0; m3 < K::M3T; ++m3) R.w3[m3][m] = W3V[(m3 * 4 + m) * 64];
+        R.b1[m] = ld4(WS + K::OFF_B1 + 16 * m + 4 * g);
+        R.b2[m] = ld4(WS + K::OFF_B2 + 16 * m + 4 * g);
+    }
+}
+// mlp_tile with register-resident operands (same MFMA order per accumulator => bit-identical results).
+// Issue order matters more than instruction count here: an exact-f32 MFMA does not co-execute with VALU work, so every
+// VALU instruction that lands between two MFMAs drains the matrix pipe first (measured: ~25 cycles per isolated v_max,
+// tools/micro/mlp_pass.hip).  The ReLUs are therefore issued as fenced groups of 8 / 32, and the layer-1 chain of hidden
+// tile m+1 is issued BEFORE the ReLU group of tile m so that group never waits for the chain it reads.
+// XR must provide 16*M3T channel rows.
+template <int CP, int NT>
+__device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, float* __restrict__ XR, const float* __restrict__ MK,
+                                              int lane_in, int n0, const float (&P)[NT][3 * CP / 4]) {
+    using K = WCfg<CP>;
+    int lane_o = lane_in;
+    asm volatile("" : "+v"(lane_o));
+    const int g = lane_o >> 4, ci = lane_o & 15;
+    f32x4 acc2[4][NT], acc1[NT], acc1n[NT];
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc2[m2][n] = Wr.b2[m2];
+    auto layer1 = [&](int m, f32x4 (&acc)[NT]) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = Wr.b1[m];
+#pragma unroll
+        for (int s = 0; s < K::K1S; ++s)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = nca_mfma(Wr.w1[m][s >> 2][s & 3], P[n][s], acc[n]);
+    };
+    layer1(0, acc1);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        if (m < 3) layer1(m + 1, acc1n);
+        float h[NT][4];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[n][r] = relu(acc1[n][r]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m2 = 0; m2 < 4; ++m2)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc2[m2][n] = nca_mfma(Wr.w2[m2][m][r], h[n][r], acc2[m2][n]);
+        if (m < 3) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc1[n] = acc1n[n];
+        }
+    }
+    // the residual operands (read-modify-write of the resolved state, same lane) are fetched before the last ReLU group
+    float xr[NT][K::M3T][4], mk[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        mk[n] = MK[(n0 + n) * WTW + ci];
+#pragma unroll
+        for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // XR holds 16*M3T channel rows (rows >= CP are scratch): no per-lane guard, no exec masking
+                xr[n][m3][r] = XR[(16 * m3 + 4 * g + r) * XRS + (n0 + n) * WTW + ci];
+            }
+    }
+    float h2[4][NT][4];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h2[m][n][r] = relu(acc2[m][n][r]);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc3[K::M3T][NT];
+#pragma unroll
+    for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc3[m3][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // out.4 has no bias
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc3[m3][n] = nca_mfma(Wr.w3[m3][m][r], h2[m][n][r], acc3[m3][n]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                XR[(16 * m3 + 4 * g + r) * XRS + (n0 + n) * WTW + ci] = fmaf(mk[n], acc3[m3][n][r], xr[n][m3][r]);
+            }
+}
+
 // Pending state out: 16-byte stores, 4 per lane (item k -> channel 4k+q4, row (lane>>2)&3, group lane&3).
-template <int CP, bool CHECK, bool EXACT = false>
+template <int CP, bool CHECK, bool EXACT = false, bool NT_STORE = false>
 __device__ __forceinline__ void store_tile(const NcaCondArgs& a, const WTile& t, const float* __restrict__ XR, int lane_in) {
     const int C = EXACT ? CP : a.C, H = a.H, W = a.W;
     const unsigned plane = (unsigned)(H * W);
@@ -492,7 +627,12 @@ __device__ __forceinline__ void store_tile(const NcaCondArgs& a, const WTile& t,
     for (int k = 0; k < CP / 4; ++k) {
         const int ch = 4 * k + q4;
         const f32x4 v = ld4(XR + ch * XRS + row * WTW + 4 * ff);
-        if (ok && ch < C) st4(ob + (unsigned)ch * plane, v);
+        if (ok && ch < C) {
+            // NT_STORE: streaming store -- the line is written through instead of sitting dirty in the XCD's L2 until
+            // the end-of-kernel write-back (the next step re-reads it through the memory-side cache either way)
+            if (NT_STORE) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ob + (unsigned)ch * plane));
+            else st4(ob + (unsigned)ch * plane, v);
+        }
     }
 }
 
