@@ -12,10 +12,10 @@
 
 namespace {
 
-#ifndef NCA_NT_STORE
-#define NCA_NT_STORE 1
+#ifndef NCA_WT_STORE
+#define NCA_WT_STORE 1
 #endif
-constexpr bool kNtStore = NCA_NT_STORE != 0;
+constexpr bool kNtStore = NCA_WT_STORE != 0;   // write-through output stores (see store_tile)
 
 template <int CP>
 struct PCfg {

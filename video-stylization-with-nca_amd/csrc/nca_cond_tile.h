@@ -628,9 +628,12 @@ __device__ __forceinline__ void store_tile(const NcaCondArgs& a, const WTile& t,
         const int ch = 4 * k + q4;
         const f32x4 v = ld4(XR + ch * XRS + row * WTW + 4 * ff);
         if (ok && ch < C) {
-            // NT_STORE: streaming store -- the line is written through instead of sitting dirty in the XCD's L2 until
-            // the end-of-kernel write-back (the next step re-reads it through the memory-side cache either way)
-            if (NT_STORE) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ob + (unsigned)ch * plane));
+            // WT_STORE: write-through (system-scope) store -- the line goes to memory now instead of sitting dirty in
+            // the XCD's L2 until the end-of-kernel write-back, which otherwise sits between two step launches (measured:
+            // -4 us launch cadence; a plain `nt` hint changes nothing).  Inline asm: hipcc has no builtin for sc0 sc1 on
+            // a 16-byte store; the trailing s_nop covers the store-data hazard the compiler would otherwise handle.
+            if (NT_STORE)
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(ob + (unsigned)ch * plane), "v"(v) : "memory");
             else st4(ob + (unsigned)ch * plane, v);
         }
     }
