@@ -34,6 +34,13 @@ def run(tag, seed=0):
     L.nca_debug_set_stamp_buffer_pc(None)
     k = buf[NWG * 8 * 8 * 16:].cpu().numpy().reshape(NWG, 8, 8).astype(np.float64)
     v = k[:, 0:4]
+    if seed == 0:
+        pw = k[:, 4:8]
+        print("   producer tile 0: entry->loads issued %.0f   wp fill %.0f   stage %.0f   perception+P write %.0f   (arrive at barrier %.0f)" % (
+            np.median(pw[..., 4] - pw[..., 0]), np.median(pw[..., 5] - pw[..., 4]), np.median(pw[..., 6] - pw[..., 5]),
+            np.median(pw[..., 1] - pw[..., 6]), np.median(pw[..., 1] - pw[..., 0])))
+        print("   consumer: entry->weights issued + biases %.0f   weights landed %.0f   (arrive at barrier %.0f)" % (
+            np.median(v[..., 4] - v[..., 0]), np.median(v[..., 5] - v[..., 4]), np.median(v[..., 1] - v[..., 0])))
     print(f"{tag:34s} startup {np.median(v[..., 2] - v[..., 0]):7.0f}   loop {np.median(v[..., 3] - v[..., 2]):8.0f} = {np.median(v[..., 3] - v[..., 2]) / 8:7.0f} per tile   whole {np.median(v[..., 3] - v[..., 0]):8.0f} cycles")
 
 run("normal")
