@@ -67,7 +67,7 @@ int ncahip_version(void) { return NCAHIP_VERSION; }
 const char* ncahip_last_error(void) { return g_err; }
 
 int ncahip_debug_force_generic(int on) {
-    nca_set_force_generic((on & 1) != 0);    // bit 0: generic any-shape kernels
+    nca_set_force_generic(on & 5);           // bit 0: generic any-shape kernels; bit 2: one launch per grow step
     nca_set_cond_variant((on >> 1) & 1);     // bit 1: symmetric wave-private ConditionedNCA kernel instead of producer/consumer
     return 0;
 }
@@ -175,7 +175,24 @@ int ncahip_cond_grow_fwd_f32(float* states, uint8_t* pre, int ring, int T, float
     const int sl = T % ring;
     if (x_final == states + (size_t)sl * slot && alive_ch >= 0)
         return fail(NCAHIP_EINVAL, "cond grow: x_final must not alias the last state slot");
-    for (int t = 0; t < T; ++t) {
+    // Fused path: all T steps in one cooperative launch of the producer/consumer kernel (grid barrier between steps).
+    NcaCondArgs a0{states, nullptr, states + slot, pre + pslot, goal, u, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch,
+                   alive_ch, alive_thr, fire_rate, clamp_lo, clamp_hi, seed, step0};
+    bool fused = false;
+    if (T > 1 && nca_cond_pc_eligible(a0)) {
+        unsigned* sync = nullptr;
+        if (hipMallocAsync((void**)&sync, 64, st) == hipSuccess) {
+            hipError_t e = hipMemsetAsync(sync, 0, 64, st);
+            if (e == hipSuccess) e = nca_launch_cond_grow_fwd_pc(a0, NcaGrowLoop{states, pre, ring, T, sync}, st);
+            (void)hipFreeAsync(sync, st);
+            if (e == hipSuccess) fused = true;
+            else if (e != hipErrorNotSupported) return hip_result(e, "cond_grow_fwd (fused)");
+            else (void)hipGetLastError();
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    for (int t = 0; t < T && !fused; ++t) {
         const int si = t % ring, so = (t + 1) % ring;
         NcaCondArgs a{states + (size_t)si * slot, t == 0 ? nullptr : pre + (size_t)si * pslot,
                       states + (size_t)so * slot, pre + (size_t)so * pslot, goal,

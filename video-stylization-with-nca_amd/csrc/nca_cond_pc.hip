@@ -15,6 +15,7 @@
 // producer wave keeps a private copy of the perception weights.
 //   workgroup = 8 waves = 4 pairs; pair p owns the 4x16 tiles at rows 4p..4p+3 of each 16x16 super-tile.
 #include "nca_cond_tile.h"
+#include <type_traits>
 
 namespace {
 
@@ -38,14 +39,45 @@ struct PCfg {
     static constexpr int OFF_WP = OFF_A2 + (WTH + 4) * RS;         // producer's copy of the perception weights [CP][28]
     static constexpr int OFF_BL = OFF_WP + CP * 28;                // consumer's copy of the biases [b1 64][b2 64]
     static constexpr int PAIR = OFF_BL + 128;
-    static constexpr int LDS_FLOATS = 4 * PAIR;
+    static constexpr int OFF_FLAG = 4 * PAIR;                       // workgroup-wide: grid-barrier verdict
+    static constexpr int LDS_FLOATS = 4 * PAIR + 4;
     static_assert(CP * ZCS <= PBUF, "z tile fits the P buffer it aliases");
     static_assert(PBUF % 4 == 0 && XRB % 4 == 0 && OFF_A3 % 4 == 0 && OFF_WP % 4 == 0 && PAIR % 4 == 0, "16-byte carve");
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 
+// Grid-wide barrier between two fused steps of a cooperative launch (every workgroup is resident).  No cache-wide
+// write-back / invalidate (measured: +40 us per step when every wave issues buffer_wbl2 / buffer_inv): everything one
+// step writes and the next reads -- state, pre mask -- is stored write-through and loaded coherently (sc1, see
+// issue_loads / store_tile), so the barrier only has to wait for this wave's stores and count arrivals.  The spin is
+// bounded: after ~2 s (or when another workgroup gave up) the launch aborts instead of hanging the device.
+__device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, volatile int* flag) {
+    __builtin_amdgcn_s_waitcnt(0);   // this wave's write-through stores have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        const unsigned long long t0 = wall_clock64();   // 100 MHz
+        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                wall_clock64() - t0 > 200000000ull) {
+                __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        *flag = ok;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
+// g.T == 0: one step described by a0 (ordinary launch).  g.T >= 1: the grow loop's steps 0..T-1 in this one
+// (cooperative) launch, see NcaGrowLoop.
 template <int CP, bool EXACT>
-__global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const NcaCondArgs a) {
+__global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const NcaCondArgs a0, const NcaGrowLoop g) {
+    NcaCondArgs a = a0;
     using K = WCfg<CP>;
     using PK = PCfg<CP>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -92,8 +124,31 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
     };
     int tile_no = 0;
     int which = 0;
-    Pos pos{tw.t, tw.t % st_x, (tw.t / st_x) % st_y, tw.t / (st_x * st_y)};   // one division per kernel
+    const Pos pos0{tw.t, tw.t % st_x, (tw.t / st_x) % st_y, tw.t / (st_x * st_y)};   // one division per kernel
+    Pos pos = pos0;
     WTile cur = tile_of(pos);
+    // fused grow loop: ring slots of step t
+    const int nsteps = g.T > 0 ? g.T : 1;
+    const size_t slot = (size_t)a0.B * C * H * W, pslot = (size_t)a0.B * H * W;
+    int ring_in = 0;
+    auto set_step = [&](int t) {
+        if (g.T > 0) {
+            const int ring_out = ring_in + 1 == g.ring ? 0 : ring_in + 1;
+            a.x_in = g.states + (size_t)ring_in * slot;
+            a.pre_in = t == 0 ? nullptr : g.pre + (size_t)ring_in * pslot;
+            a.x_out = g.states + (size_t)ring_out * slot;
+            a.pre_out = g.pre + (size_t)ring_out * pslot;
+            a.u = a0.u ? a0.u + (size_t)t * pslot : nullptr;
+            a.step = a0.step + (uint64_t)t;
+            ring_in = ring_out;
+        }
+        pos = pos0;
+        cur = tile_of(pos);
+        which = 0;
+    };
+    const int kst = nsteps > 2 ? 1 : 0;   // stamped step (light stamps build): a warm one when the launch is fused
+    (void)kst;
+    volatile int* const gflag = reinterpret_cast<volatile int*>(smem + PK::OFF_FLAG);
 
     // The two roles run separate loops with the same barrier count (every branch is wave-uniform), so neither role's
     // long-lived registers are live in the other's code.
@@ -149,24 +204,30 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
         // At equal priority the (older) consumer waves win every arbitration and the producer only issues in the gaps
         // of their MFMA stream; its instructions are few: let them go first.
         __builtin_amdgcn_s_setprio(3);
-        produce(cur, 0);
-        NCA_KSTAMP(1);
-        __syncthreads();              // first tile ready
-        NCA_KSTAMP(2);
-        while (pos.t < tw.end) {      // uniform over the workgroup
-            const Pos pn = advance(pos);
-            const WTile nxt = tile_of(pn);
+        for (int t = 0; t < nsteps; ++t) {
+            set_step(t);
+            produce(cur, 0);
+            if (t == kst) NCA_KSTAMP(1);
+            __syncthreads();              // first tile ready
+            if (t == kst) NCA_KSTAMP(2);
+            while (pos.t < tw.end) {      // uniform over the workgroup
+                const Pos pn = advance(pos);
+                const WTile nxt = tile_of(pn);
 #ifdef NCA_STAMPS
-            if (a.seed != 0xD1A6ull)  // diagnostic knob (stamps build only): idle producers
+                if (a.seed != 0xD1A6ull)  // diagnostic knob (stamps build only): idle producers
 #endif
-            produce(nxt, which ^ 1);
-            __syncthreads();          // tile buffers change hands
-            cur = nxt;
-            pos = pn;
-            which ^= 1;
-            ++tile_no;
+                produce(nxt, which ^ 1);
+                __syncthreads();          // tile buffers change hands
+                cur = nxt;
+                pos = pn;
+                which ^= 1;
+                ++tile_no;
+            }
+            if (t == kst) NCA_KSTAMP(3);
+            if (t + 1 < nsteps && !grid_barrier(g.sync, (unsigned)(t + 1) * gridDim.x, gflag)) break;
+            if (t == kst) NCA_KSTAMP(7);
+            if (t + 1 == kst) NCA_KSTAMP(0);
         }
-        NCA_KSTAMP(3);
     } else {
         MlpRegs<CP> Wr;
         mlp_load_regs_global<CP, EXACT && CP == 16>(a, lane, Wr);
@@ -216,28 +277,34 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         NCA_KSTAMP(5);
 #endif
-        NCA_KSTAMP(1);
-        __syncthreads();
-        NCA_KSTAMP(2);
-        while (pos.t < tw.end) {
-            const Pos pn = advance(pos);
-            const WTile nxt = tile_of(pn);
-#ifdef NCA_STAMPS
-            if (a.seed != 0xD1A7ull)  // diagnostic knob: idle consumers
-#endif
-            consume(cur, which);
+        for (int t = 0; t < nsteps; ++t) {
+            set_step(t);
+            if (t == kst) NCA_KSTAMP(1);
             __syncthreads();
-            cur = nxt;
-            pos = pn;
-            which ^= 1;
-            ++tile_no;
+            if (t == kst) NCA_KSTAMP(2);
+            while (pos.t < tw.end) {
+                const Pos pn = advance(pos);
+                const WTile nxt = tile_of(pn);
+#ifdef NCA_STAMPS
+                if (a.seed != 0xD1A7ull)  // diagnostic knob: idle consumers
+#endif
+                consume(cur, which);
+                __syncthreads();
+                cur = nxt;
+                pos = pn;
+                which ^= 1;
+                ++tile_no;
+            }
+            if (t == kst) NCA_KSTAMP(3);
+            if (t + 1 < nsteps && !grid_barrier(g.sync, (unsigned)(t + 1) * gridDim.x, gflag)) break;
+            if (t == kst) NCA_KSTAMP(7);
+            if (t + 1 == kst) NCA_KSTAMP(0);
         }
-        NCA_KSTAMP(3);
     }
 }
 
 template <int CP, bool EXACT>
-hipError_t launch_cond_pc(const NcaCondArgs& a, hipStream_t st) {
+hipError_t launch_cond_pc(const NcaCondArgs& a, const NcaGrowLoop& g, hipStream_t st) {
     using PK = PCfg<CP>;
     auto kern = cond_step_fwd_pc_kernel<CP, EXACT>;
     const size_t lds = (size_t)PK::LDS_FLOATS * sizeof(float);
@@ -248,17 +315,41 @@ hipError_t launch_cond_pc(const NcaCondArgs& a, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    static thread_local int cus = 0;
+    static thread_local int cus = 0, resident = 0;
     if (cus == 0) {
         int dev = 0, v = 0;
         cus = 256;
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
             cus = v;
+        int per_cu = 0, coop = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kThreadsW, lds) == hipSuccess &&
+            hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) == hipSuccess && coop)
+            resident = per_cu * cus;
     }
     const int nst = a.B * ((a.W + 15) / 16) * ((a.H + 15) / 16);
-    hipLaunchKernelGGL(kern, dim3(nst < cus ? nst : cus), dim3(kThreadsW), lds, st, a);
-    return hipGetLastError();
+    const int grid = nst < cus ? nst : cus;
+    if (g.T <= 0) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreadsW), lds, st, a, g);
+        return hipGetLastError();
+    }
+    if (grid > resident) return hipErrorNotSupported;   // the grid barrier needs every workgroup resident
+    NcaCondArgs a_ = a;
+    NcaGrowLoop g_ = g;
+    void* params[2] = {&a_, &g_};
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), dim3(grid), dim3(kThreadsW), params, (unsigned)lds, st);
+}
+
+template <typename F>
+hipError_t dispatch_cond_pc(const NcaCondArgs& a, F&& go) {
+    const bool h64 = a.hidden == 64;
+    // <16,true> loads its UpdateNet operands as 16-byte slices of the weight tensors
+    const bool wal = (((uintptr_t)a.w1 | (uintptr_t)a.w2 | (uintptr_t)a.w3) & 15) == 0;
+    if (a.C == 12 && h64) return go(std::integral_constant<int, 12>{}, std::true_type{});
+    if (a.C == 16 && h64 && wal) return go(std::integral_constant<int, 16>{}, std::true_type{});
+    if (a.C <= 12) return go(std::integral_constant<int, 12>{}, std::false_type{});
+    if (a.C <= 16) return go(std::integral_constant<int, 16>{}, std::false_type{});
+    return hipErrorInvalidValue;
 }
 
 }  // namespace
@@ -270,12 +361,12 @@ extern "C" void nca_debug_set_stamp_buffer_pc(void* p) { g_stamp_pc = (unsigned 
 hipError_t nca_launch_cond_step_fwd_pc(const NcaCondArgs& a_in, hipStream_t st) {
     NcaCondArgs a = a_in;
     a.dbg = g_stamp_pc;
-    const bool h64 = a.hidden == 64;
-    // <16,true> loads its UpdateNet operands as 16-byte slices of the weight tensors
-    const bool wal = (((uintptr_t)a.w1 | (uintptr_t)a.w2 | (uintptr_t)a.w3) & 15) == 0;
-    if (a.C == 12 && h64) return launch_cond_pc<12, true>(a, st);
-    if (a.C == 16 && h64 && wal) return launch_cond_pc<16, true>(a, st);
-    if (a.C <= 12) return launch_cond_pc<12, false>(a, st);
-    if (a.C <= 16) return launch_cond_pc<16, false>(a, st);
-    return hipErrorInvalidValue;
+    const NcaGrowLoop g{nullptr, nullptr, 0, 0, nullptr};
+    return dispatch_cond_pc(a, [&](auto cp, auto ex) { return launch_cond_pc<decltype(cp)::value, decltype(ex)::value>(a, g, st); });
+}
+hipError_t nca_launch_cond_grow_fwd_pc(const NcaCondArgs& a_in, const NcaGrowLoop& g, hipStream_t st) {
+    if (g.T < 1 || g.ring < 2 || !g.states || !g.pre || !g.sync) return hipErrorInvalidValue;
+    NcaCondArgs a = a_in;
+    a.dbg = g_stamp_pc;
+    return dispatch_cond_pc(a, [&](auto cp, auto ex) { return launch_cond_pc<decltype(cp)::value, decltype(ex)::value>(a, g, st); });
 }

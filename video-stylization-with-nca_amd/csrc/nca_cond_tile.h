@@ -155,91 +155,118 @@ struct TileRegs {
 //   halo columns  : item k -> channel 4k+q4, slot ci (<12): halo-1 row ci>>1, side ci&1
 // CHK: -1 = decide from t.inner at run time, 0 = interior tile (no bounds logic), 1 = border tile.
 // EXACT: the launch guarantees a.C == CP (no channel-padding guards).
-// Addressing: every load is  <uniform 64-bit base of the batch item> + <32-bit byte offset>, the offset being ONE
-// v_mad_u32_u24 (channel * plane bytes + pixel bytes) -- no 64-bit vector arithmetic.  Needs H*W < 2^24 and
-// C*H*W*4 < 2^32 (checked by the dispatch in nca_step_fwd.hip; larger grids take the generic kernel).
-__device__ __forceinline__ float ldf_off(const float* base, unsigned byte_off) {
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+// Addressing: raw buffer loads -- <buffer resource of the batch item (SGPRs)> + <32-bit VGPR byte offset shared by a
+// whole group of loads> + <uniform SGPR offset that steps through channels / rows>: no per-load vector arithmetic at all
+// on interior tiles.  Needs H*W < 2^24 and C*H*W*4 < 2^32 (checked by the dispatch in nca_step_fwd.hip; larger grids
+// take the generic kernel).  State-type tensors (x, pre mask: rewritten by other XCDs between the fused steps of a
+// persistent launch) are read with sc1 = agent scope, i.e. coherently, never from a stale non-coherent L2 line; the goal
+// encoding and the weights are read-only for the whole launch and stay ordinary cached loads.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAuxCoherent = 16;   // sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t nca_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
 }
-__device__ __forceinline__ f32x4 ld4_off(const float* base, unsigned byte_off) {
-    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
+template <int AUX>
+__device__ __forceinline__ float bld1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, AUX));
 }
 template <int CP, bool STATE, bool GOAL, int CHK = -1, bool EXACT = false>
 __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t, int lane_in, TileRegs<CP>& R) {
     const int C = EXACT ? CP : a.C, H = a.H, W = a.W;
-    const unsigned plane = (unsigned)(H * W), plane4 = plane * 4u;
+    const unsigned plane = (unsigned)(H * W), plane4 = plane * 4u, W4 = (unsigned)W * 4u;
     const int gch0 = C - a.goal_ch;
     const bool pending = a.pre_in != nullptr, use_alive = a.alive_ch >= 0, has_goal = a.goal_ch > 0;
     const float* const xb = a.x_in + (size_t)t.b * C * plane;
-    const float* const gb = has_goal ? a.goal + (size_t)t.b * a.goal_ch * plane : a.x_in;
     const size_t cell0 = (size_t)t.b * plane;
+    const __amdgpu_buffer_rsrc_t rx = nca_rsrc(xb);
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     const int hl = lane >> 5, l5 = lane & 31, q4 = lane >> 4, ci = lane & 15;
     const bool chk = CHK < 0 ? !t.inner : (CHK != 0);
     if (STATE && use_alive) {
-        const float* const ab = xb + (size_t)a.alive_ch * plane;
+        const __amdgpu_buffer_rsrc_t ra = nca_rsrc(xb + (size_t)a.alive_ch * plane);
+        if (!chk) {   // interior: one lane offset (columns >= 22 re-read column 21), rows step through the SGPR offset
+            const unsigned vo = (unsigned)(__mul24(t.ty0 - 3 + hl, W) + t.tx0 - 3 + min(l5, 21)) * 4u;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int gy = t.ty0 - 3 + 2 * k + hl, gx = t.tx0 - 3 + l5;
-            const bool ok = l5 < 22 && (!chk || (gy >= 0 && gy < H && gx >= 0 && gx < W));
-            R.a3v[k] = ldf_off(ab, ok ? (unsigned)(gy * W + gx) * 4u : 0u);
+            for (int k = 0; k < 5; ++k) R.a3v[k] = bld1<kAuxCoherent>(ra, vo, 2u * k * W4);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int gy = t.ty0 - 3 + 2 * k + hl, gx = t.tx0 - 3 + l5;
+                const bool ok = l5 < 22 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                R.a3v[k] = bld1<kAuxCoherent>(ra, ok ? (unsigned)(__mul24(gy, W) + gx) * 4u : 0u, 0u);
+            }
         }
     }
     if (STATE) {
         // always load (from a valid address when there is no pending mask): no branch, no wait at issue
-        const uint8_t* const pp = (pending && use_alive) ? a.pre_in + cell0 : reinterpret_cast<const uint8_t*>(xb);
+        const __amdgpu_buffer_rsrc_t rp = nca_rsrc((pending && use_alive) ? (const void*)(a.pre_in + cell0) : (const void*)xb);
+        if (!chk) {
+            const unsigned vo = (unsigned)(__mul24(t.ty0 - 2 + hl, W) + t.tx0 - 2 + min(l5, 19));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int gy = t.ty0 - 2 + 2 * k + hl, gx = t.tx0 - 2 + l5;
-            const bool ok = l5 < 20 && (!chk || (gy >= 0 && gy < H && gx >= 0 && gx < W));
-            R.prv[k] = pp[ok ? (unsigned)(gy * W + gx) : 0u];
+            for (int k = 0; k < 4; ++k) R.prv[k] = __builtin_amdgcn_raw_buffer_load_b8(rp, (int)vo, (int)(2u * k * (unsigned)W), kAuxCoherent);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int gy = t.ty0 - 2 + 2 * k + hl, gx = t.tx0 - 2 + l5;
+                const bool ok = l5 < 20 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                R.prv[k] = __builtin_amdgcn_raw_buffer_load_b8(rp, ok ? __mul24(gy, W) + gx : 0, 0, kAuxCoherent);
+            }
         }
     }
     if (STATE) {
         const int cgy = t.ty0 + q4, cgx = t.tx0 + ci;
         const bool cin = !chk || (cgy < H && cgx < W);
-        const unsigned pix = cin ? (unsigned)(cgy * W + cgx) : 0u;
+        const unsigned pix = cin ? (unsigned)(__mul24(cgy, W) + cgx) : 0u;
         // both sources are produced without touching the loaded value (a select here would wait for every load issued
         // so far); stage_tile picks one
-        R.uu = ldf_off(a.u ? a.u + cell0 : xb, a.u ? pix * 4u : 0u);
+        R.uu = bld1<0>(nca_rsrc(a.u ? (const void*)(a.u + cell0) : (const void*)xb), a.u ? pix * 4u : 0u, 0u);
         R.up = a.u ? 0.0f : nca_philox_cell(a.seed, a.step, cell0 + pix);
     }
+    const __amdgpu_buffer_rsrc_t rg = nca_rsrc(has_goal ? a.goal + (size_t)t.b * a.goal_ch * plane : xb);
     {
         const int fr = l5 >> 2, ff = l5 & 3, fgy = t.ty0 - 1 + fr, fgx = t.tx0 + 4 * ff;
         const bool fok = l5 < 24 && (!chk || (fgy >= 0 && fgy < H && fgx + 3 < W));
-        const unsigned foff4 = fok ? (unsigned)(fgy * W + fgx) * 4u : 0u;
+        const unsigned pix4 = fok ? (unsigned)(__mul24(fgy, W) + fgx) * 4u : 0u;
+        const unsigned vox = pix4 + (hl ? plane4 : 0u);   // channel 2k + hl: the 2k part rides in the SGPR offset
         if (STATE) {
 #pragma unroll
             for (int k = 0; k < CP / 2; ++k) {
-                const unsigned ch = EXACT ? (unsigned)(2 * k + hl) : (unsigned)min(2 * k + hl, C - 1);
-                R.xf[k] = ld4_off(xb, __umul24(ch, plane4) + foff4);
+                if (EXACT) R.xf[k] = bld4<kAuxCoherent>(rx, vox, 2u * k * plane4);
+                else R.xf[k] = bld4<kAuxCoherent>(rx, pix4 + __umul24((unsigned)min(2 * k + hl, C - 1), plane4), 0u);
             }
         }
         if (GOAL && has_goal) {
 #pragma unroll
             for (int k = 0; k < CP / 2; ++k) {
-                const unsigned gc = (unsigned)min(max(2 * k + hl - gch0, 0), a.goal_ch - 1);
-                R.gf[k] = ld4_off(gb, __umul24(gc, plane4) + foff4);
+                // goal channel 2k + hl - gch0; lanes below gch0 never use the value and read channel 0 instead
+                const int d = 2 * k - gch0;   // uniform
+                R.gf[k] = bld4<0>(rg, d >= 0 ? vox : pix4, d >= 0 ? (unsigned)d * plane4 : 0u);
             }
         }
     }
     {
         const int hr = ci >> 1, hgy = t.ty0 - 1 + hr, hgx = (ci & 1) ? t.tx0 + WTW : t.tx0 - 1;
         const bool hok = ci < 12 && (!chk || (hgy >= 0 && hgy < H && hgx >= 0 && hgx < W));
-        const unsigned hoff4 = hok ? (unsigned)(hgy * W + hgx) * 4u : 0u;
+        const unsigned pix4 = hok ? (unsigned)(__mul24(hgy, W) + hgx) * 4u : 0u;
+        const unsigned voh = pix4 + __umul24((unsigned)q4, plane4);   // channel 4k + q4
         if (STATE) {
 #pragma unroll
             for (int k = 0; k < CP / 4; ++k) {
-                const unsigned ch = EXACT ? (unsigned)(4 * k + q4) : (unsigned)min(4 * k + q4, C - 1);
-                R.xh[k] = ldf_off(xb, __umul24(ch, plane4) + hoff4);
+                if (EXACT) R.xh[k] = bld1<kAuxCoherent>(rx, voh, 4u * k * plane4);
+                else R.xh[k] = bld1<kAuxCoherent>(rx, pix4 + __umul24((unsigned)min(4 * k + q4, C - 1), plane4), 0u);
             }
         }
         if (GOAL && has_goal) {
 #pragma unroll
             for (int k = 0; k < CP / 4; ++k) {
-                const unsigned gc = (unsigned)min(max(4 * k + q4 - gch0, 0), a.goal_ch - 1);
-                R.gh[k] = ldf_off(gb, __umul24(gc, plane4) + hoff4);
+                const int d = 4 * k - gch0;   // uniform
+                if (d >= 0) R.gh[k] = bld1<0>(rg, voh, (unsigned)d * plane4);
+                else R.gh[k] = bld1<0>(rg, pix4 + __umul24((unsigned)max(4 * k + q4 - gch0, 0), plane4), 0u);
             }
         }
     }
@@ -330,7 +357,9 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
         const float uf = __uint_as_float(__float_as_uint(R.up) | (__float_as_uint(R.uu) & um));
         MK[lane] = (cin && wclamp(uf, 0.0f, 1.0f) < a.fire_rate) ? 1.0f : 0.0f;  // nca.py:171-174
         wave_sync();
-        if (cin && a.pre_out) a.pre_out[(size_t)t.b * plane + (unsigned)(cgy * W + cgx)] = (uint8_t)PN[(q4 + 1) * RS + ci + 4];
+        if (cin && a.pre_out)   // sc1: visible to the other XCDs at the grid barrier of a persistent launch
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)PN[(q4 + 1) * RS + ci + 4], nca_rsrc(a.pre_out + (size_t)t.b * plane),
+                                                 __mul24(cgy, W) + cgx, 0, kAuxCoherent);
     }
     NCA_STAMP(11);
     // ---- S4: z = x + goal * pre (nca.py:177) on halo 1; resolved state kept for the residual -----
@@ -722,30 +751,27 @@ __device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, const f32x4
 }
 
 // Pending state out: 16-byte stores, 4 per lane (item k -> channel 4k+q4, row (lane>>2)&3, group lane&3).
-template <int CP, bool CHECK, bool EXACT = false, bool NT_STORE = false>
+// WT: write-through at agent scope (sc1) -- the line goes to memory now instead of sitting dirty in the XCD's L2 until
+// the end-of-kernel write-back (measured: -4 us launch cadence), and between the fused steps of a persistent launch it
+// is what makes the new state visible to the other XCDs without a cache-wide write-back.
+template <int CP, bool CHECK, bool EXACT = false, bool WT = false>
 __device__ __forceinline__ void store_tile(const NcaCondArgs& a, const WTile& t, const float* __restrict__ XR, int lane_in) {
     const int C = EXACT ? CP : a.C, H = a.H, W = a.W;
-    const unsigned plane = (unsigned)(H * W);
+    const unsigned plane = (unsigned)(H * W), plane4 = plane * 4u;
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     const int q4 = lane >> 4, row = (lane >> 2) & 3, ff = lane & 3;
     const int gy = t.ty0 + row, gx = t.tx0 + 4 * ff;
     const bool ok = !CHECK || (gy < H && gx + 3 < W);
-    float* const ob = a.x_out + (size_t)t.b * C * plane + (ok ? (unsigned)(gy * W + gx) : 0u);
+    const __amdgpu_buffer_rsrc_t ro = nca_rsrc(a.x_out + (size_t)t.b * C * plane);
+    const unsigned vo = (ok ? (unsigned)(__mul24(gy, W) + gx) * 4u : 0u) + __umul24((unsigned)q4, plane4);
     wave_sync();
 #pragma unroll
     for (int k = 0; k < CP / 4; ++k) {
         const int ch = 4 * k + q4;
         const f32x4 v = ld4(XR + ch * XRS + row * WTW + 4 * ff);
-        if (ok && ch < C) {
-            // WT_STORE: write-through (system-scope) store -- the line goes to memory now instead of sitting dirty in
-            // the XCD's L2 until the end-of-kernel write-back, which otherwise sits between two step launches (measured:
-            // -4 us launch cadence; a plain `nt` hint changes nothing).  Inline asm: hipcc has no builtin for sc0 sc1 on
-            // a 16-byte store; the trailing s_nop covers the store-data hazard the compiler would otherwise handle.
-            if (NT_STORE)
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(ob + (unsigned)ch * plane), "v"(v) : "memory");
-            else st4(ob + (unsigned)ch * plane, v);
-        }
+        if (ok && ch < C)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, (int)vo, (int)(4u * k * plane4), WT ? kAuxCoherent : 0);
     }
 }
 
