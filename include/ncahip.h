@@ -47,8 +47,7 @@ int ncahip_limits(int *max_c, int *max_fc, int *max_hidden);
 
 /* Test hook (process-wide) selecting which kernel family serves the fused steps, so every variant can be checked
  * against the oracle on the same inputs: bit 0 = generic any-shape kernels instead of the aligned fast paths;
- * bit 1 = symmetric wave-private ConditionedNCA kernel instead of the default producer/consumer one;
- * bit 2 = ncahip_cond_grow_fwd_f32 issues one launch per step instead of the fused multi-step launch. */
+ * bit 1 = symmetric wave-private ConditionedNCA kernel instead of the default producer/consumer one. */
 int ncahip_debug_force_generic(int on);
 
 /* Device-side check that the MFMA operand/accumulator lane maps the kernels assume hold on

@@ -13,14 +13,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.fixture(scope="module", params=["fast", "generic", "wave", "perstep"])
+@pytest.fixture(scope="module", params=["fast", "generic", "wave"])
 def ops(request):
     """Every parity test runs twice: aligned fast-path kernels where the shape allows, and with the
     generic any-shape kernels forced (ncahip_debug_force_generic)."""
     assert torch.cuda.is_available(), "gpu tests need the MI355X"
     from ncahip import ops as _ops
     _ops.selftest()
-    _ops.force_generic({"fast": 0, "generic": 1, "wave": 2, "perstep": 4}[request.param])   # perstep: grow = one launch per step
+    _ops.force_generic({"fast": 0, "generic": 1, "wave": 2}[request.param])
     yield _ops
     _ops.force_generic(False)
 

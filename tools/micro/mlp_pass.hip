@@ -14,18 +14,7 @@ __global__ __launch_bounds__(256, 2) void pass_kernel(const float* __restrict__ 
     for (int i = tid; i < K::SHARED + 4 * 2048; i += 256) smem[i] = in[(i * 7 + blockIdx.x) & 0xFFFFF];
     __syncthreads();
     MlpRegs<CP> Wr;
-    struct { f32x4 b1[4], b2[4]; } Bs;
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(smem) + lane;
-        int o = 0;
-        for (int m = 0; m < 4; ++m) {
-            for (int q = 0; q < K::K1S4; ++q) Wr.w1[m][q] = src[64 * o++];
-            for (int m2 = 0; m2 < 4; ++m2) Wr.w2[m2][m] = src[64 * o++];
-            Wr.w3[0][m] = src[64 * o++];
-            Bs.b1[m] = src[64 * o++];
-            Bs.b2[m] = src[64 * o++];
-        }
-    }
+    mlp_load_regs<CP>(smem, lane, Wr);
     float* XR = smem + K::SHARED + wave * 2048;
     float* MK = XR + 16 * XRS;
     float P[NT][K::K1S];
@@ -33,14 +22,14 @@ __global__ __launch_bounds__(256, 2) void pass_kernel(const float* __restrict__ 
         for (int s = 0; s < K::K1S; ++s) P[n][s] = in[(lane * 31 + n * 17 + s) & 0xFFFFF];
     const unsigned long long c0 = clock64();
     for (int it = 0; it < iters; ++it) {
-        if (VAR == 0) mlp_tile_regs<CP, NT>(Wr, Bs.b1, Bs.b2, XR, MK, lane, 0, P);
+        if (VAR == 0) mlp_tile_regs<CP, NT>(Wr, XR, MK, lane, 0, P);
         if (VAR == 1) {   // same MFMA count and dependency structure, no relu
             f32x4 acc2[4][NT];
-            for (int m2 = 0; m2 < 4; ++m2) for (int n = 0; n < NT; ++n) acc2[m2][n] = Bs.b2[m2];
+            for (int m2 = 0; m2 < 4; ++m2) for (int n = 0; n < NT; ++n) acc2[m2][n] = Wr.b2[m2];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 f32x4 acc1[NT];
-                for (int n = 0; n < NT; ++n) acc1[n] = Bs.b1[m];
+                for (int n = 0; n < NT; ++n) acc1[n] = Wr.b1[m];
 #pragma unroll
                 for (int s = 0; s < K::K1S; ++s)
 #pragma unroll
@@ -63,11 +52,11 @@ __global__ __launch_bounds__(256, 2) void pass_kernel(const float* __restrict__ 
         }
         if (VAR == 2 || VAR == 3) {   // relus of one hidden tile issued as ONE group (VAR 3: fenced with sched_barrier)
             f32x4 acc2[4][NT];
-            for (int m2 = 0; m2 < 4; ++m2) for (int n = 0; n < NT; ++n) acc2[m2][n] = Bs.b2[m2];
+            for (int m2 = 0; m2 < 4; ++m2) for (int n = 0; n < NT; ++n) acc2[m2][n] = Wr.b2[m2];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 f32x4 acc1[NT];
-                for (int n = 0; n < NT; ++n) acc1[n] = Bs.b1[m];
+                for (int n = 0; n < NT; ++n) acc1[n] = Wr.b1[m];
 #pragma unroll
                 for (int s = 0; s < K::K1S; ++s)
 #pragma unroll

@@ -34,13 +34,6 @@ def run(tag, seed=0):
     L.nca_debug_set_stamp_buffer_pc(None)
     k = buf[NWG * 8 * 8 * 16:].cpu().numpy().reshape(NWG, 8, 8).astype(np.float64)
     v = k[:, 0:4]
-    if seed == 0:
-        pw = k[:, 4:8]
-        print("   producer tile 0: entry->loads issued %.0f   wp fill %.0f   stage %.0f   perception+P write %.0f   (arrive at barrier %.0f)" % (
-            np.median(pw[..., 4] - pw[..., 0]), np.median(pw[..., 5] - pw[..., 4]), np.median(pw[..., 6] - pw[..., 5]),
-            np.median(pw[..., 1] - pw[..., 6]), np.median(pw[..., 1] - pw[..., 0])))
-        print("   consumer: entry->weights issued + biases %.0f   weights landed %.0f   (arrive at barrier %.0f)" % (
-            np.median(v[..., 4] - v[..., 0]), np.median(v[..., 5] - v[..., 4]), np.median(v[..., 1] - v[..., 0])))
     print(f"{tag:34s} startup {np.median(v[..., 2] - v[..., 0]):7.0f}   loop {np.median(v[..., 3] - v[..., 2]):8.0f} = {np.median(v[..., 3] - v[..., 2]) / 8:7.0f} per tile   whole {np.median(v[..., 3] - v[..., 0]):8.0f} cycles")
 
 run("normal")
@@ -48,32 +41,3 @@ run("idle producers", 0xD1A6)
 run("idle consumers", 0xD1A7)
 run("consumer: no perception", 0xD1A8)
 run("consumer: no MLP", 0xD1A9)
-
-# fused launch: stamps of step 1 (warm) inside an 8-step persistent launch
-states = torch.empty(2, B, C, H, W, device=dev); states[0].copy_(x)
-prebuf = torch.empty(2, B, H, W, device=dev, dtype=torch.uint8)
-outb = torch.empty_like(x)
-def grow(T):
-    ops.check(L.ncahip_cond_grow_fwd_f32(states.data_ptr(), prebuf.data_ptr(), 2, T, outb.data_ptr(), goal.data_ptr(), 12, None,
-                                         w.wp.data_ptr(), w.w1.data_ptr(), w.b1.data_ptr(), w.w2.data_ptr(), w.b2.data_ptr(), w.w3.data_ptr(),
-                                         B, C, H, W, 64, 3, 0.1, 0.5, -10.0, 10.0, 42, 0, torch.cuda.current_stream().cuda_stream), "grow")
-grow(8); torch.cuda.synchronize()
-buf.zero_()
-L.nca_debug_set_stamp_buffer_pc(buf.data_ptr())
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record(); grow(8); e1.record(); torch.cuda.synchronize()
-L.nca_debug_set_stamp_buffer_pc(None)
-print("fused 8-step grow: %.1f us per step (events, incl. finalize)" % (e0.elapsed_time(e1) * 1e3 / 8))
-k = buf[NWG * 8 * 8 * 16:].cpu().numpy().reshape(NWG, 8, 8).astype(np.float64)
-for nm, sl in (("consumers", slice(0, 4)), ("producers", slice(4, 8))):
-    v = k[:, sl]
-    print(f"  {nm}: step start -> first-tile barrier arrive {np.median(v[..., 1] - v[..., 0]):.0f}  wait {np.median(v[..., 2] - v[..., 1]):.0f}   "
-          f"tile loop {np.median(v[..., 3] - v[..., 2]):.0f} = {np.median(v[..., 3] - v[..., 2]) / 8:.0f}/tile   grid barrier {np.median(v[..., 7] - v[..., 3]):.0f}   step total {np.median(v[..., 7] - v[..., 0]):.0f}")
-v = k[:, 0]
-loop = v[:, 3] - v[:, 0]
-gb = v[:, 7] - v[:, 3]
-print("  per-WG (wave 0): step work (start->loop end) min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f" % (loop.min(), np.percentile(loop, 10), np.median(loop), np.percentile(loop, 90), loop.max()))
-print("  per-WG grid barrier wait: min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f" % (gb.min(), np.percentile(gb, 10), np.median(gb), np.percentile(gb, 90), gb.max()))
-idx = np.argsort(loop)[-8:]
-print("  slowest WGs:", idx.tolist(), " their work:", loop[idx].astype(int).tolist())
-print("  work by XCD (wg % 8): ", [int(np.median(loop[x::8])) for x in range(8)])

@@ -67,7 +67,7 @@ int ncahip_version(void) { return NCAHIP_VERSION; }
 const char* ncahip_last_error(void) { return g_err; }
 
 int ncahip_debug_force_generic(int on) {
-    nca_set_force_generic(on & 5);           // bit 0: generic any-shape kernels; bit 2: one launch per grow step
+    nca_set_force_generic((on & 1) != 0);    // bit 0: generic any-shape kernels
     nca_set_cond_variant((on >> 1) & 1);     // bit 1: symmetric wave-private ConditionedNCA kernel instead of producer/consumer
     return 0;
 }
@@ -175,24 +175,7 @@ int ncahip_cond_grow_fwd_f32(float* states, uint8_t* pre, int ring, int T, float
     const int sl = T % ring;
     if (x_final == states + (size_t)sl * slot && alive_ch >= 0)
         return fail(NCAHIP_EINVAL, "cond grow: x_final must not alias the last state slot");
-    // Fused path: all T steps in one cooperative launch of the producer/consumer kernel (grid barrier between steps).
-    NcaCondArgs a0{states, nullptr, states + slot, pre + pslot, goal, u, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch,
-                   alive_ch, alive_thr, fire_rate, clamp_lo, clamp_hi, seed, step0};
-    bool fused = false;
-    if (T > 1 && nca_cond_pc_eligible(a0)) {
-        unsigned* sync = nullptr;
-        if (hipMallocAsync((void**)&sync, 64, st) == hipSuccess) {
-            hipError_t e = hipMemsetAsync(sync, 0, 64, st);
-            if (e == hipSuccess) e = nca_launch_cond_grow_fwd_pc(a0, NcaGrowLoop{states, pre, ring, T, sync}, st);
-            (void)hipFreeAsync(sync, st);
-            if (e == hipSuccess) fused = true;
-            else if (e != hipErrorNotSupported) return hip_result(e, "cond_grow_fwd (fused)");
-            else (void)hipGetLastError();
-        } else {
-            (void)hipGetLastError();
-        }
-    }
-    for (int t = 0; t < T && !fused; ++t) {
+    for (int t = 0; t < T; ++t) {
         const int si = t % ring, so = (t + 1) % ring;
         NcaCondArgs a{states + (size_t)si * slot, t == 0 ? nullptr : pre + (size_t)si * pslot,
                       states + (size_t)so * slot, pre + (size_t)so * pslot, goal,
@@ -239,6 +222,8 @@ int ncahip_cond_grow_bwd_f32(const float* states, const uint8_t* pre, int T, con
     if (goal_ch > 0 && !g_goal) return fail(NCAHIP_EINVAL, "cond grow bwd: g_goal required when goal_ch > 0");
     if (W % 4 != 0 || ((uintptr_t)states | (uintptr_t)goal | (uintptr_t)g_final | (uintptr_t)g_x0 | (uintptr_t)workspace) % 16 != 0)
         return fail(NCAHIP_ERANGE, "cond grow bwd: needs W %% 4 == 0 and 16-byte aligned buffers");
+    if ((size_t)H * W >= ((size_t)1 << 24) || (size_t)16 * H * W * 4 >= ((size_t)1 << 32))
+        return fail(NCAHIP_ERANGE, "cond grow bwd: grid too large for the tile kernels' 32-bit addressing (H*W < 2^24)");
     if (workspace_bytes < ncahip_cond_grow_bwd_workspace(B, C, H, W, hidden))
         return fail(NCAHIP_EINVAL, "cond grow bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;

@@ -158,11 +158,11 @@ struct TileRegs {
 // Addressing: raw buffer loads -- <buffer resource of the batch item (SGPRs)> + <32-bit VGPR byte offset shared by a
 // whole group of loads> + <uniform SGPR offset that steps through channels / rows>: no per-load vector arithmetic at all
 // on interior tiles.  Needs H*W < 2^24 and C*H*W*4 < 2^32 (checked by the dispatch in nca_step_fwd.hip; larger grids
-// take the generic kernel).  State-type tensors (x, pre mask: rewritten by other XCDs between the fused steps of a
-// persistent launch) are read with sc1 = agent scope, i.e. coherently, never from a stale non-coherent L2 line; the goal
-// encoding and the weights are read-only for the whole launch and stay ordinary cached loads.
+// take the generic kernel).  kAuxCoherent selects the cache policy of the state-type loads (x, pre mask): 0 = ordinary
+// cached loads (a step launch reads only what earlier launches wrote); 16 = sc1, agent-scope coherent -- what a fused
+// multi-step launch with grid barriers needs (tried and measured slower: DESIGN.md section 4).
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr int kAuxCoherent = 16;   // sc1
+constexpr int kAuxCoherent = 0;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t nca_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
 }
@@ -274,7 +274,7 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
 
 // Resolve the pending life mask, build z = x + goal*pre in LDS (halo 1), keep the resolved state for
 // the residual.  CHECK=false: no bounds logic.
-template <int CP, bool CHECK, bool EXACT = false, int ZCS = CS>
+template <int CP, bool CHECK, bool EXACT = false>
 __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t, const TileLds& L, int lane_in,
                                            const TileRegs<CP>& R, int tile_no) {
     float* const Z = L.Z;
@@ -357,7 +357,7 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
         const float uf = __uint_as_float(__float_as_uint(R.up) | (__float_as_uint(R.uu) & um));
         MK[lane] = (cin && wclamp(uf, 0.0f, 1.0f) < a.fire_rate) ? 1.0f : 0.0f;  // nca.py:171-174
         wave_sync();
-        if (cin && a.pre_out)   // sc1: visible to the other XCDs at the grid barrier of a persistent launch
+        if (cin && a.pre_out)
             __builtin_amdgcn_raw_buffer_store_b8((uint8_t)PN[(q4 + 1) * RS + ci + 4], nca_rsrc(a.pre_out + (size_t)t.b * plane),
                                                  __mul24(cgy, W) + cgx, 0, kAuxCoherent);
     }
@@ -387,7 +387,7 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
         for (int k = 0; k < CP / 2; ++k) {  // goal encoding (issued at the top of staging) consumed last
             const int ch = 2 * k + hl;
             if (has_goal && ch >= gch0 && ch < C && fok) v[k] = __builtin_elementwise_fma(R.gf[k], pn, v[k]);
-            st4(Z + ch * ZCS + fr * RS + 4 + 4 * ff, v[k]);
+            st4(Z + ch * CS + fr * RS + 4 + 4 * ff, v[k]);
         }
     }
     NCA_STAMP(13);
@@ -403,7 +403,7 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
             if (pending) v = wclamp(v * lf, a.lo, a.hi);
             if (!hok || ch >= C) v = 0.0f;
             else if (has_goal && ch >= gch0) v = fmaf(R.gh[k], pn, v);
-            Z[ch * ZCS + hr * RS + zq] = v;
+            Z[ch * CS + hr * RS + zq] = v;
         }
     }
     wave_sync();
@@ -450,56 +450,6 @@ __device__ __forceinline__ void perceive_tile(const float* __restrict__ WS, cons
             P[1][3 * c4 + f] = acc[1];
         }
         __builtin_amdgcn_sched_barrier(0);  // one channel group's 27 taps live at a time (else hipcc hoists all 4 x 28)
-    }
-}
-
-// Perception of all WTH = 4 tile rows by ONE wave, "g-major" feature order: lane group g owns channels g*CP/4 + c4, so the
-// 3*CP/4 values a lane produces are the contiguous raw features K1S*g + s (s = 3*c4 + f) and every UpdateNet A operand is a
-// plain 16-byte slice of the untouched weight tensors (mlp_load_regs_global).  ZCS: channel stride of Z with
-// (CP/4)*ZCS % 32 == 16, i.e. the four lane groups read disjoint banks.  WPL: [CP][28] copy of the perception weights.
-template <int CP, int ZCS>
-__device__ __forceinline__ void perceive_rows4(const float* __restrict__ WPL, const float* __restrict__ Z, int lane_in,
-                                               float (&P)[4][3 * CP / 4]) {
-    static_assert(((CP / 4) * ZCS) % 32 == 16, "bank layout of the g-major tile");
-    int lane = lane_in;
-    asm volatile("" : "+v"(lane));
-    const int g = lane >> 4, ci = lane & 15;
-#pragma unroll
-    for (int c4 = 0; c4 < CP / 4; ++c4) {
-        const int ch = (CP / 4) * g + c4;
-        const float* const zc = Z + ch * ZCS + ci + 3;
-        float wt[28];
-#pragma unroll
-        for (int j4 = 0; j4 < 7; ++j4) {
-            const f32x4 w4 = ld4(WPL + ch * 28 + 4 * j4);
-            wt[4 * j4 + 0] = w4[0]; wt[4 * j4 + 1] = w4[1]; wt[4 * j4 + 2] = w4[2]; wt[4 * j4 + 3] = w4[3];
-        }
-        // row pairs (r, r+1), r = 0..4, at the three column taps: one ds_read2_b32 each, straight into an aligned pair
-        const unsigned za = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)zc;
-        f32x2 nb[5][3];
-#define NCA_RD2(r, d) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(nb[r][d]) : "v"(za), "n"((r) * RS + (d)), "n"(((r) + 1) * RS + (d)))
-        NCA_RD2(0, 0); NCA_RD2(0, 1); NCA_RD2(0, 2); NCA_RD2(1, 0); NCA_RD2(1, 1); NCA_RD2(1, 2);
-        NCA_RD2(2, 0); NCA_RD2(2, 1); NCA_RD2(2, 2); NCA_RD2(3, 0); NCA_RD2(3, 1); NCA_RD2(3, 2);
-        NCA_RD2(4, 0); NCA_RD2(4, 1); NCA_RD2(4, 2);
-#undef NCA_RD2
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(nb[0][0]), "+v"(nb[0][1]), "+v"(nb[0][2]), "+v"(nb[1][0]), "+v"(nb[1][1]), "+v"(nb[1][2]), "+v"(nb[2][0]),
-                       "+v"(nb[2][1]), "+v"(nb[2][2]), "+v"(nb[3][0]), "+v"(nb[3][1]), "+v"(nb[3][2]), "+v"(nb[4][0]), "+v"(nb[4][1]),
-                       "+v"(nb[4][2])
-                     :: "memory");
-#pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};   // output rows (0,1) and (2,3); tap order as nca.py's conv
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const f32x2 w2 = {wt[9 * f + t], wt[9 * f + t]};
-                lo = __builtin_elementwise_fma(w2, nb[t / 3][t % 3], lo);
-                hi = __builtin_elementwise_fma(w2, nb[2 + t / 3][t % 3], hi);
-            }
-            P[0][3 * c4 + f] = lo[0]; P[1][3 * c4 + f] = lo[1];
-            P[2][3 * c4 + f] = hi[0]; P[3][3 * c4 + f] = hi[1];
-        }
-        __builtin_amdgcn_sched_barrier(0);  // one channel group's taps live at a time
     }
 }
 
@@ -603,56 +553,25 @@ __device__ __forceinline__ void mlp_tile(const NcaCondArgs& a, const float* __re
 template <int CP>
 struct MlpRegs {
     using K = WCfg<CP>;
-    f32x4 w1[4][K::K1S4], w2[4][4], w3[K::M3T][4];
+    f32x4 w1[4][K::K1S4], w2[4][4], w3[K::M3T][4], b1[4], b2[4];
 };
-// Straight from the weight tensors (nca.py:40-46 layouts: w1 [hid][3C], w2 [hid][hid], w3 [C][hid]) for the g-major
-// feature order of perceive_rows4.  VEC: C == CP == 16, hidden == 64, 16-byte aligned tensors -> 32 coalesced 16-byte loads.
-template <int CP, bool VEC>
-__device__ __forceinline__ void mlp_load_regs_global(const NcaCondArgs& a, int lane, MlpRegs<CP>& R) {
+template <int CP>
+__device__ __forceinline__ void mlp_load_regs(const float* __restrict__ WS, int lane, MlpRegs<CP>& R) {
     using K = WCfg<CP>;
-    const int g = lane >> 4, i = lane & 15;
-    if (VEC) {
-        static_assert(!VEC || CP == 16, "vector operand loads need 3C/4 % 4 == 0");
+    const f32x4* const W1V = reinterpret_cast<const f32x4*>(WS + K::OFF_W1) + lane;
+    const f32x4* const W2V = reinterpret_cast<const f32x4*>(WS + K::OFF_W2) + lane;
+    const f32x4* const W3V = reinterpret_cast<const f32x4*>(WS + K::OFF_W3) + lane;
+    const int g = lane >> 4;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < 4; ++m) {
 #pragma unroll
-            for (int q = 0; q < K::K1S4; ++q) R.w1[m][q] = ld4(a.w1 + (16 * m + i) * (3 * CP) + K::K1S * g + 4 * q);
+        for (int q = 0; q < K::K1S4; ++q) R.w1[m][q] = W1V[(m * K::K1S4 + q) * 64];
 #pragma unroll
-            for (int m2 = 0; m2 < 4; ++m2) R.w2[m2][m] = ld4(a.w2 + (16 * m2 + i) * 64 + 16 * m + 4 * g);
-            R.w3[0][m] = ld4(a.w3 + i * 64 + 16 * m + 4 * g);
-        }
-    } else {
-        const int C = a.C, hid = a.hidden, K1 = 3 * C;
+        for (int m2 = 0; m2 < 4; ++m2) R.w2[m2][m] = W2V[(m2 * 4 + m) * 64];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-#pragma unroll
-            for (int q = 0; q < K::K1S4; ++q)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int s = 4 * q + j, ch = (CP / 4) * g + s / 3, f = s % 3, o = 16 * m + i;
-                    const bool ok = s < K::K1S && ch < C && o < hid;
-                    const float v = a.w1[ok ? o * K1 + 3 * ch + f : 0];
-                    R.w1[m][q][j] = ok ? v : 0.0f;
-                }
-#pragma unroll
-            for (int m2 = 0; m2 < 4; ++m2)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = 16 * m2 + i, k = 16 * m + 4 * g + r;
-                    const bool ok = o < hid && k < hid;
-                    const float v = a.w2[ok ? o * hid + k : 0];
-                    R.w2[m2][m][r] = ok ? v : 0.0f;
-                }
-#pragma unroll
-            for (int m3 = 0; m3 < K::M3T; ++m3)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = 16 * m3 + i, k = 16 * m + 4 * g + r;
-                    const bool ok = o < C && k < hid;
-                    const float v = a.w3[ok ? o * hid + k : 0];
-                    R.w3[m3][m][r] = ok ? v : 0.0f;
-                }
-        }
+        for (int m3 = 0; m3 < K::M3T; ++m3) R.w3[m3][m] = W3V[(m3 * 4 + m) * 64];
+        R.b1[m] = ld4(WS + K::OFF_B1 + 16 * m + 4 * g);
+        R.b2[m] = ld4(WS + K::OFF_B2 + 16 * m + 4 * g);
     }
 }
 // mlp_tile with register-resident operands (same MFMA order per accumulator => bit-identical results).
@@ -662,9 +581,8 @@ __device__ __forceinline__ void mlp_load_regs_global(const NcaCondArgs& a, int l
 // tile m+1 is issued BEFORE the ReLU group of tile m so that group never waits for the chain it reads.
 // XR must provide 16*M3T channel rows.
 template <int CP, int NT>
-__device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, const f32x4 (&b1)[4], const f32x4 (&b2)[4],
-                                              float* __restrict__ XR, const float* __restrict__ MK, int lane_in, int n0,
-                                              const float (&P)[NT][3 * CP / 4]) {
+__device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, float* __restrict__ XR, const float* __restrict__ MK,
+                                              int lane_in, int n0, const float (&P)[NT][3 * CP / 4]) {
     using K = WCfg<CP>;
     int lane_o = lane_in;
     asm volatile("" : "+v"(lane_o));
@@ -673,10 +591,10 @@ __device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, const f32x4
 #pragma unroll
     for (int m2 = 0; m2 < 4; ++m2)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc2[m2][n] = b2[m2];
+        for (int n = 0; n < NT; ++n) acc2[m2][n] = Wr.b2[m2];
     auto layer1 = [&](int m, f32x4 (&acc)[NT]) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[n] = b1[m];
+        for (int n = 0; n < NT; ++n) acc[n] = Wr.b1[m];
 #pragma unroll
         for (int s = 0; s < K::K1S; ++s)
 #pragma unroll
@@ -752,8 +670,7 @@ __device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, const f32x4
 
 // Pending state out: 16-byte stores, 4 per lane (item k -> channel 4k+q4, row (lane>>2)&3, group lane&3).
 // WT: write-through at agent scope (sc1) -- the line goes to memory now instead of sitting dirty in the XCD's L2 until
-// the end-of-kernel write-back (measured: -4 us launch cadence), and between the fused steps of a persistent launch it
-// is what makes the new state visible to the other XCDs without a cache-wide write-back.
+// the end-of-kernel write-back (measured: -4 us launch cadence; a plain `nt` hint changes nothing).
 template <int CP, bool CHECK, bool EXACT = false, bool WT = false>
 __device__ __forceinline__ void store_tile(const NcaCondArgs& a, const WTile& t, const float* __restrict__ XR, int lane_in) {
     const int C = EXACT ? CP : a.C, H = a.H, W = a.W;
@@ -771,7 +688,7 @@ __device__ __forceinline__ void store_tile(const NcaCondArgs& a, const WTile& t,
         const int ch = 4 * k + q4;
         const f32x4 v = ld4(XR + ch * XRS + row * WTW + 4 * ff);
         if (ok && ch < C)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, (int)vo, (int)(4u * k * plane4), WT ? kAuxCoherent : 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, (int)vo, (int)(4u * k * plane4), WT ? 16 : 0);
     }
 }
 

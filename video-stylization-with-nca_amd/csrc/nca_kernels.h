@@ -66,26 +66,13 @@ hipError_t nca_launch_dynca_step_bwd(const NcaDyncaArgs& a, hipStream_t st);
 hipError_t nca_launch_cond_step_fwd_wave(const NcaCondArgs& a, hipStream_t st);
 // producer/consumer wave-specialised variant (nca_cond_pc.hip); same preconditions
 hipError_t nca_launch_cond_step_fwd_pc(const NcaCondArgs& a, hipStream_t st);
-// T fused steps of the grow loop in ONE cooperative launch (nca_cond_pc.hip): step t reads states[t % ring] (pending with
-// pre[t % ring] for t > 0) and writes states[(t+1) % ring], pre[(t+1) % ring]; a grid barrier separates the steps.
-// `a` carries everything that is constant over the loop (x_in/pre_in/x_out/pre_out/step are ignored; a.u is the uniform
-// tensor of step 0 or null, a.step the first step number).  Returns hipErrorNotSupported when the shape / device cannot
-// take the persistent path (caller falls back to one launch per step).
-struct NcaGrowLoop {
-    float* states;
-    uint8_t* pre;
-    int ring, T;
-    unsigned* sync;   // [0] arrival counter (zeroed before the launch), [1] abort flag
-};
-hipError_t nca_launch_cond_grow_fwd_pc(const NcaCondArgs& a, const NcaGrowLoop& g, hipStream_t st);
-bool nca_cond_pc_eligible(const NcaCondArgs& a);
 void nca_set_cond_variant(int v);  // 0 = producer/consumer (default), 1 = symmetric wave-private
 
 // diagnostic build hook (-DNCA_STAMPS): buffer that receives s_memtime stamps, [wave][tile][8]
 void nca_debug_set_stamp_buffer(unsigned long long* p);
 
 // test hook: route every fused step through the generic (any-shape) kernels
-void nca_set_force_generic(int bits);  // bit 0: generic any-shape kernels; bit 2: no fused multi-step grow launch
+void nca_set_force_generic(bool on);
 
 // stencils and small kernels (nca_stencil.hip)
 hipError_t nca_launch_dynca_perceive(const float* x, float* y, int B, int C, int H, int W, int pad, hipStream_t st);

@@ -928,9 +928,9 @@ hipError_t launch_cond(const NcaCondArgs& a, hipStream_t st) {
 
 }  // namespace
 
-static int g_force_generic = (getenv("NCAHIP_FORCE_GENERIC") ? 1 : 0) | (getenv("NCAHIP_NO_PERSISTENT") ? 4 : 0);   // bit 0 generic, bit 2 no fused grow launch
+static bool g_force_generic = getenv("NCAHIP_FORCE_GENERIC") != nullptr;
 static int g_cond_variant = getenv("NCAHIP_COND_VARIANT") ? atoi(getenv("NCAHIP_COND_VARIANT")) : 0;
-void nca_set_force_generic(int bits) { g_force_generic = bits & 5; }
+void nca_set_force_generic(bool on) { g_force_generic = on; }
 void nca_set_cond_variant(int v) { g_cond_variant = v; }
 
 // ---- dispatch: smallest instantiation that covers (C, fc); padding lanes carry zero weights ---
@@ -952,21 +952,12 @@ hipError_t nca_launch_dynca_step_bwd(const NcaDyncaArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-// 0: generic any-shape kernel, 1: symmetric wave-private kernel, 2: producer/consumer kernel
-static int cond_fast_path(const NcaCondArgs& a) {
+hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st) {
     // the tile kernels address with 32-bit byte offsets from the batch item's base (issue_loads): H*W < 2^24, C*H*W*4 < 2^32
     const bool small = (size_t)a.H * a.W < ((size_t)1 << 24) && (size_t)16 * a.H * a.W * 4 < ((size_t)1 << 32);
-    if (!(g_force_generic & 1) && small && a.C <= 16 && (a.W % 4 == 0) && aligned16(a.x_in) && aligned16(a.x_out) &&
+    if (!g_force_generic && small && a.C <= 16 && (a.W % 4 == 0) && aligned16(a.x_in) && aligned16(a.x_out) &&
         (a.goal == nullptr || aligned16(a.goal)))
-        return g_cond_variant == 1 ? 1 : 2;
-    return 0;
-}
-bool nca_cond_pc_eligible(const NcaCondArgs& a) { return cond_fast_path(a) == 2 && !(g_force_generic & 4); }
-
-hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st) {
-    const int path = cond_fast_path(a);
-    if (path == 1) return nca_launch_cond_step_fwd_wave(a, st);
-    if (path == 2) return nca_launch_cond_step_fwd_pc(a, st);
+        return g_cond_variant == 1 ? nca_launch_cond_step_fwd_wave(a, st) : nca_launch_cond_step_fwd_pc(a, st);
     if (a.C <= 12) return launch_cond<12>(a, st);
     if (a.C <= 16) return launch_cond<16>(a, st);
     return hipErrorInvalidValue;

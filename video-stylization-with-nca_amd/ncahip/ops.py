@@ -35,7 +35,7 @@ def _w(t: torch.Tensor, name: str, like: torch.Tensor) -> torch.Tensor:
 
 def force_generic(on) -> None:
     """Test hook (see ncahip.h): True/1 = generic any-shape kernels, 2 = symmetric wave-private ConditionedNCA
-    kernel, 4 = cond_grow issues one launch per step instead of the fused multi-step launch, False/0 = defaults."""
+    kernel, False/0 = defaults."""
     lib().ncahip_debug_force_generic(int(on))
 
 
