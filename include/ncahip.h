@@ -142,6 +142,34 @@ int ncahip_cond_finalize_f32(const float *x_pend, const uint8_t *pre, float *x_o
                              int B, int C, int H, int W, int alive_ch, float alive_thr,
                              float clamp_lo, float clamp_hi, ncahip_stream_t stream);
 
+/* ---- bf16 state storage ---------------------------------------------------------------------
+ * The same step / finalize / grow loop with the state and the goal encoding stored as bf16 (uint16_t bit patterns,
+ * [B,C,H,W] contiguous) and the UpdateNet on bf16 MFMA; weights, biases and explicit uniforms stay fp32.  Rounding
+ * points (restated by oracle.cond_step_bf16): perception in f32 from the widened state; the perception vector, both
+ * hidden activations and the weights are rounded to bf16 (RNE) as matrix operands, accumulation in f32; x' = x + mask*out
+ * in f32, rounded to bf16 on store.  Replaces the same reference code as the _f32 entry points (nca.py:181-195, :207-208)
+ * for callers that keep the pool in bf16 (BASELINE configs[2]).  Needs W % 4 == 0 and 8-byte aligned tensors
+ * (NCAHIP_ERANGE otherwise; there is no any-shape bf16 kernel).                                                      */
+int ncahip_cond_step_fwd_bf16(const uint16_t *x_in, const uint8_t *pre_in, uint16_t *x_out, uint8_t *pre_out,
+                              const uint16_t *goal, int goal_ch, const float *u,
+                              const float *wp, const float *w1, const float *b1,
+                              const float *w2, const float *b2, const float *w3,
+                              int B, int C, int H, int W, int hidden,
+                              int alive_ch, float alive_thr, float fire_rate,
+                              float clamp_lo, float clamp_hi, uint64_t seed, uint64_t step,
+                              ncahip_stream_t stream);
+int ncahip_cond_finalize_bf16(const uint16_t *x_pend, const uint8_t *pre, uint16_t *x_out,
+                              int B, int C, int H, int W, int alive_ch, float alive_thr,
+                              float clamp_lo, float clamp_hi, ncahip_stream_t stream);
+int ncahip_cond_grow_fwd_bf16(uint16_t *states, uint8_t *pre, int ring, int T, uint16_t *x_final,
+                              const uint16_t *goal, int goal_ch, const float *u,
+                              const float *wp, const float *w1, const float *b1,
+                              const float *w2, const float *b2, const float *w3,
+                              int B, int C, int H, int W, int hidden,
+                              int alive_ch, float alive_thr, float fire_rate,
+                              float clamp_lo, float clamp_hi, uint64_t seed, uint64_t step0,
+                              ncahip_stream_t stream);
+
 /* ConditionedNCA.alive(x)                   EncoderConditioning/nca.py:152-163 -> uint8 [B,H,W] */
 int ncahip_cond_alive_u8(const float *x, uint8_t *out, int B, int C, int H, int W,
                          int alive_ch, float alive_thr, ncahip_stream_t stream);

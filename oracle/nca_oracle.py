@@ -415,3 +415,32 @@ def cond_step_np(x, goal_enc, u, prm, alive_ch, thr=0.1, fire_rate=0.5):
     post = alive(np.asarray(x1[:, alive_ch], dtype=np.float32))
     life = (pre & post).astype(np.float64)[:, None]
     return np.clip(x1 * life, -10.0, 10.0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bf16-storage restatement of the ConditionedNCA step (what ncahip_cond_*_bf16 computes; there is no reference
+# code for it -- the reference is fp32 only, nca.py:181-195 -- so this states the rounding points of include/ncahip.h:
+# bf16 state/goal, f32 perception, bf16 matrix operands with f32 accumulation, bf16 store).  "parity unpinned" by
+# reference fixtures by construction; it is pinned to the fp32 oracle through the bound tested in tests/.
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def cond_step_bf16(x, goal_pad, u, prm, alive_ch=3, thr=0.1, fire_rate=0.5, lo=-10.0, hi=10.0):
+    """x, goal_pad: float32 tensors holding bf16-representable values ([B,C,H,W]; goal_pad already padded to C channels).
+    Returns (x_next, pre, x_pending): x_next = resolved next state (bf16-representable float32)."""
+    pre = cond_alive(x, alive_ch, thr) if alive_ch >= 0 else torch.ones_like(x[:, :1], dtype=torch.bool)
+    z = x + goal_pad * pre.float()
+    p = cond_perceive(z, prm["perception_net.weight"])
+    w1 = _bf(prm["update_net.out.0.weight"].flatten(1)); w2 = _bf(prm["update_net.out.2.weight"].flatten(1))
+    w3 = _bf(prm["update_net.out.4.weight"].flatten(1))
+    B, K, H, W = p.shape
+    pm = _bf(p).permute(0, 2, 3, 1).reshape(-1, K).double()
+    h1 = torch.relu(pm @ w1.double().t() + prm["update_net.out.0.bias"].double())
+    h2 = torch.relu(_bf(h1.float()).double() @ w2.double().t() + prm["update_net.out.2.bias"].double())
+    out = (_bf(h2.float()).double() @ w3.double().t()).float().reshape(B, H, W, -1).permute(0, 3, 1, 2)
+    mask = (u.clamp(0.0, 1.0) < fire_rate).float().reshape(B, 1, H, W)
+    x_pend = _bf(x + mask * out)
+    post = cond_alive(x_pend, alive_ch, thr) if alive_ch >= 0 else torch.ones_like(pre)
+    x_next = (x_pend * (pre & post).float()).clamp(lo, hi)
+    return x_next, pre, x_pend

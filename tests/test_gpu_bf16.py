@@ -1,0 +1,154 @@
+"""bf16 state storage: ncahip_cond_{step_fwd,finalize,grow_fwd}_bf16 against the oracle's cond_step_bf16 (the rounding
+points of include/ncahip.h restated on the CPU) and against the fp32 oracle.  The reference is fp32 only, so there is no
+golden fixture for this path ("parity unpinned" by reference data); it is pinned to the fp32 step through the error
+bound below.  Tolerances: bf16 has 8 significand bits; GPU and oracle differ only in f32 accumulation order, which can
+flip the final rounding of an element by one bf16 ulp (2^-8 relative)."""
+import pytest
+import torch
+
+from oracle import nca_oracle as O
+from util import load, T
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ULP = 2.0 ** -8
+
+
+def bfr(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def make_case(C, B, H, W, gch, seed=0, hidden=64):
+    g = torch.Generator().manual_seed(seed)
+    prm = {"perception_net.weight": (torch.rand(3 * C, 1, 3, 3, generator=g) - 0.5) * 0.6,
+           "update_net.out.0.weight": torch.randn(hidden, 3 * C, 1, 1, generator=g) * 0.15,
+           "update_net.out.0.bias": torch.randn(hidden, generator=g) * 0.05,
+           "update_net.out.2.weight": torch.randn(hidden, hidden, 1, 1, generator=g) * 0.12,
+           "update_net.out.2.bias": torch.randn(hidden, generator=g) * 0.05,
+           "update_net.out.4.weight": torch.randn(C, hidden, 1, 1, generator=g) * 0.1}
+    x = bfr(torch.rand(B, C, H, W, generator=g) * 1.2 - 0.2)
+    x[:, 3] = bfr(torch.rand(B, H, W, generator=g) * 0.5)          # alpha straddles the 0.1 threshold
+    goal = bfr(torch.randn(B, gch, H, W, generator=g) * 0.5) if gch else None
+    u = torch.rand(B, 1, H, W, generator=g)
+    return prm, x, goal, u
+
+
+def weights(ops, prm, like):
+    return ops.CondWeights(prm["perception_net.weight"], prm["update_net.out.0.weight"], prm["update_net.out.0.bias"],
+                           prm["update_net.out.2.weight"], prm["update_net.out.2.bias"], prm["update_net.out.4.weight"], like)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from ncahip import ops as _ops
+    _ops.selftest()
+    return _ops
+
+
+@pytest.mark.parametrize("C,shape,gch", [(16, (2, 32, 48), 12), (12, (2, 24, 32), 8), (16, (1, 8, 16), 12), (16, (1, 5, 20), 0),
+                                         (10, (2, 16, 16), 6)])
+def test_single_step_vs_bf16_oracle(ops, C, shape, gch):
+    B, H, W = shape
+    prm, x, goal, u = make_case(C, B, H, W, gch)
+    gpad = O.cond_pad_goal(goal, C) if goal is not None else torch.zeros_like(x)
+    ref_next, ref_pre, ref_pend = O.cond_step_bf16(x, gpad, u, prm)
+    xd = x.to(DEV).bfloat16()
+    w = weights(ops, prm, xd)
+    xp, pre = ops.cond_step(xd, None, None if goal is None else goal.to(DEV).bfloat16(), u.to(DEV), w, 3)
+    assert xp.dtype == torch.bfloat16
+    assert torch.equal(pre.cpu().bool().reshape(B, 1, H, W), ref_pre)            # computed from the input state: exact
+    got = xp.float().cpu()
+    err = (got - ref_pend).abs() / ref_pend.abs().clamp_min(1.0)
+    assert float(err.max()) <= 2 * ULP, float(err.max())                        # at most a rounding flip
+    assert float((got != ref_pend).float().mean()) < 0.03                       # and only on a few elements
+    # resolved state: compare where the pending alpha is not within one ulp of the threshold
+    res = ops.cond_finalize(xp, pre, 3).float().cpu()
+    pooled = torch.nn.functional.max_pool2d(ref_pend[:, 3:4], 3, 1, 1)
+    safe = ((pooled - 0.1).abs() > 2 * ULP).expand_as(res)
+    e2 = ((res - ref_next).abs() / ref_next.abs().clamp_min(1.0))[safe]
+    assert float(e2.max()) <= 2 * ULP
+
+
+def test_close_to_fp32_step(ops):
+    """One bf16 step stays within bf16 resolution of the exact fp32 step (nca.py:181-195) on the same inputs."""
+    C, B, H, W, gch = 16, 2, 32, 32, 12
+    prm, x, goal, u = make_case(C, B, H, W, gch, seed=3)
+    gpad = O.cond_pad_goal(goal, C)
+    d = O.cond_step(x, gpad, u, prm, 3, return_all=True)
+    xd = x.to(DEV).bfloat16()
+    xp, pre = ops.cond_step(xd, None, goal.to(DEV).bfloat16(), u.to(DEV), weights(ops, prm, xd), 3)
+    err = (xp.float().cpu() - d["x1"]).abs() / d["x1"].abs().clamp_min(1.0)
+    assert float(err.max()) < 3e-2 and float(err.mean()) < 3e-3, (float(err.max()), float(err.mean()))
+
+
+def test_grow_free_running_vs_oracle(ops):
+    C, B, H, W, gch, T_ = 16, 2, 32, 32, 12, 8
+    prm, x, goal, _ = make_case(C, B, H, W, gch, seed=5)
+    g = torch.Generator().manual_seed(11)
+    us = torch.rand(T_, B, 1, H, W, generator=g)
+    gpad = O.cond_pad_goal(goal, C)
+    ref = x
+    for t in range(T_):
+        ref, _, _ = O.cond_step_bf16(ref, gpad, us[t], prm)
+    xd = x.to(DEV).bfloat16()
+    out, _, _ = ops.cond_grow(xd, T_, goal.to(DEV).bfloat16(), us.to(DEV), weights(ops, prm, xd), 3)
+    got = out.float().cpu()
+    err = (got - ref).abs() / ref.abs().clamp_min(1.0)
+    # rounding flips feed back through 8 steps and through the life threshold: bounded drift, few outliers
+    assert float((err > 8 * ULP).float().mean()) < 0.01, float((err > 8 * ULP).float().mean())
+    assert float(err.mean()) < 2e-3
+
+
+def test_properties(ops):
+    C, B, H, W, gch = 16, 2, 16, 32, 12
+    prm, x, goal, u = make_case(C, B, H, W, gch, seed=7)
+    xd, gd = x.to(DEV).bfloat16(), goal.to(DEV).bfloat16()
+    w = weights(ops, prm, xd)
+    # fire rate 0: the state only passes the life mask / clamp
+    xp, pre = ops.cond_step(xd, None, gd, u.to(DEV), w, 3, fire_rate=0.0)
+    assert torch.equal(xp, xd)
+    # in-kernel Philox == explicit uniforms drawn by the library's generator, bit for bit
+    uu = ops.philox_uniform(B, H, W, seed=9, step=4, device=DEV)
+    a1, p1 = ops.cond_step(xd, None, gd, uu, w, 3)
+    a2, p2 = ops.cond_step(xd, None, gd, None, w, 3, seed=9, step=4)
+    assert torch.equal(a1, a2) and torch.equal(p1, p2)
+    # a dead grid stays dead
+    dead = torch.zeros_like(xd)
+    out, _, _ = ops.cond_grow(dead, 3, gd, None, w, 3, seed=1)
+    assert float(out.float().abs().max()) == 0.0
+    # batch independence
+    b0, _ = ops.cond_step(xd[:1].contiguous(), None, gd[:1].contiguous(), u[:1].to(DEV), w, 3)
+    full, _ = ops.cond_step(xd, None, gd, u.to(DEV), w, 3)
+    assert torch.equal(b0, full[:1])
+
+
+def test_refuses_unaligned_width(ops):
+    from ncahip._capi import NcaHipError
+    prm, x, goal, u = make_case(16, 1, 6, 10, 12)
+    xd = x.to(DEV).bfloat16()
+    with pytest.raises(NcaHipError):
+        ops.cond_step(xd, None, goal.to(DEV).bfloat16(), u.to(DEV), weights(ops, prm, xd), 3)
+
+
+def test_module_grow_bf16(ops):
+    """ConditionedNCA.grow on a bf16 state (no_grad): same class surface, bf16 in / bf16 out, close to the fp32 grow."""
+    from ncahip.nca import ConditionedNCA
+    torch.manual_seed(0)
+    m = ConditionedNCA(target_shape=(3, 32, 32), num_hidden_channels=12, living_channel_dim=3).to(DEV)
+    with torch.no_grad():
+        for p_ in m.update_net.parameters():
+            p_.add_(torch.randn_like(p_) * 0.05)
+    m.mask_rng = "philox"
+    x = (torch.rand(2, m.num_channels, 32, 32, device=DEV) * 0.8).bfloat16()
+    goal = torch.rand(2, 3, 32, 32, device=DEV)
+    with torch.no_grad():
+        m._mask_step = 0
+        yb = m.grow(x, 4, goal)
+        m._mask_step = 0
+        yf = m.grow(x.float(), 4, goal)
+    assert yb.dtype == torch.bfloat16 and yb.shape == yf.shape
+    d = (yb.float() - yf).abs()
+    assert float(d.mean()) < 2e-2, float(d.mean())
+    with pytest.raises(NotImplementedError):
+        m.grow(x, 2, goal)                      # autograd through the bf16 path is not provided

@@ -155,6 +155,65 @@ int ncahip_cond_finalize_f32(const float* x_pend, const uint8_t* pre, float* x_o
                                                (hipStream_t)stream), "cond_finalize");
 }
 
+// ---- bf16 state storage (nca_cond_bf16.hip) ---------------------------------------------------------------
+static int check_bf16_shape(const void* x_in, const void* x_out, const void* goal, int H, int W) {
+    if (W % 4 != 0 || (((uintptr_t)x_in | (uintptr_t)x_out | (uintptr_t)goal) & 7) != 0)
+        return fail(NCAHIP_ERANGE, "bf16 cond step: needs W %% 4 == 0 and 8-byte aligned state / goal tensors");
+    if ((size_t)H * W >= ((size_t)1 << 24)) return fail(NCAHIP_ERANGE, "bf16 cond step: H*W must be below 2^24");
+    return 0;
+}
+
+int ncahip_cond_step_fwd_bf16(const uint16_t* x_in, const uint8_t* pre_in, uint16_t* x_out, uint8_t* pre_out,
+                              const uint16_t* goal, int goal_ch, const float* u, const float* wp, const float* w1,
+                              const float* b1, const float* w2, const float* b2, const float* w3, int B, int C, int H,
+                              int W, int hidden, int alive_ch, float alive_thr, float fire_rate, float clamp_lo,
+                              float clamp_hi, uint64_t seed, uint64_t step, ncahip_stream_t stream) {
+    if (int rc = check_cond(x_in, x_out, pre_out, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch))
+        return rc;
+    if (int rc = check_bf16_shape(x_in, x_out, goal, H, W)) return rc;
+    if (pre_in && pre_in == pre_out) return fail(NCAHIP_EINVAL, "cond step: pre_in and pre_out must not alias");
+    NcaCondArgs a{reinterpret_cast<const float*>(x_in), pre_in, reinterpret_cast<float*>(x_out), pre_out,
+                  reinterpret_cast<const float*>(goal), u, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch,
+                  alive_ch, alive_thr, fire_rate, clamp_lo, clamp_hi, seed, step};
+    return hip_result(nca_launch_cond_step_fwd_bf16(a, (hipStream_t)stream), "cond_step_fwd_bf16");
+}
+
+int ncahip_cond_finalize_bf16(const uint16_t* x_pend, const uint8_t* pre, uint16_t* x_out, int B, int C, int H, int W,
+                              int alive_ch, float alive_thr, float clamp_lo, float clamp_hi, ncahip_stream_t stream) {
+    if (!x_pend || !x_out || (alive_ch >= 0 && !pre)) return fail(NCAHIP_EINVAL, "cond_finalize: null pointer");
+    if (!dims_ok(B, C, H, W) || alive_ch >= C) return fail(NCAHIP_EINVAL, "cond_finalize: bad size");
+    if (alive_ch >= 0 && x_pend == x_out) return fail(NCAHIP_EINVAL, "cond_finalize: in-place needs alive_ch < 0");
+    return hip_result(nca_launch_cond_finalize_bf16(x_pend, pre, x_out, B, C, H, W, alive_ch, alive_thr, clamp_lo,
+                                                    clamp_hi, (hipStream_t)stream), "cond_finalize_bf16");
+}
+
+int ncahip_cond_grow_fwd_bf16(uint16_t* states, uint8_t* pre, int ring, int T, uint16_t* x_final, const uint16_t* goal,
+                              int goal_ch, const float* u, const float* wp, const float* w1, const float* b1,
+                              const float* w2, const float* b2, const float* w3, int B, int C, int H, int W, int hidden,
+                              int alive_ch, float alive_thr, float fire_rate, float clamp_lo, float clamp_hi,
+                              uint64_t seed, uint64_t step0, ncahip_stream_t stream) {
+    if (ring < 2 || T < 1 || !pre || !x_final) return fail(NCAHIP_EINVAL, "cond grow: ring >= 2, T >= 1, buffers required");
+    if (int rc = check_cond(states, states + 1, pre, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch))
+        return rc;
+    if (int rc = check_bf16_shape(states, states, goal, H, W)) return rc;
+    const size_t slot = (size_t)B * C * H * W, pslot = (size_t)B * H * W;
+    if ((slot * sizeof(uint16_t)) % 8 != 0) return fail(NCAHIP_ERANGE, "bf16 cond grow: state slots must stay 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int sl = T % ring;
+    if (x_final == states + (size_t)sl * slot && alive_ch >= 0)
+        return fail(NCAHIP_EINVAL, "cond grow: x_final must not alias the last state slot");
+    for (int t = 0; t < T; ++t) {
+        const int si = t % ring, so = (t + 1) % ring;
+        NcaCondArgs a{reinterpret_cast<const float*>(states + (size_t)si * slot), t == 0 ? nullptr : pre + (size_t)si * pslot,
+                      reinterpret_cast<float*>(states + (size_t)so * slot), pre + (size_t)so * pslot,
+                      reinterpret_cast<const float*>(goal), u ? u + (size_t)t * pslot : nullptr, wp, w1, b1, w2, b2, w3, B, C, H,
+                      W, hidden, goal_ch, alive_ch, alive_thr, fire_rate, clamp_lo, clamp_hi, seed, step0 + (uint64_t)t};
+        if (int rc = hip_result(nca_launch_cond_step_fwd_bf16(a, st), "cond_grow_fwd_bf16")) return rc;
+    }
+    return hip_result(nca_launch_cond_finalize_bf16(states + (size_t)sl * slot, pre + (size_t)sl * pslot, x_final, B, C, H, W,
+                                                    alive_ch, alive_thr, clamp_lo, clamp_hi, st), "cond_grow finalize (bf16)");
+}
+
 int ncahip_cond_alive_u8(const float* x, uint8_t* out, int B, int C, int H, int W, int alive_ch, float alive_thr,
                          ncahip_stream_t stream) {
     if (!x || !out) return fail(NCAHIP_EINVAL, "cond_alive: null pointer");

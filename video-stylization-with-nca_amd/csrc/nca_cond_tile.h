@@ -137,15 +137,71 @@ struct WTile {
     bool valid, inner;  // inner: the 3-cell (1-cell without alive channel) halo lies inside the image
 };
 
+// ---- storage type of the state / goal tensors in HBM ----------------------------------------------
+// The tile code computes in f32; ST says how a value travels to and from memory.  Raw loaded registers are kept raw
+// until staging consumes them (converting at load time would wait for the load).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+struct StF32 {
+    static constexpr int BYTES = 4;
+    typedef float raw1;
+    typedef f32x4 raw4;
+    static __device__ __forceinline__ float cv1(raw1 v) { return v; }
+    static __device__ __forceinline__ f32x4 cv4(raw4 v) { return v; }
+    template <int AUX>
+    static __device__ __forceinline__ raw1 ld1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, AUX));
+    }
+    template <int AUX>
+    static __device__ __forceinline__ raw4 ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, AUX));
+    }
+    template <int AUX>
+    static __device__ __forceinline__ void st4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)soff, AUX);
+    }
+};
+// bf16 storage (round-to-nearest-even on store: v_cvt_pk_bf16_f32; widening on load is exact)
+struct StBF16 {
+    static constexpr int BYTES = 2;
+    typedef unsigned raw1;   // low 16 bits
+    typedef u32x2 raw4;      // 4 consecutive cells
+    static __device__ __forceinline__ float cv1(raw1 v) { return __uint_as_float(v << 16); }
+    static __device__ __forceinline__ f32x4 cv4(raw4 v) {
+        return f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16),
+                     __uint_as_float(v[1] & 0xffff0000u)};
+    }
+    template <int AUX>
+    static __device__ __forceinline__ raw1 ld1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, (int)soff, AUX);
+    }
+    template <int AUX>
+    static __device__ __forceinline__ raw4 ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, AUX));
+    }
+    static __device__ __forceinline__ unsigned pk2(float lo, float hi) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{lo, hi}, bf16x2));
+    }
+    template <int AUX>
+    static __device__ __forceinline__ void st4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk2(v[0], v[1]), pk2(v[2], v[3])}, r, (int)voff, (int)soff, AUX);
+    }
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t nca_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+
 // Registers that carry one tile's global loads from issue (before the previous tile's MFMA chain)
 // to staging (after it).
-template <int CP>
+template <int CP, typename ST = StF32>
 struct TileRegs {
-    float a3v[5];           // alpha' halo 3
-    unsigned prv[4];        // previous pre mask bytes, halo 2 (raw: converting at load time would force a wait)
-    float uu, up;           // fire-mask uniform of the lane's cell: loaded (explicit uniforms) / in-kernel Philox
-    f32x4 xf[CP / 2], gf[CP / 2];  // state / goal interior 16-byte groups
-    float xh[CP / 4], gh[CP / 4];  // state / goal halo columns
+    typename ST::raw1 a3v[5];   // alpha' halo 3
+    unsigned prv[4];            // previous pre mask bytes, halo 2 (raw: converting at load time would force a wait)
+    float uu, up;               // fire-mask uniform of the lane's cell: loaded (explicit uniforms) / in-kernel Philox
+    typename ST::raw4 xf[CP / 2], gf[CP / 2];  // state / goal interior 4-cell groups
+    typename ST::raw1 xh[CP / 4], gh[CP / 4];  // state / goal halo columns
 };
 
 // Lane geometry (all shifts of the lane id; recomputed where used, never carried across the MFMAs):
@@ -161,26 +217,15 @@ struct TileRegs {
 // take the generic kernel).  kAuxCoherent selects the cache policy of the state-type loads (x, pre mask): 0 = ordinary
 // cached loads (a step launch reads only what earlier launches wrote); 16 = sc1, agent-scope coherent -- what a fused
 // multi-step launch with grid barriers needs (tried and measured slower: DESIGN.md section 4).
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kAuxCoherent = 0;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t nca_rsrc(const void* base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
-}
-template <int AUX>
-__device__ __forceinline__ float bld1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, AUX));
-}
-template <int AUX>
-__device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, AUX));
-}
-template <int CP, bool STATE, bool GOAL, int CHK = -1, bool EXACT = false>
-__device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t, int lane_in, TileRegs<CP>& R) {
+template <int CP, bool STATE, bool GOAL, int CHK = -1, bool EXACT = false, typename ST = StF32>
+__device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t, int lane_in, TileRegs<CP, ST>& R) {
+    constexpr unsigned SB = ST::BYTES;   // "4" in the names below = one storage element
     const int C = EXACT ? CP : a.C, H = a.H, W = a.W;
-    const unsigned plane = (unsigned)(H * W), plane4 = plane * 4u, W4 = (unsigned)W * 4u;
+    const unsigned plane = (unsigned)(H * W), plane4 = plane * SB, W4 = (unsigned)W * SB;
     const int gch0 = C - a.goal_ch;
     const bool pending = a.pre_in != nullptr, use_alive = a.alive_ch >= 0, has_goal = a.goal_ch > 0;
-    const float* const xb = a.x_in + (size_t)t.b * C * plane;
+    const char* const xb = reinterpret_cast<const char*>(a.x_in) + (size_t)t.b * C * plane * SB;
     const size_t cell0 = (size_t)t.b * plane;
     const __amdgpu_buffer_rsrc_t rx = nca_rsrc(xb);
     int lane = lane_in;
@@ -188,17 +233,17 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
     const int hl = lane >> 5, l5 = lane & 31, q4 = lane >> 4, ci = lane & 15;
     const bool chk = CHK < 0 ? !t.inner : (CHK != 0);
     if (STATE && use_alive) {
-        const __amdgpu_buffer_rsrc_t ra = nca_rsrc(xb + (size_t)a.alive_ch * plane);
+        const __amdgpu_buffer_rsrc_t ra = nca_rsrc(xb + (size_t)a.alive_ch * plane4);
         if (!chk) {   // interior: one lane offset (columns >= 22 re-read column 21), rows step through the SGPR offset
-            const unsigned vo = (unsigned)(__mul24(t.ty0 - 3 + hl, W) + t.tx0 - 3 + min(l5, 21)) * 4u;
+            const unsigned vo = (unsigned)(__mul24(t.ty0 - 3 + hl, W) + t.tx0 - 3 + min(l5, 21)) * SB;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) R.a3v[k] = bld1<kAuxCoherent>(ra, vo, 2u * k * W4);
+            for (int k = 0; k < 5; ++k) R.a3v[k] = ST::template ld1<kAuxCoherent>(ra, vo, 2u * k * W4);
         } else {
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 const int gy = t.ty0 - 3 + 2 * k + hl, gx = t.tx0 - 3 + l5;
                 const bool ok = l5 < 22 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-                R.a3v[k] = bld1<kAuxCoherent>(ra, ok ? (unsigned)(__mul24(gy, W) + gx) * 4u : 0u, 0u);
+                R.a3v[k] = ST::template ld1<kAuxCoherent>(ra, ok ? (unsigned)(__mul24(gy, W) + gx) * SB : 0u, 0u);
             }
         }
     }
@@ -224,20 +269,20 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
         const unsigned pix = cin ? (unsigned)(__mul24(cgy, W) + cgx) : 0u;
         // both sources are produced without touching the loaded value (a select here would wait for every load issued
         // so far); stage_tile picks one
-        R.uu = bld1<0>(nca_rsrc(a.u ? (const void*)(a.u + cell0) : (const void*)xb), a.u ? pix * 4u : 0u, 0u);
+        R.uu = StF32::ld1<0>(nca_rsrc(a.u ? (const void*)(a.u + cell0) : (const void*)xb), a.u ? pix * 4u : 0u, 0u);
         R.up = a.u ? 0.0f : nca_philox_cell(a.seed, a.step, cell0 + pix);
     }
-    const __amdgpu_buffer_rsrc_t rg = nca_rsrc(has_goal ? a.goal + (size_t)t.b * a.goal_ch * plane : xb);
+    const __amdgpu_buffer_rsrc_t rg = nca_rsrc(has_goal ? reinterpret_cast<const char*>(a.goal) + (size_t)t.b * a.goal_ch * plane * SB : xb);
     {
         const int fr = l5 >> 2, ff = l5 & 3, fgy = t.ty0 - 1 + fr, fgx = t.tx0 + 4 * ff;
         const bool fok = l5 < 24 && (!chk || (fgy >= 0 && fgy < H && fgx + 3 < W));
-        const unsigned pix4 = fok ? (unsigned)(__mul24(fgy, W) + fgx) * 4u : 0u;
+        const unsigned pix4 = fok ? (unsigned)(__mul24(fgy, W) + fgx) * SB : 0u;
         const unsigned vox = pix4 + (hl ? plane4 : 0u);   // channel 2k + hl: the 2k part rides in the SGPR offset
         if (STATE) {
 #pragma unroll
             for (int k = 0; k < CP / 2; ++k) {
-                if (EXACT) R.xf[k] = bld4<kAuxCoherent>(rx, vox, 2u * k * plane4);
-                else R.xf[k] = bld4<kAuxCoherent>(rx, pix4 + __umul24((unsigned)min(2 * k + hl, C - 1), plane4), 0u);
+                if (EXACT) R.xf[k] = ST::template ld4<kAuxCoherent>(rx, vox, 2u * k * plane4);
+                else R.xf[k] = ST::template ld4<kAuxCoherent>(rx, pix4 + __umul24((unsigned)min(2 * k + hl, C - 1), plane4), 0u);
             }
         }
         if (GOAL && has_goal) {
@@ -245,28 +290,28 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
             for (int k = 0; k < CP / 2; ++k) {
                 // goal channel 2k + hl - gch0; lanes below gch0 never use the value and read channel 0 instead
                 const int d = 2 * k - gch0;   // uniform
-                R.gf[k] = bld4<0>(rg, d >= 0 ? vox : pix4, d >= 0 ? (unsigned)d * plane4 : 0u);
+                R.gf[k] = ST::template ld4<0>(rg, d >= 0 ? vox : pix4, d >= 0 ? (unsigned)d * plane4 : 0u);
             }
         }
     }
     {
         const int hr = ci >> 1, hgy = t.ty0 - 1 + hr, hgx = (ci & 1) ? t.tx0 + WTW : t.tx0 - 1;
         const bool hok = ci < 12 && (!chk || (hgy >= 0 && hgy < H && hgx >= 0 && hgx < W));
-        const unsigned pix4 = hok ? (unsigned)(__mul24(hgy, W) + hgx) * 4u : 0u;
+        const unsigned pix4 = hok ? (unsigned)(__mul24(hgy, W) + hgx) * SB : 0u;
         const unsigned voh = pix4 + __umul24((unsigned)q4, plane4);   // channel 4k + q4
         if (STATE) {
 #pragma unroll
             for (int k = 0; k < CP / 4; ++k) {
-                if (EXACT) R.xh[k] = bld1<kAuxCoherent>(rx, voh, 4u * k * plane4);
-                else R.xh[k] = bld1<kAuxCoherent>(rx, pix4 + __umul24((unsigned)min(4 * k + q4, C - 1), plane4), 0u);
+                if (EXACT) R.xh[k] = ST::template ld1<kAuxCoherent>(rx, voh, 4u * k * plane4);
+                else R.xh[k] = ST::template ld1<kAuxCoherent>(rx, pix4 + __umul24((unsigned)min(4 * k + q4, C - 1), plane4), 0u);
             }
         }
         if (GOAL && has_goal) {
 #pragma unroll
             for (int k = 0; k < CP / 4; ++k) {
                 const int d = 4 * k - gch0;   // uniform
-                if (d >= 0) R.gh[k] = bld1<0>(rg, voh, (unsigned)d * plane4);
-                else R.gh[k] = bld1<0>(rg, pix4 + __umul24((unsigned)max(4 * k + q4 - gch0, 0), plane4), 0u);
+                if (d >= 0) R.gh[k] = ST::template ld1<0>(rg, voh, (unsigned)d * plane4);
+                else R.gh[k] = ST::template ld1<0>(rg, pix4 + __umul24((unsigned)max(4 * k + q4 - gch0, 0), plane4), 0u);
             }
         }
     }
@@ -274,9 +319,9 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
 
 // Resolve the pending life mask, build z = x + goal*pre in LDS (halo 1), keep the resolved state for
 // the residual.  CHECK=false: no bounds logic.
-template <int CP, bool CHECK, bool EXACT = false>
+template <int CP, bool CHECK, bool EXACT = false, typename ST = StF32>
 __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t, const TileLds& L, int lane_in,
-                                           const TileRegs<CP>& R, int tile_no) {
+                                           const TileRegs<CP, ST>& R, int tile_no) {
     float* const Z = L.Z;
     float* const XR = L.XR;
     float* const A3 = L.A3;
@@ -307,7 +352,7 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
         for (int k = 0; k < 5; ++k) {
             const int gy = ty0 - 3 + 2 * k + hl, gx = tx0 - 3 + l5;
             const bool ok = !CHECK || (gy >= 0 && gy < H && gx >= 0 && gx < W);
-            if (l5 < 22) A3[(2 * k + hl) * RS + l5 + 1] = ok ? R.a3v[k] : NCA_NEG_INF;
+            if (l5 < 22) A3[(2 * k + hl) * RS + l5 + 1] = ok ? ST::cv1(R.a3v[k]) : NCA_NEG_INF;
         }
         wave_sync();
         NCA_STAMP(9);
@@ -373,7 +418,7 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
 #pragma unroll
         for (int k = 0; k < CP / 2; ++k) {  // resolved state (prefetched long ago): no memory wait here
             const int ch = 2 * k + hl;
-            v[k] = R.xf[k];
+            v[k] = ST::cv4(R.xf[k]);
             if (pending) {
                 v[k] = v[k] * lf;
 #pragma unroll
@@ -386,7 +431,7 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
 #pragma unroll
         for (int k = 0; k < CP / 2; ++k) {  // goal encoding (issued at the top of staging) consumed last
             const int ch = 2 * k + hl;
-            if (has_goal && ch >= gch0 && ch < C && fok) v[k] = __builtin_elementwise_fma(R.gf[k], pn, v[k]);
+            if (has_goal && ch >= gch0 && ch < C && fok) v[k] = __builtin_elementwise_fma(ST::cv4(R.gf[k]), pn, v[k]);
             st4(Z + ch * CS + fr * RS + 4 + 4 * ff, v[k]);
         }
     }
@@ -399,10 +444,10 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
 #pragma unroll
         for (int k = 0; k < CP / 4; ++k) {
             const int ch = 4 * k + q4;
-            float v = R.xh[k];
+            float v = ST::cv1(R.xh[k]);
             if (pending) v = wclamp(v * lf, a.lo, a.hi);
             if (!hok || ch >= C) v = 0.0f;
-            else if (has_goal && ch >= gch0) v = fmaf(R.gh[k], pn, v);
+            else if (has_goal && ch >= gch0) v = fmaf(ST::cv1(R.gh[k]), pn, v);
             Z[ch * CS + hr * RS + zq] = v;
         }
     }
@@ -668,29 +713,161 @@ __device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, float* __re
             }
 }
 
+// ---- UpdateNet on bf16 MFMA (bf16-storage kernels) -------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) { return StBF16::pk2(lo, hi); }
+// relu on a packed bf16 pair: the sign bit of each half makes it a negative int16
+__device__ __forceinline__ unsigned relu_pk(unsigned v) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), s16x2{0, 0}));
+}
+__device__ __forceinline__ s16x4 pack4(float a, float b, float c, float d) {
+    return __builtin_bit_cast(s16x4, u32x2{pk_bf16(a, b), pk_bf16(c, d)});
+}
+__device__ __forceinline__ s16x4 pack4_relu(f32x4 v) {
+    return __builtin_bit_cast(s16x4, u32x2{relu_pk(pk_bf16(v[0], v[1])), relu_pk(pk_bf16(v[2], v[3]))});
+}
+__device__ __forceinline__ f32x4 mfma_bf16(s16x4 a, s16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
+template <int CP>
+struct MlpRegsBf {
+    static constexpr int K1S = 3 * CP / 4, KS1 = (K1S + 3) / 4, M3T = (CP + 15) / 16;   // k-steps of layer 1: slots q = 3*c4 + f
+    s16x4 w1[4][KS1], w2[4][4], w3[M3T][4];
+};
+// A operands from the f32 weight tensors (nca.py:40-46 layouts), rounded to bf16.  Lane (g, i): row o = 16*tile + i,
+// k = 4g + r.  Layer 1's k order follows perceive_tile: slot q = 4s + r = 3*c4 + f is channel 4*c4 + g, filter f.
+template <int CP>
+__device__ __forceinline__ void load_weights_bf16(const NcaCondArgs& a, int lane, MlpRegsBf<CP>& R) {
+    using K = MlpRegsBf<CP>;
+    const int g = lane >> 4, i = lane & 15, C = a.C, hid = a.hidden, K1 = 3 * C;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int s = 0; s < K::KS1; ++s) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 4 * s + r, ch = 4 * (q / 3) + g, f = q % 3, o = 16 * m + i;
+                const bool ok = q < K::K1S && ch < C && o < hid;
+                const float w = a.w1[ok ? o * K1 + 3 * ch + f : 0];
+                v[r] = ok ? w : 0.0f;
+            }
+            R.w1[m][s] = pack4(v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int m2 = 0; m2 < 4; ++m2) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * m2 + i, k = 16 * m + 4 * g + r;
+                const bool ok = o < hid && k < hid;
+                const float w = a.w2[ok ? o * hid + k : 0];
+                v[r] = ok ? w : 0.0f;
+            }
+            R.w2[m2][m] = pack4(v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int m3 = 0; m3 < K::M3T; ++m3) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * m3 + i, k = 16 * m + 4 * g + r;
+                const bool ok = o < C && k < hid;
+                const float w = a.w3[ok ? o * hid + k : 0];
+                v[r] = ok ? w : 0.0f;
+            }
+            R.w3[m3][m] = pack4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// UpdateNet for rows n0..n0+NT-1 of the tile, then x' = x + mask*out in place in XR (16*M3T channel rows).
+template <int CP, int NT>
+__device__ __forceinline__ void mlp_tile_bf16(const MlpRegsBf<CP>& Wr, const float* __restrict__ B1L, const float* __restrict__ B2L,
+                                              float* __restrict__ XR, const float* __restrict__ MK, int lane_in, int n0,
+                                              const float (&P)[NT][3 * CP / 4]) {
+    using K = MlpRegsBf<CP>;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4, ci = lane & 15;
+    s16x4 pb[NT][K::KS1];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int s = 0; s < K::KS1; ++s) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = 4 * s + r < K::K1S ? P[n][4 * s + r] : 0.0f;
+            pb[n][s] = pack4(v[0], v[1], v[2], v[3]);
+        }
+    f32x4 acc2[4][NT];
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2) {
+        const f32x4 b = ld4(B2L + 16 * m2 + 4 * g);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc2[m2][n] = b;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const f32x4 b = ld4(B1L + 16 * m + 4 * g);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            f32x4 acc1 = b;
+#pragma unroll
+            for (int s = 0; s < K::KS1; ++s) acc1 = mfma_bf16(Wr.w1[m][s], pb[n][s], acc1);
+            const s16x4 hb = pack4_relu(acc1);
+#pragma unroll
+            for (int m2 = 0; m2 < 4; ++m2) acc2[m2][n] = mfma_bf16(Wr.w2[m2][m], hb, acc2[m2][n]);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        f32x4 acc3[K::M3T];
+#pragma unroll
+        for (int m3 = 0; m3 < K::M3T; ++m3) acc3[m3] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // out.4 has no bias
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const s16x4 hb = pack4_relu(acc2[m][n]);
+#pragma unroll
+            for (int m3 = 0; m3 < K::M3T; ++m3) acc3[m3] = mfma_bf16(Wr.w3[m3][m], hb, acc3[m3]);
+        }
+        const float mk = MK[(n0 + n) * WTW + ci];
+#pragma unroll
+        for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* const p = XR + (16 * m3 + 4 * g + r) * XRS + (n0 + n) * WTW + ci;
+                *p = fmaf(mk, acc3[m3][r], *p);
+            }
+    }
+}
+
+
 // Pending state out: 16-byte stores, 4 per lane (item k -> channel 4k+q4, row (lane>>2)&3, group lane&3).
 // WT: write-through at agent scope (sc1) -- the line goes to memory now instead of sitting dirty in the XCD's L2 until
 // the end-of-kernel write-back (measured: -4 us launch cadence; a plain `nt` hint changes nothing).
-template <int CP, bool CHECK, bool EXACT = false, bool WT = false>
+template <int CP, bool CHECK, bool EXACT = false, bool WT = false, typename ST = StF32>
 __device__ __forceinline__ void store_tile(const NcaCondArgs& a, const WTile& t, const float* __restrict__ XR, int lane_in) {
+    constexpr unsigned SB = ST::BYTES;
     const int C = EXACT ? CP : a.C, H = a.H, W = a.W;
-    const unsigned plane = (unsigned)(H * W), plane4 = plane * 4u;
+    const unsigned plane = (unsigned)(H * W), plane4 = plane * SB;
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     const int q4 = lane >> 4, row = (lane >> 2) & 3, ff = lane & 3;
     const int gy = t.ty0 + row, gx = t.tx0 + 4 * ff;
     const bool ok = !CHECK || (gy < H && gx + 3 < W);
-    const __amdgpu_buffer_rsrc_t ro = nca_rsrc(a.x_out + (size_t)t.b * C * plane);
-    const unsigned vo = (ok ? (unsigned)(__mul24(gy, W) + gx) * 4u : 0u) + __umul24((unsigned)q4, plane4);
+    const __amdgpu_buffer_rsrc_t ro = nca_rsrc(reinterpret_cast<char*>(a.x_out) + (size_t)t.b * C * plane * SB);
+    const unsigned vo = (ok ? (unsigned)(__mul24(gy, W) + gx) * SB : 0u) + __umul24((unsigned)q4, plane4);
     wave_sync();
 #pragma unroll
     for (int k = 0; k < CP / 4; ++k) {
         const int ch = 4 * k + q4;
         const f32x4 v = ld4(XR + ch * XRS + row * WTW + 4 * ff);
-        if (ok && ch < C)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, (int)vo, (int)(4u * k * plane4), WT ? 16 : 0);
+        if (ok && ch < C) ST::template st4<WT ? 16 : 0>(ro, vo, 4u * k * plane4, v);
     }
 }
-
 
 }  // namespace

@@ -66,6 +66,10 @@ hipError_t nca_launch_dynca_step_bwd(const NcaDyncaArgs& a, hipStream_t st);
 hipError_t nca_launch_cond_step_fwd_wave(const NcaCondArgs& a, hipStream_t st);
 // producer/consumer wave-specialised variant (nca_cond_pc.hip); same preconditions
 hipError_t nca_launch_cond_step_fwd_pc(const NcaCondArgs& a, hipStream_t st);
+// bf16 state storage + bf16 MFMA (nca_cond_bf16.hip): x_in / x_out / goal point at bf16 data
+hipError_t nca_launch_cond_step_fwd_bf16(const NcaCondArgs& a, hipStream_t st);
+hipError_t nca_launch_cond_finalize_bf16(const uint16_t* x, const uint8_t* pre, uint16_t* out, int B, int C, int H, int W,
+                                         int alive_ch, float thr, float lo, float hi, hipStream_t st);
 void nca_set_cond_variant(int v);  // 0 = producer/consumer (default), 1 = symmetric wave-private
 
 // diagnostic build hook (-DNCA_STAMPS): buffer that receives s_memtime stamps, [wave][tile][8]

@@ -38,14 +38,20 @@ class _CondGrow(torch.autograd.Function):
 def cond_grow_autograd(model, x: torch.Tensor, goal: Optional[torch.Tensor], T: int) -> torch.Tensor:
     if T == 0:
         return x
-    x = x.float().contiguous()
+    bf16 = x.dtype == torch.bfloat16      # bf16 pool (BASELINE configs[2]): bf16-storage kernels, inference only
+    x = x.contiguous() if bf16 else x.float().contiguous()
     u = model.update_net.out
     params = (model.perception_net.weight, u[0].weight, u[0].bias, u[2].weight, u[2].bias, u[4].weight)
     us = model._draw(x, T)
     cfg = dict(T=T, us=us, alive_ch=model._alive_ch(), thr=model.alpha_living_threshold, fire_rate=model.cell_fire_rate,
                lo=-10.0, hi=10.0, seed=model.mask_seed, step0=model._mask_step)
     model._mask_step += T
-    if _needs_grad(x, goal, *params):
+    if bf16:
+        if torch.is_grad_enabled() and _needs_grad(x, goal, *params):
+            raise NotImplementedError("ncahip: the bf16-storage grow loop is forward-only; train with float32 states "
+                                      "or call it under torch.no_grad()")
+        goal = None if goal is None else goal.detach().to(torch.bfloat16)
+    elif _needs_grad(x, goal, *params):
         return _CondGrow.apply(x, goal, *params, cfg)
     w = ops.CondWeights(*params, x)
     out, _, _ = ops.cond_grow(x, T, goal, us, w, cfg["alive_ch"], cfg["thr"], cfg["fire_rate"], cfg["lo"], cfg["hi"],

@@ -75,7 +75,8 @@ class ConditionedNCA(nn.Module):
     def _draw(self, x: torch.Tensor, steps: int) -> Optional[torch.Tensor]:
         if self.mask_rng == "philox":
             return None
-        return torch.stack([torch.rand_like(x[:, 0:1]) for _ in range(steps)])  # one draw per step, as nca.py:207-208
+        # one draw per step, as nca.py:207-208 (always float32: identical to the reference for float32 states)
+        return torch.stack([torch.rand_like(x[:, 0:1], dtype=torch.float32) for _ in range(steps)])
 
     def _split_goal(self, goal_encoding: torch.Tensor) -> torch.Tensor:
         """The kernels take the UNPADDED encoding; nca.py:199-203 pads zeros in front -- strip them."""

@@ -139,10 +139,17 @@ class CondWeights:
         assert self.wp.numel() == 27 * self.c and self.w1.numel() == self.hidden * 3 * self.c
 
 
-def _goal_args(goal, B, C, H, W):
+def _state_dtype(x: torch.Tensor):
+    """The ConditionedNCA step exists for fp32 and for bf16 state storage (ncahip_cond_*_bf16, see include/ncahip.h)."""
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"ncahip: ConditionedNCA state must be float32 or bfloat16, got {x.dtype}")
+    return x.dtype, ("bf16" if x.dtype == torch.bfloat16 else "f32")
+
+
+def _goal_args(goal, B, C, H, W, dtype=torch.float32):
     if goal is None:
         return None, 0
-    goal = _dev(goal, "goal")
+    goal = _dev(goal, "goal", dtype)
     assert goal.shape[0] == B and goal.shape[2:] == (H, W) and goal.shape[1] <= C
     return goal, goal.shape[1]
 
@@ -150,10 +157,12 @@ def _goal_args(goal, B, C, H, W):
 def cond_step(x: torch.Tensor, pre_in: Optional[torch.Tensor], goal: Optional[torch.Tensor],
               u: Optional[torch.Tensor], w: CondWeights, alive_ch: int = 3, thr: float = 0.1,
               fire_rate: float = 0.5, lo: float = -10.0, hi: float = 10.0, seed: int = 0, step: int = 0):
-    """One fused step; returns (x_pending, pre) -- resolve with cond_finalize (see include/ncahip.h)."""
-    x = _dev(x, "x")
+    """One fused step; returns (x_pending, pre) -- resolve with cond_finalize (see include/ncahip.h).
+    bfloat16 `x` (and `goal`) select the bf16-storage kernel."""
+    dt, sfx = _state_dtype(x)
+    x = _dev(x, "x", dt)
     B, C, H, W = x.shape
-    goal, gch = _goal_args(goal, B, C, H, W)
+    goal, gch = _goal_args(goal, B, C, H, W, dt)
     if pre_in is not None:
         pre_in = _dev(pre_in, "pre_in", torch.uint8)
     if u is not None:
@@ -162,21 +171,23 @@ def cond_step(x: torch.Tensor, pre_in: Optional[torch.Tensor], goal: Optional[to
     assert w.c == C
     x_out = torch.empty_like(x)
     pre_out = torch.empty(B, H, W, device=x.device, dtype=torch.uint8)
-    check(lib().ncahip_cond_step_fwd_f32(_p(x), _p(pre_in), _p(x_out), _p(pre_out), _p(goal), gch, _p(u), _p(w.wp),
-                                         _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), _p(w.w3), B, C, H, W, w.hidden,
-                                         alive_ch, thr, fire_rate, lo, hi, seed, step, _stream()), "cond_step_fwd")
+    fn = getattr(lib(), "ncahip_cond_step_fwd_" + sfx)
+    check(fn(_p(x), _p(pre_in), _p(x_out), _p(pre_out), _p(goal), gch, _p(u), _p(w.wp), _p(w.w1), _p(w.b1), _p(w.w2),
+             _p(w.b2), _p(w.w3), B, C, H, W, w.hidden, alive_ch, thr, fire_rate, lo, hi, seed, step, _stream()),
+          "cond_step_fwd_" + sfx)
     return x_out, pre_out
 
 
 def cond_finalize(x_pend: torch.Tensor, pre: Optional[torch.Tensor], alive_ch: int = 3, thr: float = 0.1,
                   lo: float = -10.0, hi: float = 10.0) -> torch.Tensor:
-    x_pend = _dev(x_pend, "x_pend")
+    dt, sfx = _state_dtype(x_pend)
+    x_pend = _dev(x_pend, "x_pend", dt)
     B, C, H, W = x_pend.shape
     if pre is not None:
         pre = _dev(pre, "pre", torch.uint8)
     out = torch.empty_like(x_pend)
-    check(lib().ncahip_cond_finalize_f32(_p(x_pend), _p(pre), _p(out), B, C, H, W, alive_ch, thr, lo, hi, _stream()),
-          "cond_finalize")
+    check(getattr(lib(), "ncahip_cond_finalize_" + sfx)(_p(x_pend), _p(pre), _p(out), B, C, H, W, alive_ch, thr, lo, hi,
+                                                        _stream()), "cond_finalize_" + sfx)
     return out
 
 
@@ -191,24 +202,27 @@ def cond_alive(x: torch.Tensor, alive_ch: int = 3, thr: float = 0.1) -> torch.Te
 def cond_grow(x: torch.Tensor, T: int, goal: Optional[torch.Tensor], us: Optional[torch.Tensor], w: CondWeights,
               alive_ch: int = 3, thr: float = 0.1, fire_rate: float = 0.5, lo: float = -10.0, hi: float = 10.0,
               seed: int = 0, step0: int = 0, keep_history: bool = False):
-    """T fused steps + finalize (nca.py:207-208).  Returns (x_T, states, pre)."""
-    x = _dev(x, "x")
+    """T fused steps + finalize (nca.py:207-208).  Returns (x_T, states, pre).  bfloat16 `x` / `goal` select the
+    bf16-storage kernels (forward only)."""
+    dt, sfx = _state_dtype(x)
+    x = _dev(x, "x", dt)
     B, C, H, W = x.shape
     if T == 0:
         return x.clone(), None, None
-    goal, gch = _goal_args(goal, B, C, H, W)
+    goal, gch = _goal_args(goal, B, C, H, W, dt)
     if us is not None:
         us = _dev(us, "us")
         assert us.numel() == T * B * H * W
     assert w.c == C
     ring = T + 1 if keep_history else 2
-    states = torch.empty(ring, B, C, H, W, device=x.device, dtype=torch.float32)
+    states = torch.empty(ring, B, C, H, W, device=x.device, dtype=dt)
     pre = torch.empty(ring, B, H, W, device=x.device, dtype=torch.uint8)
     states[0].copy_(x)
     out = torch.empty_like(x)
-    check(lib().ncahip_cond_grow_fwd_f32(_p(states), _p(pre), ring, T, _p(out), _p(goal), gch, _p(us), _p(w.wp),
-                                         _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), _p(w.w3), B, C, H, W, w.hidden,
-                                         alive_ch, thr, fire_rate, lo, hi, seed, step0, _stream()), "cond_grow_fwd")
+    fn = getattr(lib(), "ncahip_cond_grow_fwd_" + sfx)
+    check(fn(_p(states), _p(pre), ring, T, _p(out), _p(goal), gch, _p(us), _p(w.wp), _p(w.w1), _p(w.b1), _p(w.w2),
+             _p(w.b2), _p(w.w3), B, C, H, W, w.hidden, alive_ch, thr, fire_rate, lo, hi, seed, step0, _stream()),
+          "cond_grow_fwd_" + sfx)
     return out, states, pre
 
 
