@@ -18,11 +18,14 @@ x = torch.rand(B, C, H, W, generator=gen).to(dev)
 goal = (torch.randn(B, 12, H, W, generator=gen) * 0.5).to(dev)
 w = ops.CondWeights(prm["perception_net.weight"], prm["update_net.out.0.weight"], prm["update_net.out.0.bias"],
                     prm["update_net.out.2.weight"], prm["update_net.out.2.bias"], prm["update_net.out.4.weight"], x)
+x0, goal0 = x, goal
 L = ops.lib()
 L.nca_debug_set_stamp_buffer_pc.argtypes = [ctypes.c_void_p]
 NWG = 256
 buf = torch.zeros(NWG * 8 * 8 * 16 + NWG * 8 * 8, dtype=torch.int64, device=dev)
-def run(tag, seed=0):
+def run(tag, seed=0, bf16=False):
+    global x, goal
+    x, goal = (x0.bfloat16(), goal0.bfloat16()) if bf16 else (x0, goal0)
     buf.zero_()
     xp, pre = ops.cond_step(x, None, goal, None, w, 3)
     for _ in range(5):
@@ -41,3 +44,14 @@ run("idle producers", 0xD1A6)
 run("idle consumers", 0xD1A7)
 run("consumer: no perception", 0xD1A8)
 run("consumer: no MLP", 0xD1A9)
+print("---- bf16 storage")
+run("bf16 normal", 0, True)
+run("bf16 idle producers", 0xD1A6, True)
+run("bf16 idle consumers", 0xD1A7, True)
+run("bf16 consumer: no perception", 0xD1A8, True)
+run("bf16 consumer: no MLP", 0xD1A9, True)
+run("bf16 consumer alone, no perception", 0xD1AA, True)
+run("bf16 consumer alone, no MLP", 0xD1AB, True)
+run("bf16 consumer alone, no store", 0xD1AC, True)
+run("bf16 consumer alone, nothing", 0xD1AD, True)
+run("f32 consumer alone, nothing", 0xD1AD, False)

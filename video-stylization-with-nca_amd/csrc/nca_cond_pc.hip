@@ -136,17 +136,18 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
             if (pass == 0) NCA_STAMP(4);
 #ifdef NCA_STAMPS
             // diagnostic knobs (stamps build only): 0xD1A8 = no perception, 0xD1A9 = no MLP
-            if (a.seed == 0xD1A8ull) {
+            if (a.seed == 0xD1A8ull || a.seed == 0xD1AAull || a.seed == 0xD1ADull) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
                     for (int s_ = 0; s_ < K::K1S; ++s_) P[n][s_] = L.Z[lane + n];
             } else
 #endif
-            perceive_tile<CP, NT>(smem, L.Z, lane, pass * NT, P);
+            if constexpr (BF) perceive_tile_pipe<CP, NT>(smem, L.Z, lane, pass * NT, P);
+            else perceive_tile<CP, NT>(smem, L.Z, lane, pass * NT, P);
             if (pass == 0) NCA_STAMP(5);
 #ifdef NCA_STAMPS
-            if (a.seed == 0xD1A9ull) {
+            if (a.seed == 0xD1A9ull || a.seed == 0xD1ABull || a.seed == 0xD1ADull) {
                 float acc_ = 0.0f;
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
@@ -160,8 +161,11 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
             if (pass == 0) NCA_STAMP(6);
         }
         NCA_STAMP(7);
-        if (t.inner) store_tile<CP, false, EXACT, kNtStore, ST>(a, t, L.XR, lane);
-        else store_tile<CP, true, EXACT, kNtStore, ST>(a, t, L.XR, lane);
+#ifdef NCA_STAMPS
+        if (a.seed == 0xD1ACull || a.seed == 0xD1ADull) return;   // diagnostic knob: no store
+#endif
+        if (t.inner) store_tile<CP, false, EXACT, kNtStore && !BF, ST>(a, t, L.XR, lane);   // bf16 rows are 32-byte segments: let the L2 merge them
+        else store_tile<CP, true, EXACT, kNtStore && !BF, ST>(a, t, L.XR, lane);
         NCA_STAMP(8);
     };
 
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
             const Pos pn = advance(pos);
             const WTile nxt = tile_of(pn);
 #ifdef NCA_STAMPS
-            if (a.seed != 0xD1A6ull)  // diagnostic knob (stamps build only): idle producers
+            if (a.seed != 0xD1A6ull && (a.seed < 0xD1AAull || a.seed > 0xD1ADull))  // diagnostic knob (stamps build only): idle producers
 #endif
             produce(nxt, which ^ 1);
             __syncthreads();          // tile buffers change hands
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
         NCA_KSTAMP(1);
         __syncthreads();
         NCA_KSTAMP(2);
-        if constexpr (BF) load_weights_bf16<CP>(a, lane, Wb);
+        if constexpr (BF) load_weights_bf16<CP, EXACT>(a, lane, Wb);
         else mlp_load_regs<CP>(smem, lane, Wr);
         while (pos.t < tw.end) {
             const Pos pn = advance(pos);
@@ -264,7 +268,10 @@ hipError_t nca_launch_cond_step_fwd_pc(const NcaCondArgs& a_in, hipStream_t st) 
 // aligned x_in / x_out / goal, C <= 16, hidden <= 64, H*W < 2^24.
 hipError_t nca_launch_cond_step_fwd_bf16(const NcaCondArgs& a_in, hipStream_t st) {
     NcaCondArgs a = a_in;
-    a.dbg = nullptr;
+    a.dbg = g_stamp_pc;
+    const bool h64 = a.hidden == 64;
+    if (a.C == 12 && h64) return launch_cond_pc<12, true, StBF16>(a, st);
+    if (a.C == 16 && h64) return launch_cond_pc<16, true, StBF16>(a, st);
     if (a.C <= 12) return launch_cond_pc<12, false, StBF16>(a, st);
     if (a.C <= 16) return launch_cond_pc<16, false, StBF16>(a, st);
     return hipErrorInvalidValue;

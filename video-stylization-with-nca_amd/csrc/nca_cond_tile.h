@@ -222,7 +222,11 @@ template <int CP, bool STATE, bool GOAL, int CHK = -1, bool EXACT = false, typen
 __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t, int lane_in, TileRegs<CP, ST>& R) {
     constexpr unsigned SB = ST::BYTES;   // "4" in the names below = one storage element
     const int C = EXACT ? CP : a.C, H = a.H, W = a.W;
-    const unsigned plane = (unsigned)(H * W), plane4 = plane * SB, W4 = (unsigned)W * SB;
+    const unsigned plane = (unsigned)(H * W);
+    unsigned plane4 = plane * SB, W4 = (unsigned)W * SB;
+    // opaque per call: the k * plane4 / k * W4 offsets below are then recomputed on the scalar ALU for every tile instead
+    // of being hoisted out of the tile loop as ~40 loop-invariant SGPRs that get spilled to VGPR lanes and read back
+    asm volatile("" : "+s"(plane4), "+s"(W4));
     const int gch0 = C - a.goal_ch;
     const bool pending = a.pre_in != nullptr, use_alive = a.alive_ch >= 0, has_goal = a.goal_ch > 0;
     const char* const xb = reinterpret_cast<const char*>(a.x_in) + (size_t)t.b * C * plane * SB;
@@ -498,6 +502,65 @@ __device__ __forceinline__ void perceive_tile(const float* __restrict__ WS, cons
     }
 }
 
+// perceive_tile with the LDS operands of channel group c4+1 in flight while group c4 is computed (46 more registers:
+// used where the wave has them, i.e. the bf16-operand consumer).  All 16 reads of a group are inline asm, so the one
+// counter the hardware keeps is managed here: s_waitcnt lgkmcnt(16) = "everything but the group just issued has landed".
+template <int CP, int NT>
+__device__ __forceinline__ void perceive_tile_pipe(const float* __restrict__ WS, const float* __restrict__ Z, int lane_in,
+                                                   int n0, float (&P)[NT][3 * CP / 4]) {
+    using K = WCfg<CP>;
+    static_assert(NT == 2, "row pairs");
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4, ci = lane & 15;
+    constexpr int NG = CP / 4;
+    f32x4 wt[2][7];
+    f32x2 nb[2][9];
+    const unsigned wa0 = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)(WS + K::OFF_WP + g * K::WPS);
+    const unsigned za0 = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)(Z + g * CS + n0 * RS + ci + 3);
+    auto issue = [&](int c4, int b) {
+        const unsigned wa = wa0 + (unsigned)(4 * c4 * K::WPS * 4), za = za0 + (unsigned)(4 * c4 * CS * 4);
+#define NCA_RDW(j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wt[b][j]) : "v"(wa), "n"(16 * (j)))
+        NCA_RDW(0); NCA_RDW(1); NCA_RDW(2); NCA_RDW(3); NCA_RDW(4); NCA_RDW(5); NCA_RDW(6);
+#undef NCA_RDW
+#define NCA_RD2(i, o) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(nb[b][i]) : "v"(za), "n"(o), "n"((o) + RS))
+        NCA_RD2(0, 0); NCA_RD2(1, 1); NCA_RD2(2, 2);
+        NCA_RD2(3, RS); NCA_RD2(4, RS + 1); NCA_RD2(5, RS + 2);
+        NCA_RD2(6, 2 * RS); NCA_RD2(7, 2 * RS + 1); NCA_RD2(8, 2 * RS + 2);
+#undef NCA_RD2
+    };
+    issue(0, 0);
+#pragma unroll
+    for (int c4 = 0; c4 < NG; ++c4) {
+        const int b = c4 & 1;
+        if (c4 + 1 < NG) {
+            issue(c4 + 1, b ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(15)"   // 16 reads of the next group outstanding at most -> this group has landed
+                         : "+v"(wt[b][0]), "+v"(wt[b][1]), "+v"(wt[b][2]), "+v"(wt[b][3]), "+v"(wt[b][4]), "+v"(wt[b][5]),
+                           "+v"(wt[b][6]), "+v"(nb[b][0]), "+v"(nb[b][1]), "+v"(nb[b][2]), "+v"(nb[b][3]), "+v"(nb[b][4]),
+                           "+v"(nb[b][5]), "+v"(nb[b][6]), "+v"(nb[b][7]), "+v"(nb[b][8])
+                         :: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(wt[b][0]), "+v"(wt[b][1]), "+v"(wt[b][2]), "+v"(wt[b][3]), "+v"(wt[b][4]), "+v"(wt[b][5]),
+                           "+v"(wt[b][6]), "+v"(nb[b][0]), "+v"(nb[b][1]), "+v"(nb[b][2]), "+v"(nb[b][3]), "+v"(nb[b][4]),
+                           "+v"(nb[b][5]), "+v"(nb[b][6]), "+v"(nb[b][7]), "+v"(nb[b][8])
+                         :: "memory");
+        }
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float w = wt[b][(9 * f + t) >> 2][(9 * f + t) & 3];
+                acc = __builtin_elementwise_fma(f32x2{w, w}, nb[b][t], acc);
+            }
+            P[0][3 * c4 + f] = acc[0];
+            P[1][3 * c4 + f] = acc[1];
+        }
+    }
+}
+
 // relu as ONE integer max on the bit pattern (sign bit set <=> negative int): no NaN-canonicalising pre-pass.
 __device__ __forceinline__ float relu(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
 
@@ -739,10 +802,13 @@ struct MlpRegsBf {
 };
 // A operands from the f32 weight tensors (nca.py:40-46 layouts), rounded to bf16.  Lane (g, i): row o = 16*tile + i,
 // k = 4g + r.  Layer 1's k order follows perceive_tile: slot q = 4s + r = 3*c4 + f is channel 4*c4 + g, filter f.
-template <int CP>
+// EXACT (C == CP, hidden == 64): every guard is decided at compile time except "row i < C" of layer 3 -- no per-load
+// lane masks (each is an SGPR pair that would stay live from its load to its select: 128 of them spill the whole kernel).
+template <int CP, bool EXACT = false>
 __device__ __forceinline__ void load_weights_bf16(const NcaCondArgs& a, int lane, MlpRegsBf<CP>& R) {
     using K = MlpRegsBf<CP>;
-    const int g = lane >> 4, i = lane & 15, C = a.C, hid = a.hidden, K1 = 3 * C;
+    const int g = lane >> 4, i = lane & 15, C = EXACT ? CP : a.C, hid = EXACT ? 64 : a.hidden, K1 = 3 * C;
+    const bool row3 = i < C;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -751,9 +817,13 @@ __device__ __forceinline__ void load_weights_bf16(const NcaCondArgs& a, int lane
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = 4 * s + r, ch = 4 * (q / 3) + g, f = q % 3, o = 16 * m + i;
-                const bool ok = q < K::K1S && ch < C && o < hid;
-                const float w = a.w1[ok ? o * K1 + 3 * ch + f : 0];
-                v[r] = ok ? w : 0.0f;
+                if (EXACT) {
+                    v[r] = q < K::K1S ? a.w1[o * K1 + 3 * ch + f] : 0.0f;
+                } else {
+                    const bool ok = q < K::K1S && ch < C && o < hid;
+                    const float w = a.w1[ok ? o * K1 + 3 * ch + f : 0];
+                    v[r] = ok ? w : 0.0f;
+                }
             }
             R.w1[m][s] = pack4(v[0], v[1], v[2], v[3]);
         }
@@ -763,9 +833,13 @@ __device__ __forceinline__ void load_weights_bf16(const NcaCondArgs& a, int lane
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = 16 * m2 + i, k = 16 * m + 4 * g + r;
-                const bool ok = o < hid && k < hid;
-                const float w = a.w2[ok ? o * hid + k : 0];
-                v[r] = ok ? w : 0.0f;
+                if (EXACT) {
+                    v[r] = a.w2[o * hid + k];
+                } else {
+                    const bool ok = o < hid && k < hid;
+                    const float w = a.w2[ok ? o * hid + k : 0];
+                    v[r] = ok ? w : 0.0f;
+                }
             }
             R.w2[m2][m] = pack4(v[0], v[1], v[2], v[3]);
         }
@@ -775,11 +849,16 @@ __device__ __forceinline__ void load_weights_bf16(const NcaCondArgs& a, int lane
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = 16 * m3 + i, k = 16 * m + 4 * g + r;
-                const bool ok = o < C && k < hid;
-                const float w = a.w3[ok ? o * hid + k : 0];
-                v[r] = ok ? w : 0.0f;
+                if (EXACT) {
+                    v[r] = a.w3[(row3 ? o : 0) * hid + k];
+                } else {
+                    const bool ok = o < C && k < hid;
+                    const float w = a.w3[ok ? o * hid + k : 0];
+                    v[r] = ok ? w : 0.0f;
+                }
             }
             R.w3[m3][m] = pack4(v[0], v[1], v[2], v[3]);
+            if (EXACT && !row3) R.w3[m3][m] = s16x4{0, 0, 0, 0};
         }
     }
 }
@@ -853,7 +932,9 @@ template <int CP, bool CHECK, bool EXACT = false, bool WT = false, typename ST =
 __device__ __forceinline__ void store_tile(const NcaCondArgs& a, const WTile& t, const float* __restrict__ XR, int lane_in) {
     constexpr unsigned SB = ST::BYTES;
     const int C = EXACT ? CP : a.C, H = a.H, W = a.W;
-    const unsigned plane = (unsigned)(H * W), plane4 = plane * SB;
+    const unsigned plane = (unsigned)(H * W);
+    unsigned plane4 = plane * SB;
+    asm volatile("" : "+s"(plane4));   // see issue_loads
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     const int q4 = lane >> 4, row = (lane >> 2) & 3, ff = lane & 3;
