@@ -16,6 +16,7 @@ Extra objects on the JSON line:
   roofline          fused step kernel (dominant): exact-f32 MFMA bound, algorithmic flops/launch over
                     the HIP-event launch time (events on the launch stream).
   roofline_stencil  standalone DyNCA perception stencil: HBM bound, 20*C bytes/cell.
+  bf16_storage      the same grow loop on the bf16-storage kernels (informational; `value` stays the fp32 path).
   cpu_baseline      the CPU oracle (pure-PyTorch restatement == the reference's CPU path, bit-identical)
                     timed on this box's host cores on a bounded sample (rank 0, N=1 only).
 """
@@ -66,7 +67,7 @@ def event_ms(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def pmc_traffic(kernel_substr):
+def pmc_traffic(*kernel_substrs):
     """HBM bytes/launch of a kernel from the committed PMC passes (profiles/*_traffic.json; collected with
     separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, tools/collect_traffic.py)."""
     import glob
@@ -74,7 +75,7 @@ def pmc_traffic(kernel_substr):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
         try:
             for k, v in json.load(open(f)).items():
-                if kernel_substr in k:
+                if all(sub in k for sub in kernel_substrs):
                     best = v["hbm_bytes_per_launch"]
         except Exception:
             pass
@@ -192,7 +193,7 @@ def main():
         # one event-timed region = one grow call (T step launches issued by the C driver + one finalize launch, which is
         # <0.3 % of it and counted against the step: conservative)
         states[0].copy_(xd)
-        ms_launch = event_ms(one_step, 5) / T
+        ms_launch = event_ms(one_step_with_pool, 5) / T   # pool reset per grow (33.5 MB copy, <0.2 % of the region): the grid stays alive
         xa = out
         alive_frac_roof = float(ops.cond_alive(xa, ALIVE_CH).float().mean())
         cells = B * H * W
@@ -212,13 +213,23 @@ def main():
                        "parallelism": f"pool-shard x{world} (no data-path collective)"},
             "roofline": {"kernel": "cond_step_fwd_pc_kernel<16,*>", "bound": "mfma", "achieved": tflops,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": pmc_traffic("cond_step_fwd_pc_kernel"), "launch_ms": ms_launch, "flops_per_cell": FLOPS_PER_CELL,
+                         "traffic": pmc_traffic("cond_step_fwd_pc_kernel", "StF32"), "launch_ms": ms_launch, "flops_per_cell": FLOPS_PER_CELL,
                          "algorithmic_bytes_per_cell": BYTES_PER_CELL_STEP, "cells_per_launch": cells},
             "roofline_stencil": {"kernel": "dynca_perceive_kernel<vec4>", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
                                  "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": pmc_traffic("dynca_perceive_kernel"), "launch_ms": ms_st,
                                  "bytes_per_cell": STENCIL_BYTES_PER_CELL, "cells_per_launch": cells,
                                  "cells_per_s": cells / (ms_st * 1e-3)},
         }
+        # ---- the same grow loop with bf16 state storage (ncahip_cond_grow_fwd_bf16; BASELINE configs[2]'s storage type):
+        # reported beside the fp32 headline, never as `value`
+        xb16, gb16 = xd.bfloat16(), gd.bfloat16()
+        ms_b = event_ms(lambda: ops.cond_grow(xb16, T, gb16, None, w, ALIVE_CH, seed=42), 5) / T
+        bpc = 2 * C * 2 + GOAL_CH * 2 + 2
+        result["bf16_storage"] = {"kernel": "cond_step_fwd_pc_kernel<16,true,StBF16>", "traffic": pmc_traffic("cond_step_fwd_pc_kernel", "StBF16"), "dtype": "bf16 storage, bf16 MFMA, f32 accumulate",
+                                  "value": cells / (ms_b * 1e-3), "unit": "cell-updates/s", "launch_ms": ms_b,
+                                  "algorithmic_bytes_per_cell": bpc, "hbm_GBs": cells * bpc / (ms_b * 1e-3) / 1e9,
+                                  "hbm_frac": cells * bpc / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                  "bound": "vector ALU / LDS issue (staging + perception), see DESIGN.md"}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(prm, x0, goal)
             result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]

@@ -209,3 +209,57 @@ def test_dynca_autograd_through_module():
     for k in ("w1.weight", "w1.bias", "w2.weight", "w2.bias"):
         gk = dict(d.named_parameters())[k].grad.cpu()
         assert float((gk - p[k].grad).abs().max()) / sc(p[k].grad) < 2e-4, k
+
+
+def test_dynca_multiscale_perception_and_steps():
+    """perception_scales=[0,1] (dynca.py:102-115): the reference's own perceive_multiscale output (golden G4 ms_x -> ms_y)
+    and free-running steps against the oracle; gradients flow through the composed path."""
+    from ncahip.models.dynca import DyNCA
+    from oracle import nca_oracle as O
+    g4 = load("g4_perception")
+    m = DyNCA(4, 3, fc_dim=8, padding_mode="replicate", conditioning="none", perception_scales=[0, 1], device=torch.device(DEV))
+    y = m.perceive_multiscale(T(g4["ms_x"]).to(DEV))
+    assert rel_err(y.cpu(), T(g4["ms_y"])) < REL_TOL
+    torch.manual_seed(0)
+    m = DyNCA(12, 3, fc_dim=32, padding_mode="circular", conditioning="edges", perception_scales=[0, 1], device=torch.device(DEV))
+    prm = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    x = torch.rand(2, 12, 32, 32) - 0.5
+    img = torch.rand(2, 1, 32, 32) * 2 - 1
+    cond = O.edge_extractor(img, "tanh")
+    us = [torch.rand(2, 1, 32, 32) for _ in range(4)]
+    ref = O.dynca_nsteps(x, cond, us, {"w1.weight": prm["w1.weight"], "w1.bias": prm["w1.bias"], "w2.weight": prm["w2.weight"],
+                                       "w2.bias": prm["w2.bias"]}, "circular", 0.5, scales=(0, 1))
+    xd = x.to(DEV)
+    condd = cond.to(DEV)
+    with torch.no_grad():
+        for u in us:
+            xd = m._step_multiscale(xd, condd, 0.5, u.to(DEV))
+    assert rel_err(xd.cpu(), ref) < REL_TOL
+    xg = x.to(DEV).requires_grad_(True)
+    out, rgb = m.forward_nsteps(xg, 2, cond_img=img.to(DEV))
+    rgb.square().mean().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all() and m.w1.weight.grad is not None
+
+
+def test_webgl_interchange_and_video_loop():
+    """Row f4: a model exported to the demo's JSON and loaded back steps identically; the frame-conditioned loop
+    (video_utils.py:66-83) yields steps_per_frame images per frame in [0,1] and carries the state across frames."""
+    from ncahip import video, webgl
+    from ncahip.models.dynca import DyNCA
+    g5 = load("g5_real_weights")
+    m = DyNCA(12, 3, fc_dim=96, padding_mode="circular", conditioning="edges", edge_transform="tanh", device=torch.device(DEV))
+    with torch.no_grad():
+        m.w1.weight.copy_(T(g5["w1"])); m.w1.bias.copy_(T(g5["b1"])); m.w2.weight.copy_(T(g5["w2"])); m.w2.bias.copy_(T(g5["b2"]))
+    m2 = webgl.load_dynca(webgl.export_dynca_json([m], ["starry-night"]), device=DEV)
+    assert m2.c_in == 12 and m2.fc_dim == 96 and m2.conditioning == "edges"
+    x = torch.rand(1, 12, 32, 32, device=DEV) - 0.5
+    img = torch.rand(1, 1, 32, 32, device=DEV) * 2 - 1
+    with torch.no_grad():
+        torch.manual_seed(1); a, _ = m.forward_nsteps(x, 6, cond_img=img)
+        torch.manual_seed(1); b, _ = m2.forward_nsteps(x, 6, cond_img=img)
+    assert rel_err(b.cpu(), a.cpu()) < 1e-4                       # texture quantisation of the weights: float32 round trip
+    frames = [torch.rand(3, 32, 48, device=DEV) * 2 - 1 for _ in range(3)]
+    outs = list(video.synthesize_video(m, frames, step_n=4, steps_per_frame=2))
+    assert len(outs) == 6 and outs[0].shape == (3, 32, 48)
+    assert all(float(o.min()) >= 0.0 and float(o.max()) <= 1.0 for o in outs)
+    assert not torch.equal(outs[0], outs[-1])

@@ -72,7 +72,8 @@ def test_dynca_surface():
     assert torch.equal(d.to_rgb(torch.ones(1, 12, 2, 2)), 2 * torch.ones(1, 3, 2, 2))
     with pytest.raises(AssertionError):
         DyNCA(12, 3, seed_mode="bogus", device=cpu)
-    with pytest.raises(NotImplementedError):
+    from ncahip._capi import NcaHipError
+    with pytest.raises(NcaHipError):          # multi-scale models run the HIP stencil too: no CPU path
         DyNCA(12, 3, perception_scales=[0, 1], device=cpu).forward(torch.zeros(1, 12, 8, 8), cond_img=torch.zeros(1, 1, 8, 8))
 
 
@@ -105,3 +106,32 @@ def test_sample_pool_semantics():
     p.scatter([0, 5], g[:2] + 1)
     assert torch.equal(p[0], seed + 1) and torch.equal(p[5], batch[1] + 1)
     assert [x is None for x in p.pool] == [False, False, False, True, False, False]
+
+
+def test_webgl_json_roundtrip_and_layout():
+    """export_dynca_json -> load_dynca_weights reproduces the weights to the texture's float precision, for one model and
+    for several tiled in one texture (convert_models_to_webgl.ipynb cell 1 / docs/dynca.js:827-872)."""
+    import torch.nn as nn
+    from ncahip import webgl
+
+    class Stub(nn.Module):
+        def __init__(self, seed, k1=51, fc=96, c=12):
+            super().__init__()
+            g = torch.Generator().manual_seed(seed)
+            self.w1, self.w2 = nn.Conv2d(k1, fc, 1), nn.Conv2d(fc, c, 1)
+            self.conditioning = "edges"
+            with torch.no_grad():
+                for p in self.parameters():
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+
+    ms = [Stub(s) for s in range(3)]
+    js = webgl.export_dynca_json(ms, ["a", "b", "c"])
+    assert js["layers"][0]["shape"] == [52, 96] and js["layers"][1]["shape"] == [97, 12]      # the demo's own shapes
+    assert js["layers"][0]["edge_conditioning"] and not js["layers"][1]["edge_conditioning"]
+    for i, m in enumerate(ms):
+        w = webgl.load_dynca_weights(js, index=i)
+        for k in ("w1.weight", "w1.bias", "w2.weight", "w2.bias"):
+            ref = dict(m.named_parameters())[k].detach()
+            assert torch.allclose(w[k], ref, atol=2e-6), (i, k)
+    with pytest.raises(IndexError):
+        webgl.decode_layer(js["layers"][0], index=7)

@@ -138,5 +138,31 @@ def test_overflow_loss_is_the_reference_formula():
     s = torch.tensor([[-3.0, -1.0, 0.2, 1.0, 2.5]])
     loss, log = L({"nca_state": s})
     assert abs(float(loss) - 2.0 * (2.0 + 0 + 0 + 0 + 1.5) / 5) < 1e-7 and set(log) == {"overflow"}
-    with pytest.raises(NotImplementedError):
-        Loss(torch.device("cpu"), appearance_loss_type="OT", target_style_image=torch.rand(3, 8, 8))
+    with pytest.raises(ValueError):
+        Loss(torch.device("cpu"), appearance_loss_type="bogus", target_style_image=torch.rand(3, 64, 64))
+
+
+def test_ot_loss_arithmetic():
+    """The 'OT' appearance term (appearance_loss.py:149-210) against an independent float64 evaluation of the same
+    formulas, including the numpy-stream sub-sampling for maps larger than 32x32."""
+    import numpy as np
+    import torch
+    from ncahip.loss import ot_loss_single
+    g = torch.Generator().manual_seed(0)
+    tgt = [torch.randn(1, 8, 16, 16, generator=g), torch.randn(1, 12, 40, 40, generator=g)]
+    gen = [torch.randn(1, 8, 16, 16, generator=g), torch.randn(1, 12, 40, 40, generator=g)]
+    np.random.seed(5)
+    got = float(ot_loss_single(tgt, gen))
+    np.random.seed(5)
+    ref = 0.0
+    for t, q in zip(tgt, gen):
+        c, h, w = t.shape[1:]
+        X, Y = t.reshape(c, -1).double().numpy(), q.reshape(c, -1).double().numpy()
+        if h > 32:
+            idx = np.sort(np.random.choice(np.arange(h * w), size=1000, replace=False))
+            X, Y = X[:, idx], Y[:, idx]
+        X, Y = X.T, Y.T
+        d = 1.0 - (X @ Y.T) / (np.linalg.norm(X, axis=1)[:, None] + 1e-10) / (np.linalg.norm(Y, axis=1)[None, :] + 1e-10)
+        ref += max(d.min(1).mean(), d.min(0).mean())
+        ref += np.abs(X.mean(0) - Y.mean(0)).mean() + np.abs(np.cov(X.T) - np.cov(Y.T)).mean()
+    assert abs(got - ref) < 1e-5 * max(1.0, abs(ref)), (got, ref)

@@ -95,3 +95,42 @@ def dynca_nsteps_autograd(model, x, cond, T, update_rate, want_states=False):
     out, states = ops.dynca_nsteps(x, T, cond, us, w, cfg["pad"], cfg["rate"], cfg["seed"], cfg["step0"],
                                    keep_history=want_states)
     return out, (states if want_states else None)
+
+
+# ------------------------------------------------------------------------------------ standalone stencil (multi-scale path)
+_SOBEL_X = ((-1.0, 0.0, 1.0), (-2.0, 0.0, 2.0), (-1.0, 0.0, 1.0))
+_LAPL = ((1.0, 2.0, 1.0), (2.0, -12.0, 2.0), (1.0, 2.0, 1.0))
+_TORCH_PAD = {"replicate": "replicate", "circular": "circular", "reflect": "reflect", "constant": "constant", "zeros": "constant"}
+
+
+def _perceive_ref(x, pad_mode):
+    """The same map as the HIP stencil in torch ops on the device -- used only to differentiate it (dynca.py:84-98)."""
+    c = x.shape[1]
+    sx = torch.tensor(_SOBEL_X, device=x.device)
+    filt = torch.stack([sx, sx.t(), torch.tensor(_LAPL, device=x.device)])
+    z = torch.nn.functional.pad(x, [1, 1, 1, 1], _TORCH_PAD[pad_mode])
+    ys = [torch.nn.functional.conv2d(z, f.reshape(1, 1, 3, 3).repeat(c, 1, 1, 1), groups=c) for f in filt]
+    return torch.cat([x] + ys, dim=1)
+
+
+class _HipPerceive(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pad_mode):
+        ctx.pad_mode = pad_mode
+        ctx.save_for_backward(x)
+        return ops.dynca_perceive(x, pad_mode)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        with torch.enable_grad():
+            xr = x.detach().requires_grad_(True)
+            (gx,) = torch.autograd.grad(_perceive_ref(xr, ctx.pad_mode), xr, gy)
+        return gx, None
+
+
+def hip_perceive(x: torch.Tensor, pad_mode: str) -> torch.Tensor:
+    x = x.float().contiguous()
+    if _needs_grad(x):
+        return _HipPerceive.apply(x, pad_mode)
+    return ops.dynca_perceive(x, pad_mode)

@@ -4,13 +4,15 @@ In scope here: the overflow term (loss.py:37-40), exact.  The VGG16 appearance /
 "next" row f2 of SURVEY.md section 8: torchvision and the ImageNet weights are not available offline, so the
 feature extractor below is a pure-torch VGG16-features definition that loads a local `vgg16-397923af.pth`
 when NCAHIP_VGG16_WEIGHTS points at one and otherwise runs with seeded random weights (timing stand-in;
-loss values vs the reference are then "parity unpinned").  Appearance types: 'Gram' and 'SlW' (sliced
-Wasserstein, project-sort); the reference's default 'OT' (relaxed EMD, appearance_loss.py:139-244) is not
-restated yet and raises.
+loss values vs the reference are then "parity unpinned").  Appearance types: 'OT' (the reference's default: relaxed
+EMD over cosine distances + first/second moment matching, appearance_loss.py:149-220), 'Gram' and 'SlW' (sliced
+Wasserstein, project-sort).  The OT arithmetic itself is pinned by tests/test_trainer_logic.py against an independent
+float64 evaluation of the same formulas.
 """
 import os
 import warnings
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -80,6 +82,44 @@ def _sliced_wasserstein(a, b, n_proj=32):
     return ((pa - pb) ** 2).mean()
 
 
+def _pairwise_cos(x, y):
+    """appearance_loss.py:150-156: 1 - <x_i, y_j> / (|x_i| + 1e-10) / (|y_j| + 1e-10), x [N,d], y [M,d]."""
+    xn = torch.sqrt((x ** 2).sum(1)).view(-1, 1)
+    yn = torch.sqrt((y ** 2).sum(1)).view(1, -1)
+    return 1.0 - torch.mm(x, y.t()) / (xn + 1e-10) / (yn + 1e-10)
+
+
+def _relaxed_emd(x, y):
+    """appearance_loss.py:158-174: max of the two mean nearest-neighbour cosine distances."""
+    d = _pairwise_cos(x, y)
+    return torch.max(d.min(1)[0].mean(), d.min(0)[0].mean())
+
+
+def _moment_loss(x, y):
+    """appearance_loss.py:176-192: mean |mu_x - mu_y| + mean |cov_x - cov_y| (unbiased covariances), x [N,d], y [M,d]."""
+    mx, my = x.mean(0, keepdim=True), y.mean(0, keepdim=True)
+    xc, yc = x - mx, y - my
+    cx = torch.mm(xc.t(), xc) / (x.shape[0] - 1)
+    cy = torch.mm(yc.t(), yc) / (y.shape[0] - 1)
+    return (mx - my).abs().mean() + (cx - cy).abs().mean()
+
+
+def ot_loss_single(target_feats, gen_feats, n_samples=1000):
+    """appearance_loss.py:194-210 for ONE generated image: per style layer, (sub-sampled when the map is larger than
+    32x32: np.random.choice(h*w, 1000, replace=False), sorted -- the same consumption of numpy's global stream) relaxed
+    EMD + moment loss between the target's and the image's feature vectors."""
+    loss = 0
+    for t, gfeat in zip(target_feats, gen_feats):
+        c, h, w = t.shape[1], t.shape[2], t.shape[3]
+        tv, gv = t.reshape(c, -1), gfeat.reshape(c, -1)
+        if h > 32:
+            idx = torch.as_tensor(np.sort(np.random.choice(np.arange(h * w), size=n_samples, replace=False)), device=t.device)
+            tv, gv = tv[:, idx], gv[:, idx]
+        tv, gv = tv.t(), gv.t()          # [N, d]
+        loss = loss + _relaxed_emd(tv, gv) + _moment_loss(tv, gv)
+    return loss
+
+
 class Loss(nn.Module):
     def __init__(self, device, content_loss_weight=1.0, overflow_loss_weight=1.0, appearance_loss_weight=1.0,
                  appearance_loss_type="OT", target_style_image=None):
@@ -94,9 +134,8 @@ class Loss(nn.Module):
             self.loss_weights["overflow"] = overflow_loss_weight
         if appearance_loss_weight != 0:
             assert target_style_image is not None, "Target style image required to use appearance loss"
-            if appearance_loss_type not in ("Gram", "SlW"):
-                raise NotImplementedError(f"ncahip.loss: appearance_loss_type={appearance_loss_type!r} is not restated yet "
-                                          "(SURVEY.md section 8 row f2); use 'SlW' or 'Gram'")
+            if appearance_loss_type not in ("OT", "Gram", "SlW"):
+                raise ValueError(f"ncahip.loss: unknown appearance_loss_type={appearance_loss_type!r}")
             self.loss_weights["appearance"] = appearance_loss_weight
         if content_loss_weight != 0:
             self.loss_weights["content"] = content_loss_weight
@@ -127,7 +166,12 @@ class Loss(nn.Module):
             gf = self.vgg(gen, tuple(sorted(need)))
             if "appearance" in self.loss_weights:
                 acc = 0
-                for l in STYLE_LAYERS:
+                if self.appearance_loss_type == "OT":    # appearance_loss.py:212-220: mean over the batch
+                    tgt = [self.style_feats[l] for l in STYLE_LAYERS]
+                    for b in range(gen.shape[0]):
+                        acc = acc + ot_loss_single(tgt, [gf[l][b:b + 1] for l in STYLE_LAYERS])
+                    acc = acc / gen.shape[0]
+                for l in (STYLE_LAYERS if self.appearance_loss_type != "OT" else ()):
                     if self.appearance_loss_type == "Gram":
                         acc = acc + F.mse_loss(_gram(gf[l]), _gram(self.style_feats[l]).expand(gf[l].shape[0], -1, -1))
                     else:

@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..autograd import dynca_nsteps_autograd
+from ..autograd import dynca_nsteps_autograd, hip_perceive
 
 
 class EdgeExtractor(nn.Module):
@@ -114,28 +114,50 @@ class DyNCA(nn.Module):
         with torch.no_grad():  # dynca.py:123: no gradient into the edge map
             return self.cond_layer(cond_img).float().contiguous()
 
-    def _single_scale(self):
-        if list(self.perception_scales) != [0]:
-            raise NotImplementedError(
-                "ncahip DyNCA: multi-scale perception (perception_scales != [0], dynca.py:102-115) is not in the HIP "
-                "path yet (SURVEY.md section 8 row f3)")
+    def _multiscale(self) -> bool:
+        return list(self.perception_scales) != [0]
 
     # ------------------------------------------------------------------ reference surface
     def perceive_torch(self, x, scale=0):
+        """dynca.py:75-100: [x, Sx*x, Sy*x, L*x]; scale > 0: bilinear down by 2^scale, perceive, bilinear up.  The stencil
+        is the HIP kernel (ncahip_dynca_perceive_f32); the two resamplings are torch ops on the device."""
         assert scale in [0, 1, 2, 3, 4, 5]
-        if scale != 0:
-            self._single_scale()
-        return ops.dynca_perceive(x.float(), self.padding_mode)
+        x = x.float()
+        if scale == 0:
+            return hip_perceive(x, self.padding_mode)
+        _, _, h, w = x.shape
+        xs = F.interpolate(x, size=(int(h // (2 ** scale)), int(w // (2 ** scale))), mode="bilinear", align_corners=False)
+        return F.interpolate(hip_perceive(xs, self.padding_mode), size=(h, w), mode="bilinear", align_corners=False)
 
     def perceive_multiscale(self, x, cond_mat=None):
-        self._single_scale()
-        y = self.perceive_torch(x, 0)
+        """dynca.py:102-115: mean over perception_scales, then the conditioning channels."""
+        y = sum(self.perceive_torch(x, scale=s) for s in self.perception_scales) / len(self.perception_scales)
         return y if cond_mat is None else torch.cat([y, cond_mat], dim=1)
 
+    def _step_multiscale(self, x, cond, update_rate, u):
+        """One step with perception_scales != [0] (dynca.py:117-138).  Not fused: HIP stencil per scale + device
+        resampling + the two 1x1 convolutions as library GEMMs (the fused kernel covers the
+        single-scale models)."""
+        y = self.perceive_multiscale(x, cond)
+        dx = self.w2(F.relu(self.w1(y)))
+        mask = torch.floor(u + update_rate)
+        return x + dx * mask
+
+    def _draw_one(self, x):
+        b, _, h, w = x.shape
+        if self.mask_rng == "philox":
+            u = ops.philox_uniform(b, h, w, self.mask_seed, self._mask_step, device=x.device)
+        else:
+            u = torch.rand(b, 1, h, w, device=x.device)        # dynca.py:131
+        self._mask_step += 1
+        return u
+
     def forward(self, x, update_rate=0.5, return_perception=False, cond_img=None):
-        self._single_scale()
         cond = self._cond(x, cond_img)
-        out, _ = dynca_nsteps_autograd(self, x, cond, 1, update_rate)
+        if self._multiscale():
+            out = self._step_multiscale(x.float(), cond, update_rate, self._draw_one(x))
+        else:
+            out, _ = dynca_nsteps_autograd(self, x, cond, 1, update_rate)
         if return_perception:
             return out, self.to_rgb(out), self.perceive_multiscale(x, cond)
         return out, self.to_rgb(out)
@@ -160,8 +182,14 @@ class DyNCA(nn.Module):
         return sd.repeat(n, 1, 1, 1).to(self.device)
 
     def forward_nsteps(self, input_state, step_n, update_rate=0.5, return_middle_feature=False, cond_img=None):
-        self._single_scale()
         cond = self._cond(input_state, cond_img)
+        if self._multiscale():
+            x, mids = input_state.float(), []
+            for _ in range(step_n):
+                x = self._step_multiscale(x, cond, update_rate, self._draw_one(x))
+                if return_middle_feature:
+                    mids.append(self.to_rgb(x))
+            return (x, self.to_rgb(x), mids) if return_middle_feature else (x, self.to_rgb(x))
         out, states = dynca_nsteps_autograd(self, input_state, cond, step_n, update_rate,
                                             want_states=return_middle_feature)
         feature = self.to_rgb(out)
