@@ -79,6 +79,7 @@ __device__ __forceinline__ f32x4 nca_mfma(float a, float b, f32x4 c) {
 // group walks one contiguous chunk of the tile list (spatially adjacent tiles share halos).
 struct NcaTileWalk {
     int t, end, stride;
+    int base, local;   // t = base + local: first tile of this XCD's chunk, rank of the workgroup inside the XCD
 };
 __device__ __forceinline__ NcaTileWalk nca_tile_walk(int ntiles) {
     const int nwg = gridDim.x, wg = blockIdx.x;
@@ -90,5 +91,7 @@ __device__ __forceinline__ NcaTileWalk nca_tile_walk(int ntiles) {
     w.t = xcd * chunk + local;
     w.end = min(ntiles, (xcd + 1) * chunk);
     w.stride = nloc;
+    w.base = xcd * chunk;
+    w.local = local;
     return w;
 }

@@ -87,17 +87,29 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
     const int st_x = (W + PSTW - 1) / PSTW, st_y = (H + PSTH - 1) / PSTH;
     const int halo = a.alive_ch >= 0 ? 3 : 1;
     NcaTileWalk tw = nca_tile_walk(a.B * st_x * st_y);
-    // super-tile coordinates advance incrementally (no integer division per tile)
-    struct Pos { int t, sx, sy, b; };
-    auto advance = [&](Pos p) -> Pos {
-        p.t += tw.stride;
-        p.sx += tw.stride;
-        while (p.sx >= st_x) {
-            p.sx -= st_x;
-            if (++p.sy == st_y) { p.sy = 0; ++p.b; }
+    // Round k of the XCD's chunk hands tile base + k*nloc + ((local + k) mod nloc) to this workgroup: the nloc workgroups
+    // of an XCD still sweep nloc consecutive super-tiles together (shared halos in its L2), but the rotation walks every
+    // workgroup across the columns of the image -- with the plain stride a workgroup whose first tile sits on the left or
+    // right image border gets ONLY border tiles (nloc = 32 is a multiple of the 16 super-tile columns at 256^2) and
+    // finishes ~8 % after the others.
+    struct Pos { int k, t, sx, sy, b; };
+    const int n_rounds = (tw.end - tw.base + tw.stride - 1) / tw.stride;
+    auto pos_of = [&](int k) -> Pos {
+        Pos p{k, tw.end, 0, 0, 0};
+        if (k < n_rounds) {
+            int r = tw.local + k;
+            while (r >= tw.stride) r -= tw.stride;
+            p.t = tw.base + k * tw.stride + r;
+            if (p.t < tw.end) {
+                p.sx = p.t % st_x;
+                const int q = p.t / st_x;
+                p.sy = q % st_y;
+                p.b = q / st_y;
+            }
         }
         return p;
     };
+    auto advance = [&](const Pos& p) -> Pos { return pos_of(p.k + 1); };
     auto tile_of = [&](const Pos& p) -> WTile {
         WTile w{0, 0, 0, false, false};
         if (p.t < tw.end) {
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
     };
 
     int which = 0;
-    Pos pos{tw.t, tw.t % st_x, (tw.t / st_x) % st_y, tw.t / (st_x * st_y)};   // one division per kernel
+    Pos pos = pos_of(0);
     WTile cur = tile_of(pos);
     // The two roles run separate loops with the same barrier count (all branches are wave-uniform): the consumer's
     // 128 weight registers are then not live in the producer's code and vice versa.
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
         NCA_KSTAMP(1);
         __syncthreads();              // weight image + first tile ready
         NCA_KSTAMP(2);
-        while (pos.t < tw.end) {      // uniform over the workgroup
+        while (pos.k < n_rounds) {    // uniform over the workgroup
             const Pos pn = advance(pos);
             const WTile nxt = tile_of(pn);
 #ifdef NCA_STAMPS
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
         NCA_KSTAMP(2);
         if constexpr (BF) load_weights_bf16<CP, EXACT>(a, lane, Wb);
         else mlp_load_regs<CP>(smem, lane, Wr);
-        while (pos.t < tw.end) {
+        while (pos.k < n_rounds) {
             const Pos pn = advance(pos);
             const WTile nxt = tile_of(pn);
             NCA_STAMP(0);

@@ -375,6 +375,10 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                 }
             } else {
                 // ---- MLP on MFMA: layer 1 streamed tile-by-tile into layer 2 -----------------
+                // Issue order (see nca_cond_tile.h, mlp_tile_regs): the A operands of hidden tile m+1 are read from LDS
+                // while tile m's MFMA chain runs (an LDS read next to its use stalls the in-order pipe for the whole
+                // latency), and the ReLUs are issued as ONE fenced group per tile (a VALU instruction inside an f32 MFMA
+                // stream drains the matrix pipe: ~25 cycles each when scattered).
                 f32x4 acc2[K::M2T][NT];
     #pragma unroll
                 for (int m2 = 0; m2 < K::M2T; ++m2) {
@@ -382,30 +386,48 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
     #pragma unroll
                     for (int n = 0; n < NT; ++n) acc2[m2][n] = bias;
                 }
-    #pragma unroll 1
-                for (int m = 0; m < K::M1T; ++m) {
+                float wa1[K::K1S], wa2[4][K::M2T];
+                f32x4 bias1;
+                auto fetch = [&](int m) {
                     const float* const w1m = W1L + m * K::K1S * 64 + lane;
-                    const f32x4 bias = *reinterpret_cast<const f32x4*>(B1L + 16 * m + 4 * g);
-                    f32x4 acc1[NT];
     #pragma unroll
-                    for (int n = 0; n < NT; ++n) acc1[n] = bias;
-    #pragma unroll
-                    for (int s = 0; s < K::K1S; ++s) {
-                        const float wa = w1m[s * 64];
-    #pragma unroll
-                        for (int n = 0; n < NT; ++n) acc1[n] = nca_mfma(wa, P[n][s], acc1[n]);
-                    }
+                    for (int s = 0; s < K::K1S; ++s) wa1[s] = w1m[s * 64];
                     const float* const w2m = W2L + (4 * m) * 64 + lane;
     #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < 4; ++r)
     #pragma unroll
-                        for (int m2 = 0; m2 < K::M2T; ++m2) {
-                            const float wa = w2m[(m2 * K::K2S + r) * 64];
+                        for (int m2 = 0; m2 < K::M2T; ++m2) wa2[r][m2] = w2m[(m2 * K::K2S + r) * 64];
+                    bias1 = *reinterpret_cast<const f32x4*>(B1L + 16 * m + 4 * g);
+                };
+                fetch(0);
+    #pragma unroll 1
+                for (int m = 0; m < K::M1T; ++m) {
+                    f32x4 acc1[NT];
     #pragma unroll
-                            for (int n = 0; n < NT; ++n)
-                                acc2[m2][n] = nca_mfma(wa, fmaxf(acc1[n][r], 0.0f), acc2[m2][n]);
-                        }
-                    }
+                    for (int n = 0; n < NT; ++n) acc1[n] = bias1;
+    #pragma unroll
+                    for (int s = 0; s < K::K1S; ++s)
+    #pragma unroll
+                        for (int n = 0; n < NT; ++n) acc1[n] = nca_mfma(wa1[s], P[n][s], acc1[n]);
+                    float w2c[4][K::M2T];
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r)
+    #pragma unroll
+                        for (int m2 = 0; m2 < K::M2T; ++m2) w2c[r][m2] = wa2[r][m2];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m + 1 < K::M1T) fetch(m + 1);        // in flight across this tile's layer-2 MFMAs and the next chain
+                    float h[NT][4];
+    #pragma unroll
+                    for (int n = 0; n < NT; ++n)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) h[n][r] = __int_as_float(max(__float_as_int(acc1[n][r]), 0));   // relu
+                    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r)
+    #pragma unroll
+                        for (int m2 = 0; m2 < K::M2T; ++m2)
+    #pragma unroll
+                            for (int n = 0; n < NT; ++n) acc2[m2][n] = nca_mfma(w2c[r][m2], h[n][r], acc2[m2][n]);
                 }
                 // ---- residual + stochastic mask (dynca.py:131-133) ---------------------------
     #pragma unroll
