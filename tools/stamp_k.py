@@ -37,6 +37,10 @@ def run(tag, seed=0, bf16=False):
     L.nca_debug_set_stamp_buffer_pc(None)
     k = buf[NWG * 8 * 8 * 16:].cpu().numpy().reshape(NWG, 8, 8).astype(np.float64)
     v = k[:, 0:4]
+    if seed == 0:
+        c = k[:, 0:4]
+        d = [np.median(c[..., 4] - c[..., 2])] + [np.median(c[..., 5 + i] - c[..., 4 + i]) for i in range(3)]
+        print("   consumer: cycles for tile 0 (from the first barrier), 1, 2, 3:", " ".join("%.0f" % v for v in d))
     print(f"{tag:34s} startup {np.median(v[..., 2] - v[..., 0]):7.0f}   loop {np.median(v[..., 3] - v[..., 2]):8.0f} = {np.median(v[..., 3] - v[..., 2]) / 8:7.0f} per tile   whole {np.median(v[..., 3] - v[..., 0]):8.0f} cycles")
 
 run("normal")

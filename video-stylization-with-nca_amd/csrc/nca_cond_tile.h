@@ -114,6 +114,35 @@ __device__ __forceinline__ void fill_image_w(float* __restrict__ dst, const floa
     }
 }
 
+// Two-phase variant: every image's loads are issued before the first one is waited for (fill_image_w waits per batch
+// of 8 -- eight cold round trips in a row at kernel start).  Validity travels as a bit mask in one VGPR.
+template <int N, int NTHR>
+struct FillRegs {
+    static constexpr int PER = (N + NTHR - 1) / NTHR;
+    static_assert(PER <= 32, "one mask word");
+    float v[PER];
+    unsigned ok;
+};
+template <int N, int NTHR, typename MapT>
+__device__ __forceinline__ void fill_load(FillRegs<N, NTHR>& r, const float* __restrict__ src, int tid, MapT map) {
+    r.ok = 0u;
+#pragma unroll
+    for (int u = 0; u < FillRegs<N, NTHR>::PER; ++u) {
+        const int idx = tid + NTHR * u;
+        const long o = idx < N ? map(idx) : -1;
+        r.ok |= (o >= 0 ? 1u : 0u) << u;
+        r.v[u] = src[o >= 0 ? o : 0];
+    }
+}
+template <int N, int NTHR>
+__device__ __forceinline__ void fill_store(const FillRegs<N, NTHR>& r, float* __restrict__ dst, int tid) {
+#pragma unroll
+    for (int u = 0; u < FillRegs<N, NTHR>::PER; ++u) {
+        const int idx = tid + NTHR * u;
+        if (idx < N) dst[idx] = ((r.ok >> u) & 1u) ? r.v[u] : 0.0f;
+    }
+}
+
 // LDS arrays of one tile (all rows RS floats wide, image col tx0+c <-> index c+4; see WCfg for the sizes)
 struct TileLds {
     float* Z;     // z = x + goal*pre, halo 1: [CP][6][RS]
@@ -834,7 +863,10 @@ __device__ __forceinline__ void load_weights_bf16(const NcaCondArgs& a, int lane
             for (int r = 0; r < 4; ++r) {
                 const int o = 16 * m2 + i, k = 16 * m + 4 * g + r;
                 if (EXACT) {
-                    v[r] = a.w2[o * hid + k];
+                    if (r == 0) {   // k = 16m + 4g + r: the four r's are one 16-byte slice of row o (64 floats per row)
+                        const f32x4 q4 = ld4(a.w2 + o * hid + k);
+                        v[0] = q4[0]; v[1] = q4[1]; v[2] = q4[2]; v[3] = q4[3];
+                    }
                 } else {
                     const bool ok = o < hid && k < hid;
                     const float w = a.w2[ok ? o * hid + k : 0];
@@ -850,7 +882,10 @@ __device__ __forceinline__ void load_weights_bf16(const NcaCondArgs& a, int lane
             for (int r = 0; r < 4; ++r) {
                 const int o = 16 * m3 + i, k = 16 * m + 4 * g + r;
                 if (EXACT) {
-                    v[r] = a.w3[(row3 ? o : 0) * hid + k];
+                    if (r == 0) {
+                        const f32x4 q4 = ld4(a.w3 + (row3 ? o : 0) * hid + k);
+                        v[0] = q4[0]; v[1] = q4[1]; v[2] = q4[2]; v[3] = q4[3];
+                    }
                 } else {
                     const bool ok = o < C && k < hid;
                     const float w = a.w3[ok ? o * hid + k : 0];
