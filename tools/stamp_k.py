@@ -38,6 +38,8 @@ def run(tag, seed=0, bf16=False):
     k = buf[NWG * 8 * 8 * 16:].cpu().numpy().reshape(NWG, 8, 8).astype(np.float64)
     v = k[:, 0:4]
     if seed == 0:
+        print("   entry -> first barrier arrival: consumers %.0f   producers %.0f" % (
+            np.median(k[:, 0:4, 1] - k[:, 0:4, 0]), np.median(k[:, 4:8, 1] - k[:, 4:8, 0])))
         c = k[:, 0:4]
         d = [np.median(c[..., 4] - c[..., 2])] + [np.median(c[..., 5 + i] - c[..., 4 + i]) for i in range(3)]
         print("   consumer: cycles for tile 0 (from the first barrier), 1, 2, 3:", " ".join("%.0f" % v for v in d))

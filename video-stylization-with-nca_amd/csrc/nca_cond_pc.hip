@@ -35,7 +35,7 @@ struct PCfg {
 
 template <int CP, bool EXACT, typename ST>
 __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const NcaCondArgs a) {
-    constexpr bool BF = ST::BYTES == 2;   // bf16 storage: bf16 MFMA operands straight from the weight tensors, no LDS image
+    constexpr bool BF = ST::BYTES == 2;   // bf16 storage: UpdateNet on bf16 MFMA (operands rounded from the same LDS image)
     using K = WCfg<CP>;
     using PK = PCfg<CP>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
         FillRegs<K::M3T * 16 * 64, 256> f3;
         FillRegs<K::HID, 256> fb1, fb2;
         FillRegs<CP * K::WPS, 256> fwp;
-        if (!BF) {
+        {
             fill_load(f1, a.w1, tid, [&](int idx) -> long {
                 const int j = idx & 3, l = (idx >> 2) & 63, q = (idx >> 8) % K::K1S4, m = (idx >> 8) / K::K1S4;
                 const int s = 4 * q + j, gg = l >> 4, o = 16 * m + (l & 15);
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
             const int ch = idx / K::WPS, j = idx % K::WPS;
             return (ch < C && j < 27) ? (long)ch * 27 + j : -1;
         });
-        if (!BF) {
+        {
             fill_store(f1, smem + K::OFF_W1, tid);
             fill_store(f2, smem + K::OFF_W2, tid);
             fill_store(f3, smem + K::OFF_W3, tid);
@@ -223,12 +223,11 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
         }
         NCA_KSTAMP(3);
     } else {
-        // bf16 operands come straight from the weight tensors: their (cold) loads overlap the producers' first tile
-        if constexpr (BF) load_weights_bf16<CP, EXACT>(a, lane, Wb);
         NCA_KSTAMP(1);
         __syncthreads();
         NCA_KSTAMP(2);
-        if constexpr (!BF) mlp_load_regs<CP>(smem, lane, Wr);
+        if constexpr (BF) load_weights_bf16_lds<CP>(smem, lane, Wb);   // same image, rounded to bf16 operand pairs
+        else mlp_load_regs<CP>(smem, lane, Wr);
         while (pos.k < n_rounds) {
             const Pos pn = advance(pos);
             const WTile nxt = tile_of(pn);
@@ -297,8 +296,7 @@ hipError_t nca_launch_cond_step_fwd_pc(const NcaCondArgs& a_in, hipStream_t st) 
 hipError_t nca_launch_cond_step_fwd_bf16(const NcaCondArgs& a_in, hipStream_t st) {
     NcaCondArgs a = a_in;
     a.dbg = g_stamp_pc;
-    // the EXACT instantiations read w2 / w3 as 16-byte slices
-    const bool h64 = a.hidden == 64 && (((uintptr_t)a.w2 | (uintptr_t)a.w3) & 15) == 0;
+    const bool h64 = a.hidden == 64;
     if (a.C == 12 && h64) return launch_cond_pc<12, true, StBF16>(a, st);
     if (a.C == 16 && h64) return launch_cond_pc<16, true, StBF16>(a, st);
     if (a.C <= 12) return launch_cond_pc<12, false, StBF16>(a, st);

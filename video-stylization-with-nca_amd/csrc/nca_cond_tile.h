@@ -831,70 +831,26 @@ struct MlpRegsBf {
 };
 // A operands from the f32 weight tensors (nca.py:40-46 layouts), rounded to bf16.  Lane (g, i): row o = 16*tile + i,
 // k = 4g + r.  Layer 1's k order follows perceive_tile: slot q = 4s + r = 3*c4 + f is channel 4*c4 + g, filter f.
-// EXACT (C == CP, hidden == 64): every guard is decided at compile time except "row i < C" of layer 3 -- no per-load
-// lane masks (each is an SGPR pair that would stay live from its load to its select: 128 of them spill the whole kernel).
-template <int CP, bool EXACT = false>
-__device__ __forceinline__ void load_weights_bf16(const NcaCondArgs& a, int lane, MlpRegsBf<CP>& R) {
-    using K = MlpRegsBf<CP>;
-    const int g = lane >> 4, i = lane & 15, C = EXACT ? CP : a.C, hid = EXACT ? 64 : a.hidden, K1 = 3 * C;
-    const bool row3 = i < C;
+// bf16 A operands from the workgroup's f32 A-operand image in LDS (built cooperatively: every weight is fetched from
+// memory once per workgroup; loading them per wave straight from the tensors cost 19 K instead of 7 K cycles of cold start).  The image's k order of layer 1
+// (k-step s = 4q + j <-> channel 4*(s/3) + g, filter s%3) is exactly the bf16 slot order q' = 4s' + r.
+template <int CP>
+__device__ __forceinline__ void load_weights_bf16_lds(const float* __restrict__ WS, int lane, MlpRegsBf<CP>& R) {
+    using K = WCfg<CP>;
+    using KB = MlpRegsBf<CP>;
+    static_assert(KB::KS1 == K::K1S4 && KB::M3T == K::M3T, "image layout");
+    const f32x4* const W1V = reinterpret_cast<const f32x4*>(WS + K::OFF_W1) + lane;
+    const f32x4* const W2V = reinterpret_cast<const f32x4*>(WS + K::OFF_W2) + lane;
+    const f32x4* const W3V = reinterpret_cast<const f32x4*>(WS + K::OFF_W3) + lane;
+    auto pk = [](f32x4 v) { return pack4(v[0], v[1], v[2], v[3]); };
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
 #pragma unroll
-        for (int s = 0; s < K::KS1; ++s) {
-            float v[4];
+        for (int s = 0; s < KB::KS1; ++s) R.w1[m][s] = pk(W1V[(m * K::K1S4 + s) * 64]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = 4 * s + r, ch = 4 * (q / 3) + g, f = q % 3, o = 16 * m + i;
-                if (EXACT) {
-                    v[r] = q < K::K1S ? a.w1[o * K1 + 3 * ch + f] : 0.0f;
-                } else {
-                    const bool ok = q < K::K1S && ch < C && o < hid;
-                    const float w = a.w1[ok ? o * K1 + 3 * ch + f : 0];
-                    v[r] = ok ? w : 0.0f;
-                }
-            }
-            R.w1[m][s] = pack4(v[0], v[1], v[2], v[3]);
-        }
+        for (int m2 = 0; m2 < 4; ++m2) R.w2[m2][m] = pk(W2V[(m2 * 4 + m) * 64]);
 #pragma unroll
-        for (int m2 = 0; m2 < 4; ++m2) {
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 16 * m2 + i, k = 16 * m + 4 * g + r;
-                if (EXACT) {
-                    if (r == 0) {   // k = 16m + 4g + r: the four r's are one 16-byte slice of row o (64 floats per row)
-                        const f32x4 q4 = ld4(a.w2 + o * hid + k);
-                        v[0] = q4[0]; v[1] = q4[1]; v[2] = q4[2]; v[3] = q4[3];
-                    }
-                } else {
-                    const bool ok = o < hid && k < hid;
-                    const float w = a.w2[ok ? o * hid + k : 0];
-                    v[r] = ok ? w : 0.0f;
-                }
-            }
-            R.w2[m2][m] = pack4(v[0], v[1], v[2], v[3]);
-        }
-#pragma unroll
-        for (int m3 = 0; m3 < K::M3T; ++m3) {
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 16 * m3 + i, k = 16 * m + 4 * g + r;
-                if (EXACT) {
-                    if (r == 0) {
-                        const f32x4 q4 = ld4(a.w3 + (row3 ? o : 0) * hid + k);
-                        v[0] = q4[0]; v[1] = q4[1]; v[2] = q4[2]; v[3] = q4[3];
-                    }
-                } else {
-                    const bool ok = o < C && k < hid;
-                    const float w = a.w3[ok ? o * hid + k : 0];
-                    v[r] = ok ? w : 0.0f;
-                }
-            }
-            R.w3[m3][m] = pack4(v[0], v[1], v[2], v[3]);
-            if (EXACT && !row3) R.w3[m3][m] = s16x4{0, 0, 0, 0};
-        }
+        for (int m3 = 0; m3 < KB::M3T; ++m3) R.w3[m3][m] = pk(W3V[(m3 * 4 + m) * 64]);
     }
 }
 
