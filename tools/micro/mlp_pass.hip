@@ -22,14 +22,14 @@ __global__ __launch_bounds__(256, 2) void pass_kernel(const float* __restrict__ 
         for (int s = 0; s < K::K1S; ++s) P[n][s] = in[(lane * 31 + n * 17 + s) & 0xFFFFF];
     const unsigned long long c0 = clock64();
     for (int it = 0; it < iters; ++it) {
-        if (VAR == 0) mlp_tile_regs<CP, NT>(Wr, XR, MK, lane, 0, P);
+        if (VAR == 0) mlp_tile_regs<CP, NT>(Wr, smem, XR, MK, lane, 0, P);
         if (VAR == 1) {   // same MFMA count and dependency structure, no relu
             f32x4 acc2[4][NT];
-            for (int m2 = 0; m2 < 4; ++m2) for (int n = 0; n < NT; ++n) acc2[m2][n] = Wr.b2[m2];
+            for (int m2 = 0; m2 < 4; ++m2) for (int n = 0; n < NT; ++n) acc2[m2][n] = ld4(smem + K::OFF_B2 + 16 * m2 + 4 * (lane >> 4));
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 f32x4 acc1[NT];
-                for (int n = 0; n < NT; ++n) acc1[n] = Wr.b1[m];
+                for (int n = 0; n < NT; ++n) acc1[n] = ld4(smem + K::OFF_B1 + 16 * m + 4 * (lane >> 4));
 #pragma unroll
                 for (int s = 0; s < K::K1S; ++s)
 #pragma unroll
@@ -52,11 +52,11 @@ __global__ __launch_bounds__(256, 2) void pass_kernel(const float* __restrict__ 
         }
         if (VAR == 2 || VAR == 3) {   // relus of one hidden tile issued as ONE group (VAR 3: fenced with sched_barrier)
             f32x4 acc2[4][NT];
-            for (int m2 = 0; m2 < 4; ++m2) for (int n = 0; n < NT; ++n) acc2[m2][n] = Wr.b2[m2];
+            for (int m2 = 0; m2 < 4; ++m2) for (int n = 0; n < NT; ++n) acc2[m2][n] = ld4(smem + K::OFF_B2 + 16 * m2 + 4 * (lane >> 4));
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 f32x4 acc1[NT];
-                for (int n = 0; n < NT; ++n) acc1[n] = Wr.b1[m];
+                for (int n = 0; n < NT; ++n) acc1[n] = ld4(smem + K::OFF_B1 + 16 * m + 4 * (lane >> 4));
 #pragma unroll
                 for (int s = 0; s < K::K1S; ++s)
 #pragma unroll

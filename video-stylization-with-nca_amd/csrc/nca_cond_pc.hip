@@ -169,8 +169,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
                     for (int s_ = 0; s_ < K::K1S; ++s_) P[n][s_] = L.Z[lane + n];
             } else
 #endif
-            if constexpr (BF) perceive_tile_pipe<CP, NT>(smem, L.Z, lane, pass * NT, P);
-            else perceive_tile<CP, NT>(smem, L.Z, lane, pass * NT, P);
+            perceive_tile_pipe<CP, NT>(smem, L.Z, lane, pass * NT, P);   // next channel group's LDS reads in flight
             if (pass == 0) NCA_STAMP(5);
 #ifdef NCA_STAMPS
             if (a.seed == 0xD1A9ull || a.seed == 0xD1ABull || a.seed == 0xD1ADull) {
@@ -183,7 +182,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
             } else
 #endif
             if constexpr (BF) mlp_tile_bf16<CP, NT>(Wb, smem + K::OFF_B1, smem + K::OFF_B2, L.XR, L.MK, lane, pass * NT, P);
-            else mlp_tile_regs<CP, NT>(Wr, L.XR, L.MK, lane, pass * NT, P);
+            else mlp_tile_regs<CP, NT>(Wr, smem, L.XR, L.MK, lane, pass * NT, P);
             if (pass == 0) NCA_STAMP(6);
         }
         NCA_STAMP(7);
@@ -238,7 +237,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
             consume(cur, which);
             if (tile_no < 4) NCA_KSTAMP(4 + tile_no);   // light stamps: end of the first four tiles (cold-start profile)
             NCA_STAMP(1);
-            __syncthreads();
+            __syncthreads();   // (workgroup scope: lgkmcnt(0) + s_barrier -- the tile's global stores are not waited for)
             NCA_STAMP(2);
             cur = nxt;
             pos = pn;

@@ -690,7 +690,7 @@ __device__ __forceinline__ void mlp_tile(const NcaCondArgs& a, const float* __re
 template <int CP>
 struct MlpRegs {
     using K = WCfg<CP>;
-    f32x4 w1[4][K::K1S4], w2[4][4], w3[K::M3T][4], b1[4], b2[4];
+    f32x4 w1[4][K::K1S4], w2[4][4], w3[K::M3T][4];
 };
 template <int CP>
 __device__ __forceinline__ void mlp_load_regs(const float* __restrict__ WS, int lane, MlpRegs<CP>& R) {
@@ -707,8 +707,6 @@ __device__ __forceinline__ void mlp_load_regs(const float* __restrict__ WS, int 
         for (int m2 = 0; m2 < 4; ++m2) R.w2[m2][m] = W2V[(m2 * 4 + m) * 64];
 #pragma unroll
         for (int m3 = 0; m3 < K::M3T; ++m3) R.w3[m3][m] = W3V[(m3 * 4 + m) * 64];
-        R.b1[m] = ld4(WS + K::OFF_B1 + 16 * m + 4 * g);
-        R.b2[m] = ld4(WS + K::OFF_B2 + 16 * m + 4 * g);
     }
 }
 // mlp_tile with register-resident operands (same MFMA order per accumulator => bit-identical results).
@@ -718,20 +716,30 @@ __device__ __forceinline__ void mlp_load_regs(const float* __restrict__ WS, int 
 // tile m+1 is issued BEFORE the ReLU group of tile m so that group never waits for the chain it reads.
 // XR must provide 16*M3T channel rows.
 template <int CP, int NT>
-__device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, float* __restrict__ XR, const float* __restrict__ MK,
-                                              int lane_in, int n0, const float (&P)[NT][3 * CP / 4]) {
+__device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, const float* __restrict__ WS, float* __restrict__ XR,
+                                              const float* __restrict__ MK, int lane_in, int n0,
+                                              const float (&P)[NT][3 * CP / 4]) {
     using K = WCfg<CP>;
     int lane_o = lane_in;
     asm volatile("" : "+v"(lane_o));
     const int g = lane_o >> 4, ci = lane_o & 15;
+    // accumulator seeds: eight LDS reads issued together before the MFMA stream (they live only during this phase, so
+    // the perception before it has the registers to pipeline its own reads)
+    f32x4 b1[4], b2[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        b1[m] = ld4(WS + K::OFF_B1 + 16 * m + 4 * g);
+        b2[m] = ld4(WS + K::OFF_B2 + 16 * m + 4 * g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 acc2[4][NT], acc1[NT], acc1n[NT];
 #pragma unroll
     for (int m2 = 0; m2 < 4; ++m2)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc2[m2][n] = Wr.b2[m2];
+        for (int n = 0; n < NT; ++n) acc2[m2][n] = b2[m2];
     auto layer1 = [&](int m, f32x4 (&acc)[NT]) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[n] = Wr.b1[m];
+        for (int n = 0; n < NT; ++n) acc[n] = b1[m];
 #pragma unroll
         for (int s = 0; s < K::K1S; ++s)
 #pragma unroll
