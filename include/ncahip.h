@@ -142,6 +142,19 @@ int ncahip_cond_finalize_f32(const float *x_pend, const uint8_t *pre, float *x_o
                              int B, int C, int H, int W, int alive_ch, float alive_thr,
                              float clamp_lo, float clamp_hi, ncahip_stream_t stream);
 
+/* ---- bf16 state storage, DyNCA ---------------------------------------------------------------
+ * DyNCA.forward / forward_nsteps (dynca.py:117-138, :168-178) with the state stored as bf16 (uint16_t bit patterns);
+ * cond, uniforms and weights stay fp32.  The step computes exactly as the _f32 entry points on the widened state
+ * (exact fp32 MFMA) and rounds x + dx*mask to bf16 (RNE) on store: storage format only, same kernel.               */
+int ncahip_dynca_step_fwd_bf16(const uint16_t *x_in, uint16_t *x_out, const float *cond, const float *u,
+                               const float *w1, const float *b1, const float *w2, const float *b2,
+                               int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                               float update_rate, uint64_t seed, uint64_t step, ncahip_stream_t stream);
+int ncahip_dynca_nsteps_fwd_bf16(uint16_t *states, int ring, int T, const float *cond, const float *u,
+                                 const float *w1, const float *b1, const float *w2, const float *b2,
+                                 int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                                 float update_rate, uint64_t seed, uint64_t step0, ncahip_stream_t stream);
+
 /* ---- bf16 state storage ---------------------------------------------------------------------
  * The same step / finalize / grow loop with the state and the goal encoding stored as bf16 (uint16_t bit patterns,
  * [B,C,H,W] contiguous) and the UpdateNet on bf16 MFMA; weights, biases and explicit uniforms stay fp32.  Rounding

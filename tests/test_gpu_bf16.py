@@ -152,3 +152,54 @@ def test_module_grow_bf16(ops):
     assert float(d.mean()) < 2e-2, float(d.mean())
     with pytest.raises(NotImplementedError):
         m.grow(x, 2, goal)                      # autograd through the bf16 path is not provided
+
+
+# ------------------------------------------------------------------------------------------------ DyNCA, bf16 storage
+@pytest.mark.parametrize("C,fc,cc,pad,shape", [(12, 96, 3, "circular", (2, 24, 32)), (16, 128, 3, "replicate", (1, 16, 48)),
+                                               (12, 96, 0, "reflect", (2, 9, 11)), (16, 128, 2, "constant", (1, 8, 36))])
+def test_dynca_bf16_storage(ops, C, fc, cc, pad, shape):
+    """ncahip_dynca_nsteps_fwd_bf16: exact fp32 step on the widened state, rounded to bf16 on store.  Per step the GPU and
+    the oracle (dynca.py:117-138 restated, then .bfloat16()) can differ by one final-rounding flip."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(C + fc + cc)
+    k1 = 4 * C + cc
+    prm = {"w1.weight": torch.randn(fc, k1, 1, 1, generator=g) * (0.5 / k1 ** 0.5), "w1.bias": torch.randn(fc, generator=g) * 0.1,
+           "w2.weight": torch.randn(C, fc, 1, 1, generator=g) * (0.3 / fc ** 0.5), "w2.bias": torch.randn(C, generator=g) * 0.02}
+    x = bfr(torch.rand(B, C, H, W, generator=g) - 0.5)
+    cond = (torch.rand(B, cc, H, W, generator=g) * 2 - 1) if cc else None
+    T_ = 3
+    us = torch.rand(T_, B, 1, H, W, generator=g)
+    w = ops.DyncaWeights(prm["w1.weight"], prm["w1.bias"], prm["w2.weight"], prm["w2.bias"], x.to(DEV))
+    # teacher-forced single steps
+    cur = x
+    for t in range(T_):
+        ref = bfr(O.dynca_step(cur, cond, us[t], prm, pad, 0.5))
+        got, _ = ops.dynca_nsteps(cur.to(DEV).bfloat16(), 1, None if cond is None else cond.to(DEV), us[t:t + 1].to(DEV), w, pad, 0.5)
+        assert got.dtype == torch.bfloat16
+        gf = got.float().cpu()
+        err = (gf - ref).abs() / ref.abs().clamp_min(1.0)
+        assert float(err.max()) <= 2 * ULP and float((gf != ref).float().mean()) < 0.01
+        cur = ref
+    # free-running T steps in one call, in-kernel Philox == explicit uniforms
+    uu = torch.stack([ops.philox_uniform(B, H, W, seed=3, step=t, device=DEV) for t in range(T_)])
+    a1, _ = ops.dynca_nsteps(x.to(DEV).bfloat16(), T_, None if cond is None else cond.to(DEV), uu, w, pad, 0.5)
+    a2, _ = ops.dynca_nsteps(x.to(DEV).bfloat16(), T_, None if cond is None else cond.to(DEV), None, w, pad, 0.5, seed=3, step0=0)
+    assert torch.equal(a1, a2)
+
+
+def test_dynca_module_bf16(ops):
+    from ncahip.models.dynca import DyNCA
+    torch.manual_seed(0)
+    m = DyNCA(12, 3, fc_dim=96, padding_mode="circular", conditioning="edges", device=torch.device(DEV))
+    m.mask_rng = "philox"
+    x = (torch.rand(2, 12, 32, 32, device=DEV) - 0.5).bfloat16()
+    img = torch.rand(2, 1, 32, 32, device=DEV) * 2 - 1
+    with torch.no_grad():
+        m._mask_step = 0
+        yb, rgb = m.forward_nsteps(x, 4, cond_img=img)
+        m._mask_step = 0
+        yf, _ = m.forward_nsteps(x.float(), 4, cond_img=img)
+    assert yb.dtype == torch.bfloat16 and rgb.shape == (2, 3, 32, 32)
+    assert float((yb.float() - yf).abs().mean()) < 1e-2
+    with pytest.raises(NotImplementedError):
+        m.forward_nsteps(x, 2, cond_img=img)

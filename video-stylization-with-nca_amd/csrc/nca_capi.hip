@@ -246,6 +246,34 @@ int ncahip_cond_grow_fwd_f32(float* states, uint8_t* pre, int ring, int T, float
                                                alive_ch, alive_thr, clamp_lo, clamp_hi, st), "cond_grow finalize");
 }
 
+// ---- bf16 state storage for the DyNCA step (same kernel, exact f32 compute, RNE on store) ----------------------
+int ncahip_dynca_step_fwd_bf16(const uint16_t* x_in, uint16_t* x_out, const float* cond, const float* u, const float* w1,
+                               const float* b1, const float* w2, const float* b2, int B, int C, int H, int W, int fc,
+                               int c_cond, int pad_mode, float update_rate, uint64_t seed, uint64_t step,
+                               ncahip_stream_t stream) {
+    if (int rc = check_dynca(x_in, x_out, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
+    NcaDyncaArgs a{reinterpret_cast<const float*>(x_in), reinterpret_cast<float*>(x_out), cond, u, w1, b1, w2, b2, B, C, H, W,
+                   fc, c_cond, pad_mode, update_rate, seed, step};
+    return hip_result(nca_launch_dynca_step_fwd_bf16(a, (hipStream_t)stream), "dynca_step_fwd_bf16");
+}
+
+int ncahip_dynca_nsteps_fwd_bf16(uint16_t* states, int ring, int T, const float* cond, const float* u, const float* w1,
+                                 const float* b1, const float* w2, const float* b2, int B, int C, int H, int W, int fc,
+                                 int c_cond, int pad_mode, float update_rate, uint64_t seed, uint64_t step0,
+                                 ncahip_stream_t stream) {
+    if (ring < 2 || T < 0) return fail(NCAHIP_EINVAL, "dynca nsteps: ring >= 2 and T >= 0 required");
+    if (int rc = check_dynca(states, states + 1, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
+    const size_t slot = (size_t)B * C * H * W, uslot = (size_t)B * H * W;
+    for (int t = 0; t < T; ++t) {
+        NcaDyncaArgs a{reinterpret_cast<const float*>(states + (size_t)(t % ring) * slot),
+                       reinterpret_cast<float*>(states + (size_t)((t + 1) % ring) * slot), cond,
+                       u ? u + (size_t)t * uslot : nullptr, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode,
+                       update_rate, seed, step0 + (uint64_t)t};
+        if (int rc = hip_result(nca_launch_dynca_step_fwd_bf16(a, (hipStream_t)stream), "dynca_nsteps_fwd_bf16")) return rc;
+    }
+    return 0;
+}
+
 int ncahip_dynca_step_bwd_f32(const float* x_t, const float* cond, const float* u, const float* w1, const float* b1,
                               const float* w2, const float* b2, int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
                               float update_rate, uint64_t seed, uint64_t step, const float* g_next, float* g_x, float* h_out,

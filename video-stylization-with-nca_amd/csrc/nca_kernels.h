@@ -62,6 +62,7 @@ hipError_t nca_launch_reduce_wp(const float* part, float* dst, int B, int C, int
 hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st);
 hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st);
 hipError_t nca_launch_dynca_step_bwd(const NcaDyncaArgs& a, hipStream_t st);
+hipError_t nca_launch_dynca_step_fwd_bf16(const NcaDyncaArgs& a, hipStream_t st);   // x_in / x_out hold bf16
 // wave-private-tile variant (nca_cond_wave.hip); needs W % 4 == 0 and 16-byte aligned x_in / goal
 hipError_t nca_launch_cond_step_fwd_wave(const NcaCondArgs& a, hipStream_t st);
 // producer/consumer wave-specialised variant (nca_cond_pc.hip); same preconditions

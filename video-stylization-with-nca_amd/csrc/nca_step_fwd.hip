@@ -120,6 +120,41 @@ __device__ __forceinline__ void pos_load(const PosT& ps, const float* __restrict
     }
 }
 
+// bf16 storage (ncahip_dynca_*_bf16): the same positions, 2-byte elements.  Raw bits are kept until staging consumes
+// them (converting at load time would wait for the load): v4 holds the 8-byte group of the vector path, v1 the four
+// halfwords of the per-element path.
+typedef unsigned nca_u32x2 __attribute__((ext_vector_type(2)));
+template <int CPH>
+struct RawB16 {
+    nca_u32x2 v4[CPH];
+    unsigned v1[CPH][4];
+};
+template <int CPH, typename PosT>
+__device__ __forceinline__ void pos_load_b16(const PosT& ps, const uint16_t* __restrict__ base, unsigned plane, int ch0, int C,
+                                             RawB16<CPH>& r) {
+    if (ps.vec) {
+#pragma unroll
+        for (int c = 0; c < CPH; ++c) {
+            const unsigned ch = (unsigned)min(ch0 + c, C - 1);
+            r.v4[c] = *reinterpret_cast<const nca_u32x2*>(base + (ch * plane + ps.eo[0]));
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CPH; ++c) {
+            const unsigned ch = (unsigned)min(ch0 + c, C - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r.v1[c][j] = base[ch * plane + ps.eo[j]];
+        }
+    }
+}
+__device__ __forceinline__ float nca_b16_to_f32(unsigned bits16) { return __uint_as_float(bits16 << 16); }
+// round-to-nearest-even f32 -> bf16 (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint16_t nca_f32_to_b16(float v) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    return (uint16_t)(__builtin_bit_cast(unsigned, __builtin_convertvector(f2{v, 0.0f}, b2)) & 0xffffu);
+}
+
 template <typename PosT>
 __device__ __forceinline__ void pos_store(const PosT& ps, float* __restrict__ Zc /* &Z[ch][0][0] */, const float (&v)[4]) {
     float* const d = Zc + ps.r * PosT::RS + ps.q + 3;
@@ -166,8 +201,9 @@ struct DyncaCfg {
 // hidden layer, then dh = (W2^T (G*mask)) * 1[h>0] and dL/dy = W1^T dh on MFMA (accumulator tile == next B
 // operand, as in the forward); writes relu(h), dh and dL/dy[:4C].  The two weight-gradient GEMMs
 // (dW2 = (G*mask) h^T, dW1 = dh y^T, K = all cells) are plain library GEMMs on those buffers.
-template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT, bool VEC, bool BWD = false>
+template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT, bool VEC, bool BWD = false, bool B16 = false>
 __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(const NcaDyncaArgs a) {
+    static_assert(!(BWD && B16), "the bf16-storage step is forward only");
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
     using Pos = TilePos<TH, TW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -224,7 +260,8 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
     for (NcaTileWalk tw = nca_tile_walk(ntiles); tw.t < tw.end; tw.t += tw.stride) {
         const int txi = tw.t % tiles_x, tyi = (tw.t / tiles_x) % tiles_y, b = tw.t / (tiles_x * tiles_y);
         const int ty0 = tyi * TH, tx0 = txi * TW;
-        const float* const xb = a.x_in + (size_t)b * C * plane;
+        const float* const xb = a.x_in + (size_t)b * C * plane;                                    // f32 storage
+        const uint16_t* const xb16 = reinterpret_cast<const uint16_t*>(a.x_in) + (size_t)b * C * plane;   // bf16 storage
 
         // ---- issue every global load of the tile, then retire the previous tile ---------
         // (staging index made opaque per tile: its derived coordinates are recomputed here rather than
@@ -235,7 +272,9 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
         Pos ps;
         ps.template init<VEC>(st, ty0, tx0, H, W, a.pad_mode);
         float xv[K::CPH][4];
-        pos_load<K::CPH>(ps, xb, (unsigned)plane, half * K::CPH, 0, C, xv);
+        RawB16<B16 ? K::CPH : 1> xr;
+        if constexpr (B16) pos_load_b16<K::CPH>(ps, xb16, (unsigned)plane, half * K::CPH, C, xr);
+        else pos_load<K::CPH>(ps, xb, (unsigned)plane, half * K::CPH, 0, C, xv);
         const int cr = st / TW, cq = st % TW, cgy = ty0 + cr, cgx = tx0 + cq;  // this thread's cell
         const bool cin = cgy < H && cgx < W;
         const size_t cell = (size_t)b * plane + (cin ? (size_t)cgy * W + cgx : 0);
@@ -252,6 +291,13 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
             for (int c = 0; c < K::CPH; ++c) {
                 const int ch = half * K::CPH + c;
                 float v[4];
+                if constexpr (B16) {   // widen now (exact): the loads have long landed
+                    const unsigned lo = xr.v4[c][0], hi = xr.v4[c][1];
+                    const float w4[4] = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u),
+                                         __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xv[c][j] = ps.vec ? w4[j] : nca_b16_to_f32(xr.v1[c][j]);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = (ch < C && ps.ev[j]) ? xv[c][j] : 0.0f;
                 pos_store(ps, Z + ch * K::CS, v);
@@ -435,7 +481,9 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                     const int gy = ty0 + r0[n], gx = tx0 + q0[n];
                     if (gy < H && gx < W) {
                         const float mk = MK[r0[n] * TW + q0[n]];
-                        float* const ob = a.x_out + (size_t)b * C * plane + (size_t)gy * W + gx;
+                        const size_t o0 = (size_t)b * C * plane + (size_t)gy * W + gx;
+                        float* const ob = a.x_out + o0;
+                        uint16_t* const ob16 = reinterpret_cast<uint16_t*>(a.x_out) + o0;
     #pragma unroll
                         for (int m2 = 0; m2 < K::M2T; ++m2)
     #pragma unroll
@@ -443,7 +491,9 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                                 const int ch = 16 * m2 + 4 * g + r;
                                 if (ch < C) {
                                     const float xo = Z[ch * K::CS + (r0[n] + 1) * K::RS + q0[n] + 4];
-                                    ob[ch * plane] = xo + acc2[m2][n][r] * mk;
+                                    const float xn = xo + acc2[m2][n][r] * mk;
+                                    if constexpr (B16) ob16[ch * plane] = nca_f32_to_b16(xn);
+                                    else ob[ch * plane] = xn;
                                 }
                             }
                     }
@@ -829,11 +879,11 @@ int grid_for(int ntiles, int wg_per_cu) {
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
-template <int CP, int FC, bool HAS_COND, bool VEC>
+template <int CP, int FC, bool HAS_COND, bool VEC, bool B16 = false>
 hipError_t launch_dynca_v(const NcaDyncaArgs& a, hipStream_t st) {
     constexpr int TH = 8, TW = 32, NT = 4;
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
-    auto kern = dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, VEC>;
+    auto kern = dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, VEC, false, B16>;
     const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
     static thread_local bool attr_done = false;
     if (!attr_done) {
@@ -960,6 +1010,20 @@ hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st) {
     const bool hc = a.c_cond > 0;
     if (a.C <= 12 && a.fc <= 96) return hc ? launch_dynca<12, 96, true>(a, st) : launch_dynca<12, 96, false>(a, st);
     if (a.C <= 16 && a.fc <= 128) return hc ? launch_dynca<16, 128, true>(a, st) : launch_dynca<16, 128, false>(a, st);
+    return hipErrorInvalidValue;
+}
+
+// bf16 state storage: x_in / x_out point at bf16 data (cond, uniforms, weights stay f32); same kernel, exact f32 compute,
+// round-to-nearest-even on store.  The 8-byte vector path needs W % 4 == 0 and 8-byte aligned planes.
+template <int CP, int FC, bool HAS_COND>
+static hipError_t launch_dynca_b16(const NcaDyncaArgs& a, hipStream_t st) {
+    const bool vec = (a.W % 4 == 0) && (((uintptr_t)a.x_in & 7u) == 0) && (((size_t)a.H * a.W) % 4 == 0);
+    return vec ? launch_dynca_v<CP, FC, HAS_COND, true, true>(a, st) : launch_dynca_v<CP, FC, HAS_COND, false, true>(a, st);
+}
+hipError_t nca_launch_dynca_step_fwd_bf16(const NcaDyncaArgs& a, hipStream_t st) {
+    const bool hc = a.c_cond > 0;
+    if (a.C <= 12 && a.fc <= 96) return hc ? launch_dynca_b16<12, 96, true>(a, st) : launch_dynca_b16<12, 96, false>(a, st);
+    if (a.C <= 16 && a.fc <= 128) return hc ? launch_dynca_b16<16, 128, true>(a, st) : launch_dynca_b16<16, 128, false>(a, st);
     return hipErrorInvalidValue;
 }
 

@@ -83,8 +83,12 @@ class _DyncaNSteps(torch.autograd.Function):
 
 
 def dynca_nsteps_autograd(model, x, cond, T, update_rate, want_states=False):
-    x = x.float().contiguous()
+    bf16 = x.dtype == torch.bfloat16      # bf16 pool: bf16-storage entry points, inference only
+    x = x.contiguous() if bf16 else x.float().contiguous()
     params = (model.w1.weight, model.w1.bias, model.w2.weight, model.w2.bias)
+    if bf16 and _needs_grad(x, *params):
+        raise NotImplementedError("ncahip: the bf16-storage DyNCA steps are forward-only; train with float32 states or call "
+                                  "them under torch.no_grad()")
     us = model._draw(x, T)
     cfg = dict(T=T, us=us, pad=model.padding_mode, rate=float(update_rate), seed=model.mask_seed, step0=model._mask_step,
                want_states=want_states)

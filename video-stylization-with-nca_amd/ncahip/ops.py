@@ -25,6 +25,13 @@ def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     return t.contiguous()
 
 
+def _state_dtype(x: torch.Tensor):
+    """The fused steps exist for fp32 and for bf16 state storage (ncahip_*_bf16, see include/ncahip.h)."""
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"ncahip: the NCA state must be float32 or bfloat16, got {x.dtype}")
+    return x.dtype, ("bf16" if x.dtype == torch.bfloat16 else "f32")
+
+
 def _w(t: torch.Tensor, name: str, like: torch.Tensor) -> torch.Tensor:
     """weights: detach, squeeze 1x1 conv dims, move next to the state if needed."""
     t = t.detach()
@@ -105,7 +112,8 @@ def dynca_nsteps(x: torch.Tensor, T: int, cond: Optional[torch.Tensor], us: Opti
                  keep_history: bool = False):
     """T fused steps.  Returns (x_T, states) where states is the [ring,B,C,H,W] buffer (ring=T+1 when
     keep_history, else 2)."""
-    x = _dev(x, "x")
+    dt, sfx = _state_dtype(x)           # bfloat16 state -> bf16-storage entry points (forward only)
+    x = _dev(x, "x", dt)
     B, C, H, W = x.shape
     if T == 0:
         return x.clone(), None
@@ -117,11 +125,11 @@ def dynca_nsteps(x: torch.Tensor, T: int, cond: Optional[torch.Tensor], us: Opti
         assert us.numel() == T * B * H * W
     assert w.c == C and w.k1 == 4 * C + c_cond, (w.c, w.k1, C, c_cond)
     ring = T + 1 if keep_history else 2
-    states = torch.empty(ring, B, C, H, W, device=x.device, dtype=torch.float32)
+    states = torch.empty(ring, B, C, H, W, device=x.device, dtype=dt)
     states[0].copy_(x)
-    check(lib().ncahip_dynca_nsteps_fwd_f32(_p(states), ring, T, _p(cond), _p(us), _p(w.w1), _p(w.b1), _p(w.w2),
-                                            _p(w.b2), B, C, H, W, w.fc, c_cond, PAD_MODES[pad_mode], update_rate,
-                                            seed, step0, _stream()), "dynca_nsteps_fwd")
+    check(getattr(lib(), "ncahip_dynca_nsteps_fwd_" + sfx)(_p(states), ring, T, _p(cond), _p(us), _p(w.w1), _p(w.b1), _p(w.w2),
+                                                           _p(w.b2), B, C, H, W, w.fc, c_cond, PAD_MODES[pad_mode],
+                                                           update_rate, seed, step0, _stream()), "dynca_nsteps_fwd_" + sfx)
     return states[T % ring], states
 
 
@@ -137,13 +145,6 @@ class CondWeights:
         self.hidden = self.w1.shape[0]
         self.c = self.w3.shape[0]
         assert self.wp.numel() == 27 * self.c and self.w1.numel() == self.hidden * 3 * self.c
-
-
-def _state_dtype(x: torch.Tensor):
-    """The ConditionedNCA step exists for fp32 and for bf16 state storage (ncahip_cond_*_bf16, see include/ncahip.h)."""
-    if x.dtype not in (torch.float32, torch.bfloat16):
-        raise TypeError(f"ncahip: ConditionedNCA state must be float32 or bfloat16, got {x.dtype}")
-    return x.dtype, ("bf16" if x.dtype == torch.bfloat16 else "f32")
 
 
 def _goal_args(goal, B, C, H, W, dtype=torch.float32):
