@@ -42,7 +42,8 @@ typedef void *ncahip_stream_t;   /* hipStream_t */
 int ncahip_version(void);
 const char *ncahip_last_error(void);
 
-/* Largest shapes the fused step kernels accept (C <= max_c, fc <= max_fc, hidden <= 64). */
+/* Largest shapes the fused step kernels accept (C <= max_c, fc <= max_fc, hidden <= 64).  The DyNCA *forward* entry
+ * points additionally take 16 < C <= 32 (BASELINE configs[4]); the backward kernels cover C <= max_c.                */
 int ncahip_limits(int *max_c, int *max_fc, int *max_hidden);
 
 /* Test hook (process-wide) selecting which kernel family serves the fused steps, so every variant can be checked

@@ -436,3 +436,25 @@ def test_dynca_backward_vs_oracle_autograd(ops, C, fc, cc, shape, pad):
     assert _grad_close(gr["x0"], dx0)
     assert _grad_close(gr["w1"], grads["w1.weight"][:, :, 0, 0]) and _grad_close(gr["b1"], grads["w1.bias"])
     assert _grad_close(gr["w2"], grads["w2.weight"][:, :, 0, 0]) and _grad_close(gr["b2"], grads["w2.bias"])
+
+
+def test_dynca_c32_forward(ops):
+    """BASELINE configs[4] channel count: C = 32 state channels (+3 conditioning) on the forward kernels, fp32 and bf16 storage."""
+    from oracle import nca_oracle as O
+    C, fc, cc, B, H, W = 32, 128, 3, 1, 24, 40
+    g = torch.Generator().manual_seed(32)
+    k1 = 4 * C + cc
+    prm = {"w1.weight": torch.randn(fc, k1, 1, 1, generator=g) * (0.5 / k1 ** 0.5), "w1.bias": torch.randn(fc, generator=g) * 0.1,
+           "w2.weight": torch.randn(C, fc, 1, 1, generator=g) * (0.3 / fc ** 0.5), "w2.bias": torch.randn(C, generator=g) * 0.02}
+    x = torch.rand(B, C, H, W, generator=g) - 0.5
+    cond = torch.rand(B, cc, H, W, generator=g) * 2 - 1
+    us = [torch.rand(B, 1, H, W, generator=g) for _ in range(3)]
+    w = ops.DyncaWeights(prm["w1.weight"], prm["w1.bias"], prm["w2.weight"], prm["w2.bias"], x.to(DEV))
+    for pad in ("circular", "replicate"):
+        ref = O.dynca_nsteps(x, cond, us, prm, pad, 0.5)
+        got, _ = ops.dynca_nsteps(x.to(DEV), 3, cond.to(DEV), torch.stack(us).to(DEV), w, pad, 0.5)
+        assert rel_err(got.cpu(), ref) < REL_TOL
+    xb = x.bfloat16()
+    gotb, _ = ops.dynca_nsteps(xb.to(DEV), 1, cond.to(DEV), us[0][None].to(DEV), w, "circular", 0.5)
+    refb = O.dynca_step(xb.float(), cond, us[0], prm, "circular", 0.5).bfloat16().float()
+    assert float(((gotb.float().cpu() - refb).abs() / refb.abs().clamp_min(1.0)).max()) <= 2.0 ** -7

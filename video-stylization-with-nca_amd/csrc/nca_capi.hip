@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int kMaxC = 16, kMaxFc = 128, kMaxHidden = 64, kMaxCond = 4;
+constexpr int kMaxC = 16, kMaxCDynca = 32, kMaxFc = 128, kMaxHidden = 64, kMaxCond = 4;   // DyNCA forward: C <= 32 (configs[4])
 
 thread_local char g_err[512] = "";
 
@@ -38,8 +38,8 @@ int check_dynca(const void* x_in, const void* x_out, const void* cond, const voi
     if ((c_cond > 0) != (cond != nullptr)) return fail(NCAHIP_EINVAL, "dynca step: cond pointer / c_cond mismatch");
     if (pad_mode < 0 || pad_mode > 3) return fail(NCAHIP_EINVAL, "dynca step: bad pad_mode %d", pad_mode);
     if (pad_mode == NCAHIP_PAD_REFLECT && (H < 2 || W < 2)) return fail(NCAHIP_EINVAL, "reflect pad needs H,W >= 2");
-    if (C > kMaxC || fc > kMaxFc || c_cond > kMaxCond)
-        return fail(NCAHIP_ERANGE, "dynca step: C=%d fc=%d c_cond=%d exceeds (%d,%d,%d)", C, fc, c_cond, kMaxC, kMaxFc,
+    if (C > kMaxCDynca || fc > kMaxFc || c_cond > kMaxCond)
+        return fail(NCAHIP_ERANGE, "dynca step: C=%d fc=%d c_cond=%d exceeds (%d,%d,%d)", C, fc, c_cond, kMaxCDynca, kMaxFc,
                     kMaxCond);
     if (x_in == x_out) return fail(NCAHIP_EINVAL, "dynca step: x_in and x_out must not alias (halo reads)");
     return 0;
@@ -281,6 +281,7 @@ int ncahip_dynca_step_bwd_f32(const float* x_t, const float* cond, const float* 
     if (!g_next || !g_x || !h_out || !dh_out || !dy_scratch) return fail(NCAHIP_EINVAL, "dynca step bwd: null pointer");
     if (int rc = check_dynca(x_t, g_x, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
     if (g_next == g_x) return fail(NCAHIP_EINVAL, "dynca step bwd: g_next and g_x must not alias");
+    if (C > kMaxC) return fail(NCAHIP_ERANGE, "dynca step bwd: C=%d exceeds %d (the backward kernels cover C <= 16)", C, kMaxC);
     NcaDyncaArgs a{x_t, nullptr, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step,
                    g_next, h_out, dh_out, dy_scratch, g_x};
     return hip_result(nca_launch_dynca_step_bwd(a, (hipStream_t)stream), "dynca_step_bwd");

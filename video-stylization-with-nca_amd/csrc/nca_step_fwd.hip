@@ -126,8 +126,7 @@ __device__ __forceinline__ void pos_load(const PosT& ps, const float* __restrict
 typedef unsigned nca_u32x2 __attribute__((ext_vector_type(2)));
 template <int CPH>
 struct RawB16 {
-    nca_u32x2 v4[CPH];
-    unsigned v1[CPH][4];
+    unsigned v1[CPH][4];   // vector path: [0..1] = the 8-byte group; per-element path: one halfword each
 };
 template <int CPH, typename PosT>
 __device__ __forceinline__ void pos_load_b16(const PosT& ps, const uint16_t* __restrict__ base, unsigned plane, int ch0, int C,
@@ -136,7 +135,9 @@ __device__ __forceinline__ void pos_load_b16(const PosT& ps, const uint16_t* __r
 #pragma unroll
         for (int c = 0; c < CPH; ++c) {
             const unsigned ch = (unsigned)min(ch0 + c, C - 1);
-            r.v4[c] = *reinterpret_cast<const nca_u32x2*>(base + (ch * plane + ps.eo[0]));
+            const nca_u32x2 t = *reinterpret_cast<const nca_u32x2*>(base + (ch * plane + ps.eo[0]));
+            r.v1[c][0] = t[0];
+            r.v1[c][1] = t[1];
         }
     } else {
 #pragma unroll
@@ -194,7 +195,8 @@ struct DyncaCfg {
     static_assert(FC % 16 == 0 && CP % 4 == 0 && TW % 16 == 0, "shape");
     static_assert(NTILES16 % (4 * NT) == 0, "tile must split evenly over 4 waves x NT");
     static_assert(OFF_Z % 4 == 0 && CS % 4 == 0 && TH * TW == kThreads, "16-byte carve; one cell per thread");
-    static_assert(LDS_FLOATS_BWD * 4 <= 160 * 1024, "LDS budget (backward)");
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+    static constexpr bool kBwdFits = LDS_FLOATS_BWD * 4 <= 160 * 1024;   // checked where the backward variant is launched
 };
 
 // BWD = true: the backward data path of the same step (autograd through dynca.py:117-138).  Recomputes the
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                 const int ch = half * K::CPH + c;
                 float v[4];
                 if constexpr (B16) {   // widen now (exact): the loads have long landed
-                    const unsigned lo = xr.v4[c][0], hi = xr.v4[c][1];
+                    const unsigned lo = xr.v1[c][0], hi = xr.v1[c][1];
                     const float w4[4] = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u),
                                          __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
 #pragma unroll
@@ -881,7 +883,7 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 template <int CP, int FC, bool HAS_COND, bool VEC, bool B16 = false>
 hipError_t launch_dynca_v(const NcaDyncaArgs& a, hipStream_t st) {
-    constexpr int TH = 8, TW = 32, NT = 4;
+    constexpr int TH = 8, TW = 32, NT = CP > 16 ? 2 : 4;   // C = 32: 33 perception values per cell row -> two rows per pass
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
     auto kern = dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, VEC, false, B16>;
     const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
@@ -907,6 +909,7 @@ template <int CP, int FC, bool HAS_COND>
 hipError_t launch_dynca_bwd(const NcaDyncaArgs& a, hipStream_t st) {
     constexpr int TH = 8, TW = 32, NT = 4;
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
+    static_assert(K::kBwdFits, "LDS budget (backward)");
     const bool vec = (a.W % 4 == 0) && aligned16(a.x_in);
     const size_t lds = (size_t)K::LDS_FLOATS_BWD * sizeof(float);
     const int ntiles = a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
@@ -1010,6 +1013,7 @@ hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st) {
     const bool hc = a.c_cond > 0;
     if (a.C <= 12 && a.fc <= 96) return hc ? launch_dynca<12, 96, true>(a, st) : launch_dynca<12, 96, false>(a, st);
     if (a.C <= 16 && a.fc <= 128) return hc ? launch_dynca<16, 128, true>(a, st) : launch_dynca<16, 128, false>(a, st);
+    if (a.C <= 32 && a.fc <= 128) return hc ? launch_dynca<32, 128, true>(a, st) : launch_dynca<32, 128, false>(a, st);   // configs[4]
     return hipErrorInvalidValue;
 }
 
@@ -1024,6 +1028,7 @@ hipError_t nca_launch_dynca_step_fwd_bf16(const NcaDyncaArgs& a, hipStream_t st)
     const bool hc = a.c_cond > 0;
     if (a.C <= 12 && a.fc <= 96) return hc ? launch_dynca_b16<12, 96, true>(a, st) : launch_dynca_b16<12, 96, false>(a, st);
     if (a.C <= 16 && a.fc <= 128) return hc ? launch_dynca_b16<16, 128, true>(a, st) : launch_dynca_b16<16, 128, false>(a, st);
+    if (a.C <= 32 && a.fc <= 128) return hc ? launch_dynca_b16<32, 128, true>(a, st) : launch_dynca_b16<32, 128, false>(a, st);
     return hipErrorInvalidValue;
 }
 
