@@ -230,6 +230,13 @@ def main():
                                   "algorithmic_bytes_per_cell": bpc, "hbm_GBs": cells * bpc / (ms_b * 1e-3) / 1e9,
                                   "hbm_frac": cells * bpc / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                   "bound": "vector ALU / LDS issue (staging + perception), see DESIGN.md"}
+        # ---- the same loop started from ConditionedNCA.generate_seed (nca.py:130-150: one live centre cell, most of the grid
+        # dead): the kernels have no data-dependent early-out, so this must match `value` (SURVEY.md 8d asks for both)
+        xs = torch.zeros_like(xd)
+        xs[:, ALIVE_CH:, H // 2, W // 2] = 1.0
+        ms_s = event_ms(lambda: ops.cond_grow(xs, T, gd, None, w, ALIVE_CH, seed=42), 3) / T
+        result["from_seed"] = {"value": cells / (ms_s * 1e-3), "unit": "cell-updates/s", "launch_ms": ms_s,
+                               "alive_fraction_at_end": float(ops.cond_alive(ops.cond_grow(xs, T, gd, None, w, ALIVE_CH, seed=42)[0], ALIVE_CH).float().mean())}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(prm, x0, goal)
             result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
