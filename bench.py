@@ -17,6 +17,7 @@ Extra objects on the JSON line:
                     the HIP-event launch time (events on the launch stream).
   roofline_stencil  standalone DyNCA perception stencil: HBM bound, 20*C bytes/cell.
   bf16_storage      the same grow loop on the bf16-storage kernels (informational; `value` stays the fp32 path).
+  f32_bf16x3        the same loop with ncahip_cond_precision(1) (opt-in bf16-pair emulation of the fp32 products).
   cpu_baseline      the CPU oracle (pure-PyTorch restatement == the reference's CPU path, bit-identical)
                     timed on this box's host cores on a bounded sample (rank 0, N=1 only).
 """
@@ -230,6 +231,18 @@ def main():
                                   "algorithmic_bytes_per_cell": bpc, "hbm_GBs": cells * bpc / (ms_b * 1e-3) / 1e9,
                                   "hbm_frac": cells * bpc / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                   "bound": "vector ALU / LDS issue (staging + perception), see DESIGN.md"}
+        # ---- opt-in bf16x3 emulation of the fp32 products (ncahip_cond_precision(1)): fp32 storage, ~1e-5 relative error
+        # per step -- informational, never `value`
+        ops.set_cond_precision("bf16x3")
+        try:
+            ms_x = event_ms(lambda: ops.cond_grow(xd, T, gd, None, w, ALIVE_CH, seed=42), 5) / T
+            x3, _ = ops.cond_step(xd, None, gd, None, w, ALIVE_CH, seed=7)
+        finally:
+            ops.set_cond_precision("exact")
+        xe, _ = ops.cond_step(xd, None, gd, None, w, ALIVE_CH, seed=7)
+        result["f32_bf16x3"] = {"value": cells / (ms_x * 1e-3), "unit": "cell-updates/s", "launch_ms": ms_x,
+                                "max_rel_err_vs_exact_step": float(((x3 - xe).abs() / xe.abs().clamp_min(1.0)).max()),
+                                "dtype": "f32 storage; products as 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi), f32 accumulate"}
         # ---- the same loop started from ConditionedNCA.generate_seed (nca.py:130-150: one live centre cell, most of the grid
         # dead): the kernels have no data-dependent early-out, so this must match `value` (SURVEY.md 8d asks for both)
         xs = torch.zeros_like(xd)

@@ -46,6 +46,13 @@ const char *ncahip_last_error(void);
  * points additionally take 16 < C <= 32 (BASELINE configs[4]); the backward kernels cover C <= max_c.                */
 int ncahip_limits(int *max_c, int *max_fc, int *max_hidden);
 
+/* Arithmetic of the UpdateNet products in ncahip_cond_step_fwd_f32 / ncahip_cond_grow_fwd_f32 (process-wide; C in {12,16},
+ * hidden = 64, aligned shapes -- other shapes always compute exactly):
+ *   0  exact fp32 MFMA (default; bit-compatible with an fmaf chain -- what every parity claim and bench.py's `value` use)
+ *   1  "bf16x3": each fp32 operand as a bf16 pair, three bf16 MFMAs per product block, f32 accumulation; relative error
+ *      ~1e-5 per step (inside the 1e-4 bar, not exact), about twice the throughput.  The backward always recomputes exactly. */
+int ncahip_cond_precision(int mode);
+
 /* Test hook (process-wide) selecting which kernel family serves the fused steps, so every variant can be checked
  * against the oracle on the same inputs: bit 0 = generic any-shape kernels instead of the aligned fast paths;
  * bit 1 = symmetric wave-private ConditionedNCA kernel instead of the default producer/consumer one. */

@@ -203,3 +203,35 @@ def test_dynca_module_bf16(ops):
     assert float((yb.float() - yf).abs().mean()) < 1e-2
     with pytest.raises(NotImplementedError):
         m.forward_nsteps(x, 2, cond_img=img)
+
+
+# ------------------------------------------------------------------------------------------------ opt-in bf16x3 products
+@pytest.mark.parametrize("C,shape,gch", [(16, (2, 32, 48), 12), (12, (2, 24, 32), 8)])
+def test_bf16x3_precision_mode(ops, C, shape, gch):
+    """ncahip_cond_precision(1): fp32 storage, every UpdateNet product from three bf16 MFMAs.  Must stay inside the 1e-4
+    parity bar against the fp32 oracle (nca.py:181-195) on a teacher-forced step, and well above the exact mode's error."""
+    from util import REL_TOL
+    B, H, W = shape
+    g = torch.Generator().manual_seed(1)
+    prm, x, goal, u = make_case(C, B, H, W, gch, seed=2)
+    x = torch.rand(B, C, H, W, generator=g) * 1.2 - 0.2          # full fp32 values
+    x[:, 3] = torch.rand(B, H, W, generator=g) * 0.5
+    goal = torch.randn(B, gch, H, W, generator=g) * 0.5
+    gpad = O.cond_pad_goal(goal, C)
+    d = O.cond_step(x, gpad, u, prm, 3, return_all=True)
+    xd = x.to(DEV)
+    w = weights(ops, prm, xd)
+    try:
+        ops.set_cond_precision("bf16x3")
+        xs, pre_s = ops.cond_step(xd, None, goal.to(DEV), u.to(DEV), w, 3)
+    finally:
+        ops.set_cond_precision("exact")
+    xe, pre_e = ops.cond_step(xd, None, goal.to(DEV), u.to(DEV), w, 3)
+    assert torch.equal(pre_s, pre_e)
+    ref = d["x1"]
+    es = float(((xs.cpu() - ref).abs() / ref.abs().clamp_min(1.0)).max())
+    ee = float(((xe.cpu() - ref).abs() / ref.abs().clamp_min(1.0)).max())
+    assert es < REL_TOL, es                      # the parity bar
+    assert ee < 5e-6 and es > ee                 # and it is NOT the exact path
+    with pytest.raises(Exception):
+        ops.set_cond_precision(7)

@@ -28,3 +28,16 @@ for name, xx, gg in (("f32", x, goal), ("bf16", x.bfloat16(), goal.bfloat16())):
     alive = float(ops.cond_alive(out.float(), 3).float().mean())
     res[name] = {"ms_per_grow": ms, "us_per_step": ms * 1e3 / T, "Gcells_s": B * H * W * T / ms / 1e6, "alive": alive}
 print(json.dumps(res))
+ops.set_cond_precision("bf16x3")
+ops.cond_grow(x, T, goal, None, w, 3, seed=1); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for i in range(5):
+    outs, _, _ = ops.cond_grow(x, T, goal, None, w, 3, seed=1, step0=64 * i)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 5
+xs, _ = ops.cond_step(x, None, goal, None, w, 3, seed=5)
+ops.set_cond_precision("exact")
+xe, _ = ops.cond_step(x, None, goal, None, w, 3, seed=5)
+err = float(((xs - xe).abs() / xe.abs().clamp_min(1.0)).max())
+print(json.dumps({"f32_bf16x3": {"us_per_step": ms * 1e3 / T, "Gcells_s": B * H * W * T / ms / 1e6, "max_rel_err_vs_exact_one_step": err}}))

@@ -61,3 +61,17 @@ run("bf16 consumer alone, no MLP", 0xD1AB, True)
 run("bf16 consumer alone, no store", 0xD1AC, True)
 run("bf16 consumer alone, nothing", 0xD1AD, True)
 run("f32 consumer alone, nothing", 0xD1AD, False)
+print("---- per-workgroup spread of (entry -> loop end), fp32 normal run")
+x, goal = x0, goal0
+buf.zero_()
+xp, pre = ops.cond_step(x, None, goal, None, w, 3)
+for _ in range(3):
+    xp2, pre2 = ops.cond_step(xp, pre, goal, None, w, 3, step=1)
+torch.cuda.synchronize()
+L.nca_debug_set_stamp_buffer_pc(buf.data_ptr())
+xp2, pre2 = ops.cond_step(xp, pre, goal, None, w, 3, step=2)
+torch.cuda.synchronize()
+L.nca_debug_set_stamp_buffer_pc(None)
+k = buf[NWG * 8 * 8 * 16:].cpu().numpy().reshape(NWG, 8, 8).astype(np.float64)
+wl = (k[:, 0, 3] - k[:, 0, 0])
+print("   whole: min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f   (max/median %.3f)" % (wl.min(), np.percentile(wl, 10), np.median(wl), np.percentile(wl, 90), wl.max(), wl.max() / np.median(wl)))

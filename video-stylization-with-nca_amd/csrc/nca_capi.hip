@@ -66,6 +66,12 @@ extern "C" {
 int ncahip_version(void) { return NCAHIP_VERSION; }
 const char* ncahip_last_error(void) { return g_err; }
 
+int ncahip_cond_precision(int mode) {
+    if (mode != 0 && mode != 1) return fail(NCAHIP_EINVAL, "cond precision: 0 (exact fp32) or 1 (bf16x3)");
+    nca_set_cond_precision(mode);
+    return 0;
+}
+
 int ncahip_debug_force_generic(int on) {
     nca_set_force_generic((on & 1) != 0);    // bit 0: generic any-shape kernels
     nca_set_cond_variant((on >> 1) & 1);     // bit 1: symmetric wave-private ConditionedNCA kernel instead of producer/consumer

@@ -33,8 +33,9 @@ struct PCfg {
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 
-template <int CP, bool EXACT, typename ST>
+template <int CP, bool EXACT, typename ST, bool SPLIT = false>
 __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const NcaCondArgs a) {
+    static_assert(!SPLIT || ST::BYTES == 4, "bf16x3 emulation is an option of the fp32-storage kernel");
     constexpr bool BF = ST::BYTES == 2;   // bf16 storage: UpdateNet on bf16 MFMA (operands rounded from the same LDS image)
     using K = WCfg<CP>;
     using PK = PCfg<CP>;
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
     };
     MlpRegs<CP> Wr;        // exact-f32 operands (f32 storage)
     MlpRegsBf<CP> Wb;      // bf16 operands (bf16 storage)
+    MlpRegsSplit<CP> Ws;   // bf16 hi/lo operand pairs (fp32 storage, ncahip_cond_precision(1))
     auto consume = [&](const WTile& t, int which) {
         if (!t.valid) return;
         const TileLds L = lds_of(which);
@@ -181,7 +183,8 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
                 L.XR[lane] = acc_;
             } else
 #endif
-            if constexpr (BF) mlp_tile_bf16<CP, NT>(Wb, smem + K::OFF_B1, smem + K::OFF_B2, L.XR, L.MK, lane, pass * NT, P);
+            if constexpr (SPLIT) mlp_tile_split<CP, NT>(Ws, smem + K::OFF_B1, smem + K::OFF_B2, L.XR, L.MK, lane, pass * NT, P);
+            else if constexpr (BF) mlp_tile_bf16<CP, NT>(Wb, smem + K::OFF_B1, smem + K::OFF_B2, L.XR, L.MK, lane, pass * NT, P);
             else mlp_tile_regs<CP, NT>(Wr, smem, L.XR, L.MK, lane, pass * NT, P);
             if (pass == 0) NCA_STAMP(6);
         }
@@ -225,7 +228,8 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
         NCA_KSTAMP(1);
         __syncthreads();
         NCA_KSTAMP(2);
-        if constexpr (BF) load_weights_bf16_lds<CP>(smem, lane, Wb);   // same image, rounded to bf16 operand pairs
+        if constexpr (SPLIT) load_weights_split_lds<CP>(smem, lane, Ws);
+        else if constexpr (BF) load_weights_bf16_lds<CP>(smem, lane, Wb);   // same image, rounded to bf16 operand pairs
         else mlp_load_regs<CP>(smem, lane, Wr);
         while (pos.k < n_rounds) {
             const Pos pn = advance(pos);
@@ -248,10 +252,10 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
     }
 }
 
-template <int CP, bool EXACT, typename ST = StF32>
+template <int CP, bool EXACT, typename ST = StF32, bool SPLIT = false>
 hipError_t launch_cond_pc(const NcaCondArgs& a, hipStream_t st) {
     using PK = PCfg<CP>;
-    auto kern = cond_step_fwd_pc_kernel<CP, EXACT, ST>;
+    auto kern = cond_step_fwd_pc_kernel<CP, EXACT, ST, SPLIT>;
     const size_t lds = (size_t)PK::LDS_FLOATS * sizeof(float);
     static thread_local bool attr_done = false;
     if (!attr_done) {
@@ -279,10 +283,16 @@ hipError_t launch_cond_pc(const NcaCondArgs& a, hipStream_t st) {
 extern "C" void nca_debug_set_stamp_buffer_pc(void* p);
 static unsigned long long* g_stamp_pc = nullptr;
 extern "C" void nca_debug_set_stamp_buffer_pc(void* p) { g_stamp_pc = (unsigned long long*)p; }
+static int g_cond_precision = 0;
+void nca_set_cond_precision(int mode) { g_cond_precision = mode; }
 hipError_t nca_launch_cond_step_fwd_pc(const NcaCondArgs& a_in, hipStream_t st) {
     NcaCondArgs a = a_in;
     a.dbg = g_stamp_pc;
     const bool h64 = a.hidden == 64;
+    if (g_cond_precision == 1 && h64) {   // opt-in bf16x3 emulation of the fp32 products (exact shapes only)
+        if (a.C == 12) return launch_cond_pc<12, true, StF32, true>(a, st);
+        if (a.C == 16) return launch_cond_pc<16, true, StF32, true>(a, st);
+    }
     if (a.C == 12 && h64) return launch_cond_pc<12, true>(a, st);
     if (a.C == 16 && h64) return launch_cond_pc<16, true>(a, st);
     if (a.C <= 12) return launch_cond_pc<12, false>(a, st);

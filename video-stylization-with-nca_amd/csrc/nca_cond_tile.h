@@ -924,6 +924,116 @@ __device__ __forceinline__ void mlp_tile_bf16(const MlpRegsBf<CP>& Wr, const flo
 }
 
 
+// ---- UpdateNet with fp32 operands emulated by bf16 pairs ("bf16x3") --------------------------------------------------
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi) keeps 16 significand bits; W likewise.  W*x ~ Whi*xhi + Whi*xlo +
+// Wlo*xhi on v_mfma_f32_16x16x16_bf16 (products exact, f32 accumulation): relative error per product ~2^-17 (the dropped
+// Wlo*xlo term and the two truncations), i.e. ~1e-5 -- inside the 1e-4 parity bar but NOT the exact-f32 step; opt-in
+// (ncahip_cond_precision).  Three bf16 MFMAs cost 24-48 cycles against 128 for the four exact-f32 ones they replace, and
+// they co-execute with the vector ALU.
+template <int CP>
+struct MlpRegsSplit {
+    MlpRegsBf<CP> hi, lo;
+};
+__device__ __forceinline__ f32x4 widen4(s16x4 b) {
+    const u32x2 v = __builtin_bit_cast(u32x2, b);
+    return f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16),
+                 __uint_as_float(v[1] & 0xffff0000u)};
+}
+__device__ __forceinline__ void split4(f32x4 v, s16x4& hi, s16x4& lo) {
+    hi = pack4(v[0], v[1], v[2], v[3]);
+    const f32x4 d = v - widen4(hi);
+    lo = pack4(d[0], d[1], d[2], d[3]);
+}
+template <int CP>
+__device__ __forceinline__ void load_weights_split_lds(const float* __restrict__ WS, int lane, MlpRegsSplit<CP>& R) {
+    using K = WCfg<CP>;
+    using KB = MlpRegsBf<CP>;
+    const f32x4* const W1V = reinterpret_cast<const f32x4*>(WS + K::OFF_W1) + lane;
+    const f32x4* const W2V = reinterpret_cast<const f32x4*>(WS + K::OFF_W2) + lane;
+    const f32x4* const W3V = reinterpret_cast<const f32x4*>(WS + K::OFF_W3) + lane;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int s = 0; s < KB::KS1; ++s) split4(W1V[(m * K::K1S4 + s) * 64], R.hi.w1[m][s], R.lo.w1[m][s]);
+#pragma unroll
+        for (int m2 = 0; m2 < 4; ++m2) split4(W2V[(m2 * 4 + m) * 64], R.hi.w2[m2][m], R.lo.w2[m2][m]);
+#pragma unroll
+        for (int m3 = 0; m3 < KB::M3T; ++m3) split4(W3V[(m3 * 4 + m) * 64], R.hi.w3[m3][m], R.lo.w3[m3][m]);
+    }
+}
+__device__ __forceinline__ f32x4 mfma_split(s16x4 whi, s16x4 wlo, s16x4 xhi, s16x4 xlo, f32x4 c) {
+    c = mfma_bf16(whi, xlo, c);   // small terms first
+    c = mfma_bf16(wlo, xhi, c);
+    return mfma_bf16(whi, xhi, c);
+}
+template <int CP, int NT>
+__device__ __forceinline__ void mlp_tile_split(const MlpRegsSplit<CP>& Wr, const float* __restrict__ B1L, const float* __restrict__ B2L,
+                                               float* __restrict__ XR, const float* __restrict__ MK, int lane_in, int n0,
+                                               const float (&P)[NT][3 * CP / 4]) {
+    using K = MlpRegsBf<CP>;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4, ci = lane & 15;
+    s16x4 ph[NT][K::KS1], pl[NT][K::KS1];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int s = 0; s < K::KS1; ++s) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = 4 * s + r < K::K1S ? P[n][4 * s + r] : 0.0f;
+            split4(v, ph[n][s], pl[n][s]);
+        }
+    f32x4 acc2[4][NT];
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2) {
+        const f32x4 b = ld4(B2L + 16 * m2 + 4 * g);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc2[m2][n] = b;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const f32x4 b = ld4(B1L + 16 * m + 4 * g);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            f32x4 acc1 = b;
+#pragma unroll
+            for (int s = 0; s < K::KS1; ++s) acc1 = mfma_split(Wr.hi.w1[m][s], Wr.lo.w1[m][s], ph[n][s], pl[n][s], acc1);
+            f32x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = relu(acc1[r]);
+            s16x4 hh, hl;
+            split4(h, hh, hl);
+#pragma unroll
+            for (int m2 = 0; m2 < 4; ++m2) acc2[m2][n] = mfma_split(Wr.hi.w2[m2][m], Wr.lo.w2[m2][m], hh, hl, acc2[m2][n]);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        f32x4 acc3[K::M3T];
+#pragma unroll
+        for (int m3 = 0; m3 < K::M3T; ++m3) acc3[m3] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // out.4 has no bias
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            f32x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = relu(acc2[m][n][r]);
+            s16x4 hh, hl;
+            split4(h, hh, hl);
+#pragma unroll
+            for (int m3 = 0; m3 < K::M3T; ++m3) acc3[m3] = mfma_split(Wr.hi.w3[m3][m], Wr.lo.w3[m3][m], hh, hl, acc3[m3]);
+        }
+        const float mk = MK[(n0 + n) * WTW + ci];
+#pragma unroll
+        for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* const p = XR + (16 * m3 + 4 * g + r) * XRS + (n0 + n) * WTW + ci;
+                *p = fmaf(mk, acc3[m3][r], *p);
+            }
+    }
+}
+
 // Pending state out: 16-byte stores, 4 per lane (item k -> channel 4k+q4, row (lane>>2)&3, group lane&3).
 // WT: write-through at agent scope (sc1) -- the line goes to memory now instead of sitting dirty in the XCD's L2 until
 // the end-of-kernel write-back (measured: -4 us launch cadence; a plain `nt` hint changes nothing).

@@ -30,6 +30,7 @@ SIGNATURES = {
     "ncahip_cond_alive_u8": [_P, _P, _I, _I, _I, _I, _I, _F, _P],
     "ncahip_cond_grow_fwd_f32": [_P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F,
                                  _F, _F, _F, _U64, _U64, _P],
+    "ncahip_cond_precision": [_I],
     "ncahip_dynca_step_fwd_bf16": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P],
     "ncahip_dynca_nsteps_fwd_bf16": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P],
     "ncahip_cond_step_fwd_bf16": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F,

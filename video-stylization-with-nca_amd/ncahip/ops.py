@@ -46,6 +46,11 @@ def force_generic(on) -> None:
     lib().ncahip_debug_force_generic(int(on))
 
 
+def set_cond_precision(mode) -> None:
+    """'exact' / 0 (default) or 'bf16x3' / 1: see ncahip_cond_precision in include/ncahip.h."""
+    check(lib().ncahip_cond_precision({"exact": 0, "bf16x3": 1}.get(mode, mode)), "cond_precision")
+
+
 def selftest(device=None) -> None:
     scratch = torch.zeros(1024, dtype=torch.int32, device=device or "cuda")
     check(lib().ncahip_selftest(scratch.data_ptr(), _stream()), "ncahip_selftest")
