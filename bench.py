@@ -214,7 +214,7 @@ def main():
                        "parallelism": f"pool-shard x{world} (no data-path collective)"},
             "roofline": {"kernel": "cond_step_fwd_pc_kernel<16,*>", "bound": "mfma", "achieved": tflops,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": pmc_traffic("cond_step_fwd_pc_kernel", "StF32"), "launch_ms": ms_launch, "flops_per_cell": FLOPS_PER_CELL,
+                         "traffic": pmc_traffic("cond_step_fwd_pc_kernel", "StF32, false"), "launch_ms": ms_launch, "flops_per_cell": FLOPS_PER_CELL,
                          "algorithmic_bytes_per_cell": BYTES_PER_CELL_STEP, "cells_per_launch": cells},
             "roofline_stencil": {"kernel": "dynca_perceive_kernel<vec4>", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
                                  "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": pmc_traffic("dynca_perceive_kernel"), "launch_ms": ms_st,

@@ -21,6 +21,6 @@ f = glob.glob("$out/${tag}_prof/**/*kernel_stats.csv", recursive=True)
 rows = list(csv.DictReader(open(f[0])))
 with open("$out/${tag}_kernel_stats.txt", "w") as o:
     for r in rows[:14]:
-        line = "%-90s calls %6s avg_ns %12s pct %6s" % (r["Name"][:90], r["Calls"], r["AverageNs"], r["Percentage"])
+        line = "%-120s calls %6s avg_ns %12s pct %6s" % (r["Name"][:120], r["Calls"], r["AverageNs"], r["Percentage"])
         print(line); o.write(line + "\n")
 PY
