@@ -7,7 +7,7 @@ import torch
 import bench
 from ncahip import ops
 
-def run(B, T, H=256, W=256, C=16, iters=3):
+def run(B, T, H=256, W=256, C=16, iters=3, warm=2):
     dev = "cuda"
     gen = torch.Generator().manual_seed(0)
     prm = bench.make_weights(gen)
@@ -18,8 +18,10 @@ def run(B, T, H=256, W=256, C=16, iters=3):
                         prm["update_net.out.2.weight"], prm["update_net.out.2.bias"], prm["update_net.out.4.weight"], x)
     def fwd():
         return ops.cond_grow(x, T, goal, None, w, 3, seed=1, step0=0, keep_history=True)
-    out, states, pre = fwd()
-    g = ops.cond_grow_backward(states, pre, goal, None, w, cot, T, 3, seed=1, step0=0)
+    for _ in range(warm):   # the history ring is GBs: let the caching allocator settle before timing
+        out, states, pre = fwd()
+        g = ops.cond_grow_backward(states, pre, goal, None, w, cot, T, 3, seed=1, step0=0)
+        del out, states, pre, g
     torch.cuda.synchronize()
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     tf = tb = 0.0
@@ -34,6 +36,10 @@ def run(B, T, H=256, W=256, C=16, iters=3):
                       "fwd_Gcells_s": cells / tf / 1e6, "fwd_bwd_Gcells_s": cells / (tf + tb) / 1e6,
                       "bwd_over_fwd": tb / tf}))
 
+import sys
+if len(sys.argv) > 1 and sys.argv[1] == 'cfg3':
+    run(32, 96, iters=2, warm=1)      # BASELINE configs[2] shape: B=32, 96 steps, forward with history + backward
+    sys.exit(0)
 run(8, 16)
 
 
