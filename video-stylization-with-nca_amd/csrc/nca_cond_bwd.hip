@@ -248,8 +248,30 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dO[n][r] = pass ? dOall[NT + n][r] : dOall[n][r];
-            // ---- data path: W3^T, W2^T, W1^T ---------------------------------------------------------------
+            // Backward data path and weight gradients, layer by layer from the output: each layer's weight-gradient product
+            // is issued as soon as its two factors exist, so h2 dies after layer 3, d2 and h1 after layer 2, P and d1 after
+            // layer 1 (all five tiles alive at once through a separate weight-gradient phase cost 36 spilled registers).
+            // Weight gradients go per 16-cell tile through the cell-major buffer TB[cell][row]: lane (g,ci) writes its 4
+            // accumulator rows of a tile with ONE 16-byte store; operand fragments A[i][k=g] = TB[4s+g][rowA+i],
+            // B[k=g][j] = TB[4s+g][rowB+j] are 16 consecutive floats per lane group.
+            float* const tw_ = TB + ci * TBS + 4 * g;            // this lane's cell row, accumulator-row offset
+            const float* const tr_ = TB + g * TBS + ci;           // operand reads: cell 4s+g -> + 4*s*TBS
             f32x4 d2[4][NT], d1[4][NT], dp[K::MJ][NT];
+            // ---- layer 3: dW3 = dO (rows 0..15) x h2 (rows 16..79);  d2 = (W3^T dO) * 1[h2 > 0] ---------------------------
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                wave_sync();  // TB free (gradient tile consumed above / previous products done)
+                st4(tw_, f32x4{dO[n][0], dO[n][1], dO[n][2], dO[n][3]});
+#pragma unroll
+                for (int m = 0; m < 4; ++m) st4(tw_ + 16 + 16 * m, h2[m][n]);
+                wave_sync();
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float av = tr_[4 * s * TBS];
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) aW3[nb] = nca_mfma(av, tr_[4 * s * TBS + 16 + 16 * nb], aW3[nb]);
+                }
+            }
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -264,6 +286,29 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) d2[m][n][r] = h2[m][n][r] > 0.0f ? d2[m][n][r] : 0.0f;
+            }
+            // ---- layer 2: dW2 = d2 (rows 0..63) x h1 (rows 64..127);  d1 = (W2^T d2) * 1[h1 > 0] ---------------------------
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                wave_sync();
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    st4(tw_ + 16 * m, d2[m][n]);
+                    st4(tw_ + 64 + 16 * m, h1[m][n]);
+                }
+                wave_sync();
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    float bv[4];
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) bv[nb] = tr_[4 * s * TBS + 64 + 16 * nb];
+#pragma unroll
+                    for (int ma = 0; ma < 4; ++ma) {
+                        const float av = tr_[4 * s * TBS + 16 * ma];
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) aW2[ma][nb] = nca_mfma(av, bv[nb], aW2[ma][nb]);
+                    }
+                }
             }
             const int w2t_lane = (ci & 3) * 64 + (ci >> 2) * 16 + 4 * g;  // transposed read of the forward W2 image
 #pragma unroll
@@ -284,66 +329,15 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
                     for (int r = 0; r < 4; ++r) d1[m][n][r] = h1[m][n][r] > 0.0f ? d1[m][n][r] : 0.0f;
             }
 #pragma unroll
-            for (int mj = 0; mj < K::MJ; ++mj) {
-#pragma unroll
-                for (int n = 0; n < NT; ++n) dp[mj][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int mp = 0; mp < 4; ++mp)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float wa = W1T[(mj * 16 + 4 * mp + r) * 64 + lane];
-#pragma unroll
-                        for (int n = 0; n < NT; ++n) dp[mj][n] = nca_mfma(wa, d1[mp][n][r], dp[mj][n]);
-                    }
-            }
-#pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) { db1[m][r] += d1[m][n][r]; db2[m][r] += d2[m][n][r]; }
-
-            // ---- weight gradients: per 16-cell tile, through the cell-major buffer TB[cell][row] ---------------------
-            //      lane (g,ci) writes its 4 accumulator rows of a tile with ONE 16-byte store; operand fragments
-            //      A[i][k=g] = TB[4s+g][rowA+i], B[k=g][j] = TB[4s+g][rowB+j] are 16 consecutive floats per lane group.
+            // ---- layer 1: dW1 = d1 (rows 0..63) x P (rows 64.., natural perception index j = 3c+f);  dp = W1^T d1 ---------
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                float* const tw_ = TB + ci * TBS + 4 * g;            // this lane's cell row, accumulator-row offset
-                const float* const tr_ = TB + g * TBS + ci;           // operand reads: cell 4s+g -> + 4*s*TBS
-                wave_sync();  // TB free (gradient tile consumed above / previous products done)
-                // dW3 = dO (rows 0..15) x h2 (rows 16..79)
-                st4(tw_, f32x4{dO[n][0], dO[n][1], dO[n][2], dO[n][3]});
-#pragma unroll
-                for (int m = 0; m < 4; ++m) st4(tw_ + 16 + 16 * m, h2[m][n]);
                 wave_sync();
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float av = tr_[4 * s * TBS];
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) aW3[nb] = nca_mfma(av, tr_[4 * s * TBS + 16 + 16 * nb], aW3[nb]);
-                }
-                wave_sync();
-                // dW2 = d2 (rows 0..63) x h1 (rows 64..127)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    st4(tw_ + 16 * m, d2[m][n]);
-                    st4(tw_ + 64 + 16 * m, h1[m][n]);
-                }
-                wave_sync();
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    float bv[4];
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) bv[nb] = tr_[4 * s * TBS + 64 + 16 * nb];
-#pragma unroll
-                    for (int ma = 0; ma < 4; ++ma) {
-                        const float av = tr_[4 * s * TBS + 16 * ma];
-#pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) aW2[ma][nb] = nca_mfma(av, bv[nb], aW2[ma][nb]);
-                    }
-                }
-                wave_sync();
-                // dW1 = d1 (rows 0..63) x P (rows 64.., natural perception index j = 3c+f)
 #pragma unroll
                 for (int m = 0; m < 4; ++m) st4(tw_ + 16 * m, d1[m][n]);
 #pragma unroll
@@ -363,6 +357,19 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
                         for (int nb = 0; nb < K::MJ; ++nb) aW1[ma][nb] = nca_mfma(av, bv[nb], aW1[ma][nb]);
                     }
                 }
+            }
+#pragma unroll
+            for (int mj = 0; mj < K::MJ; ++mj) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) dp[mj][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mp = 0; mp < 4; ++mp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float wa = W1T[(mj * 16 + 4 * mp + r) * 64 + lane];
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) dp[mj][n] = nca_mfma(wa, d1[mp][n][r], dp[mj][n]);
+                    }
             }
             // ---- dL/dperception out: [j][2 rows][16] via TB, 16-byte stores -----------------------------------
             wave_sync();
