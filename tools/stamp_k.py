@@ -41,8 +41,8 @@ def run(tag, seed=0, bf16=False):
         print("   entry -> first barrier arrival: consumers %.0f   producers %.0f" % (
             np.median(k[:, 0:4, 1] - k[:, 0:4, 0]), np.median(k[:, 4:8, 1] - k[:, 4:8, 0])))
         c = k[:, 0:4]
-        d = [np.median(c[..., 4] - c[..., 2])] + [np.median(c[..., 5 + i] - c[..., 4 + i]) for i in range(3)]
-        print("   consumer: cycles for tile 0 (from the first barrier), 1, 2, 3:", " ".join("%.0f" % v for v in d))
+        print("   consumer, tile 2: consume %.0f   barrier wait %.0f   next tile's top after %.0f cycles" % (
+            np.median(c[..., 5] - c[..., 4]), np.median(c[..., 6] - c[..., 5]), np.median(c[..., 7] - c[..., 6])))
     print(f"{tag:34s} startup {np.median(v[..., 2] - v[..., 0]):7.0f}   loop {np.median(v[..., 3] - v[..., 2]):8.0f} = {np.median(v[..., 3] - v[..., 2]) / 8:7.0f} per tile   whole {np.median(v[..., 3] - v[..., 0]):8.0f} cycles")
 
 run("normal")

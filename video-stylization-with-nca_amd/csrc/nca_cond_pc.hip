@@ -238,10 +238,13 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
 #ifdef NCA_STAMPS
             if (a.seed != 0xD1A7ull)  // diagnostic knob: idle consumers
 #endif
+            if (tile_no == 2) NCA_KSTAMP(4);            // light stamps around one steady-state tile: top / consumed / barrier passed
             consume(cur, which);
-            if (tile_no < 4) NCA_KSTAMP(4 + tile_no);   // light stamps: end of the first four tiles (cold-start profile)
+            if (tile_no == 2) NCA_KSTAMP(5);
             NCA_STAMP(1);
             __syncthreads();   // (workgroup scope: lgkmcnt(0) + s_barrier -- the tile's global stores are not waited for)
+            if (tile_no == 2) NCA_KSTAMP(6);
+            if (tile_no == 3) NCA_KSTAMP(7);
             NCA_STAMP(2);
             cur = nxt;
             pos = pn;

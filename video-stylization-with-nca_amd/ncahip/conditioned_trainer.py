@@ -1,20 +1,25 @@
-"""ConditionedNCATrainer drop-in (reference: EncoderConditioning/conditioned_trainer.py:27-181).
+"""Pool-based training loop of the goal-conditioned NCA on the HIP hot path.
 
-Same constructor and method surface; the inner loop keeps the reference's semantics -- idxs from
-`random.sample`, targets from `np.random.choice`, empty/dead pool slots reseeded, the first two batch
-entries replaced by fresh seeds, TWO train_batch calls per iteration, T ~ random.randint(min,max) NCA steps,
-per-parameter gradient L2 normalisation, Adam + MultiStepLR([5000], 0.3) stepped once per train_batch --
-with the hot path on the HIP kernels and the host synchronisation points removed from it:
-  * the batch is one index_select from the device-resident pool (no Python stack);
-  * dead samples are found with one alive-mask kernel over the batch and replaced by torch.where
-    (the reference syncs once per sample, conditioned_trainer.py:112);
-  * per-parameter grad sums are fetched with one transfer instead of one .item() per parameter (:139-142);
-  * with torch.distributed initialised (ncahip.dist), each rank trains on its own pool shard and the flat
-    gradient bucket is all-reduced once per train_batch, before the normalisation.
+Public surface = the reference's `ConditionedNCATrainer` (EncoderConditioning/conditioned_trainer.py:27-181): constructor
+arguments, `sample_batch / sample_targets / train_batch / update_pool / train / damage / emit_metrics`.  What an iteration
+does is the reference's recipe, stated here once (line numbers are the reference's):
+
+  idxs     = random.sample(range(pool), batch_size)                              (:160)
+  targets  = dataset[np.random.choice(len(dataset), batch_size)]                 (:118-120)
+  batch    = pool[idxs], empty or dead entries <- seed (:104-115), entries 0 and 1 <- fresh seeds (:167)
+  twice:     T = random.randint(min_steps, max_steps); x = nca.grow(x, T, targets); loss; backward;
+             every parameter's gradient /= its own L2 norm + 1e-10; Adam; MultiStepLR([5000], 0.3) step   (:122-151, :169-171)
+  pool[idxs] = x                                                                  (:153-154)
+
+How it is carried out differs: the pool is one device tensor (index_select / index_copy_ instead of a Python list and
+`torch.stack`), dead samples are found by ONE alive-mask launch over the batch instead of a host round trip per sample,
+the per-parameter gradient sums the reference logs are fetched with a single transfer, and with `torch.distributed`
+initialised every rank owns pool_size/world slots and the gradients travel in one flat all-reduce before they are normalised
+(ncahip.dist).  `loss=` accepts any module mapping the reference's loss-input dict to `(loss, summary)`.
 """
 import math
 import random
-from typing import Any, Optional, Tuple  # noqa
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -24,6 +29,8 @@ from .loss import Loss
 from .sample_pool import SamplePool
 from .trainer import NCATrainer
 
+_GRAD_EPS = 1e-10
+
 
 class ConditionedNCATrainer(NCATrainer):
     def __init__(self, nca, target_dataset, target_style_image, nca_steps=[48, 96], lr: float = 2e-3,
@@ -31,101 +38,114 @@ class ConditionedNCATrainer(NCATrainer):
                  appearance_loss_type: str = "OT", appearance_loss_weight: float = 1.0, content_loss_weight: float = 1.0,
                  overflow_loss_weight: float = 1.0, device: Optional[torch.device] = None, visualiser=None, loss=None):
         super().__init__(pool_size, num_damaged, log_base_path, device)
+        self.nca, self.visualiser = nca, visualiser
+        # data
         self.target_dataset = target_dataset
-        self.target_size = self.target_dataset.target_size
-        self.nca = nca
-        self.min_steps, self.max_steps = nca_steps[0], nca_steps[1]
-        self.num_target_channels = self.target_size[0]
-        self.image_size = self.target_size[-1]
-        self.rgb = self.target_size[0] == 3
+        self.target_size = target_dataset.target_size
+        self.num_target_channels, self.image_size = self.target_size[0], self.target_size[-1]
+        self.rgb = self.num_target_channels == 3
+        # schedule
+        self.min_steps, self.max_steps = nca_steps
         self.damage_radius = damage_radius
-        self.optimizer = torch.optim.Adam(self.nca.parameters(), lr=lr)
-        self.lr_sched = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, [5000], gamma=0.3)
-        self.visualiser = visualiser
-        # `loss=` (extension): any module mapping the reference's input dict to (loss, summary)
-        self.loss = loss if loss is not None else Loss(
-            device=self.device, content_loss_weight=content_loss_weight, overflow_loss_weight=overflow_loss_weight,
-            appearance_loss_weight=appearance_loss_weight, appearance_loss_type=appearance_loss_type,
-            target_style_image=target_style_image)
-        self.pool_size = ncadist.shard_size(pool_size)   # this rank's shard of the global pool
-        self.pool = SamplePool(self.pool_size)
         self.log_every = 1
+        self.optimizer = torch.optim.Adam(nca.parameters(), lr=lr)
+        self.lr_sched = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=[5000], gamma=0.3)
+        # objective
+        if loss is None:
+            loss = Loss(device=self.device, target_style_image=target_style_image, appearance_loss_type=appearance_loss_type,
+                        appearance_loss_weight=appearance_loss_weight, content_loss_weight=content_loss_weight,
+                        overflow_loss_weight=overflow_loss_weight)
+        self.loss = loss
+        # this rank's shard of the pool
+        self.pool_size = ncadist.shard_size(pool_size)
+        self.pool = SamplePool(self.pool_size)
 
-    def emit_metrics(self, i: int, batch, outputs, targets, loss, metrics={}):
-        with torch.no_grad():
-            self.train_writer.add_scalar("loss", loss, i)
-            self.train_writer.add_scalar("log10(loss)", math.log10(loss), i)
-            self.train_writer.add_images("batch", self.to_rgb(batch), i, dataformats="NCHW")
-            self.train_writer.add_images("outputs", self.to_rgb(outputs), i, dataformats="NCHW")
-            self.train_writer.add_images("targets", self.to_rgb(targets), i, dataformats="NCHW")
-            for k in metrics:
-                self.train_writer.add_scalar(k, metrics[k], i)
-
-    def damage(self, batch):
-        size = batch.size(0)
-        s = self.image_size
-        yy, xx = np.ogrid[:s, :s]
-        for i in range(self.num_damaged):
-            cy, cx = np.random.randint(0, s, 2)
-            mask = torch.from_numpy((yy - cy) ** 2 + (xx - cx) ** 2 <= self.damage_radius ** 2).to(batch.device)
-            batch[max(size - i - 1, 0)][:, mask] *= 0.0
-        return batch
+    # ------------------------------------------------------------------------------------------------ sampling
+    def sample_targets(self, sampled_indices):
+        picks = np.random.choice(len(self.target_dataset), size=len(sampled_indices), replace=True)
+        return self.target_dataset[picks]
 
     def sample_batch(self, sampled_indices, sample_pool) -> torch.Tensor:
-        seed = self.nca.generate_seed(1)[0].to(self.device)
-        batch = sample_pool.gather(sampled_indices, seed).to(self.device)
-        dead = ~self.nca.alive(batch).flatten(1).any(dim=1)           # one kernel, no per-sample sync
-        return torch.where(dead[:, None, None, None], seed[None], batch)
+        fresh = self.nca.generate_seed(1)[0].to(self.device)
+        states = sample_pool.gather(sampled_indices, fresh).to(self.device)      # never-written slots come back as `fresh`
+        any_alive = self.nca.alive(states).flatten(1).any(dim=1)
+        return torch.where(any_alive.view(-1, 1, 1, 1), states, fresh.unsqueeze(0))
 
-    def sample_targets(self, sampled_indices):
-        random_indices = np.random.choice(len(self.target_dataset), len(sampled_indices), replace=True)
-        return self.target_dataset[random_indices]
-
-    def train_batch(self, batch, targets):
-        num_steps = random.randint(self.min_steps, self.max_steps)
-        batch = self.nca.grow(batch, num_steps=num_steps, goal=targets)
-        loss_input_dict = {"target_images": targets, "nca_state": batch,
-                           "generated_images": batch[:, : self.num_target_channels, :, :]}
-        loss, loss_summary = self.loss(loss_input_dict)
-        self.optimizer.zero_grad()
-        loss.backward()
-        params = [p for p in self.nca.parameters() if p.requires_grad]
-        ncadist.allreduce_mean_grads(params)                         # one flat bucket, before the normalisation
-        for p in params:
-            if p.grad is not None:
-                p.grad /= torch.norm(p.grad) + 1e-10
-        self.optimizer.step()
-        self.lr_sched.step()
-        names = [n for n, W in self.nca.named_parameters() if W.grad is not None]
-        sums = torch.stack([W.grad.sum() for n, W in self.nca.named_parameters() if W.grad is not None] + [loss.detach()])
-        vals = sums.tolist()                                          # the only host sync of the step
-        loss_v = vals[-1]
-        grad_dict = {"{}_grad".format(n): v for n, v in zip(names, vals[:-1])}
-        summary = {k: (float(v) if not isinstance(v, float) else v) for k, v in (loss_summary or {}).items()}
-        return (batch.detach(), loss_v,
-                {"loss": loss_v, **summary, "log10loss": math.log10(loss_v + 1e-5), **grad_dict})
+    def damage(self, batch):
+        n, side = batch.size(0), self.image_size
+        rows, cols = np.ogrid[:side, :side]
+        for k in range(self.num_damaged):
+            cy, cx = np.random.randint(0, side, 2)
+            disc = (rows - cy) ** 2 + (cols - cx) ** 2 <= self.damage_radius ** 2
+            batch[max(n - 1 - k, 0)][:, torch.from_numpy(disc).to(batch.device)] = 0.0
+        return batch
 
     def update_pool(self, idxs, outputs, targets):
         self.pool[idxs] = outputs.detach()
 
+    # ------------------------------------------------------------------------------------------------ one optimiser step
+    def _normalise_and_step(self) -> List[torch.nn.Parameter]:
+        live = [p for p in self.nca.parameters() if p.requires_grad]
+        ncadist.allreduce_mean_grads(live)               # global-batch gradient first, then the per-tensor normalisation
+        for p in live:
+            if p.grad is not None:
+                p.grad.div_(p.grad.norm() + _GRAD_EPS)
+        self.optimizer.step()
+        self.lr_sched.step()
+        return live
+
+    def _report(self, loss: torch.Tensor, parts: Optional[Dict]) -> Dict[str, float]:
+        named = [(n, p.grad) for n, p in self.nca.named_parameters() if p.grad is not None]
+        fetched = torch.stack([g.sum() for _, g in named] + [loss.detach()]).tolist()     # the step's only host sync
+        value = fetched.pop()
+        report = {"loss": value}
+        report.update({k: float(v) for k, v in (parts or {}).items()})
+        report["log10loss"] = math.log10(value + 1e-5)
+        report.update({f"{n}_grad": s for (n, _), s in zip(named, fetched)})
+        return report
+
+    def train_batch(self, batch, targets):
+        steps = random.randint(self.min_steps, self.max_steps)
+        grown = self.nca.grow(batch, num_steps=steps, goal=targets)
+        loss, parts = self.loss({"generated_images": grown[:, :self.num_target_channels], "nca_state": grown,
+                                 "target_images": targets})
+        self.optimizer.zero_grad()
+        loss.backward()
+        self._normalise_and_step()
+        report = self._report(loss, parts)
+        return grown.detach(), report["loss"], report
+
+    # ------------------------------------------------------------------------------------------------ loop
+    def emit_metrics(self, i: int, batch, outputs, targets, loss, metrics={}):
+        w = self.train_writer
+        w.scalars(i, **{"loss": loss, "log10(loss)": math.log10(loss)})
+        for tag, images in (("batch", batch), ("outputs", outputs), ("targets", targets)):
+            w.add_images(tag, self.to_rgb(images), i, dataformats="NCHW")
+        w.scalars(i, **metrics)
+
+    def _iteration(self, i: int, batch_size: int):
+        idxs: Sequence[int] = random.sample(range(len(self.pool)), batch_size)
+        with torch.no_grad():
+            targets = self.sample_targets(idxs).to(self.device)
+            batch = self.sample_batch(idxs, self.pool).to(self.device)
+            batch[:2] = self.nca.generate_seed(2).to(self.device)
+        outputs = batch
+        for _ in range(2):                                # the reference trains twice on every sampled batch
+            outputs, loss, metrics = self.train_batch(outputs, targets)
+        self.update_pool(idxs, outputs, targets)
+        return batch, outputs, targets, loss, metrics
+
     def train(self, batch_size, epochs, *args, **kwargs):
         try:
-            import tqdm
-            bar = tqdm.tqdm(range(epochs))
+            from tqdm import tqdm
+            progress = tqdm(range(epochs))
         except Exception:
-            bar = range(epochs)
+            progress = range(epochs)
         self.pool = SamplePool(self.pool_size)
-        for i in bar:
-            idxs = random.sample(range(len(self.pool)), batch_size)
-            with torch.no_grad():
-                targets = self.sample_targets(idxs).to(self.device)
-                batch = self.sample_batch(idxs, self.pool).to(self.device)
-                batch[:2] = self.nca.generate_seed(2).to(self.device)
-            outputs, loss, metrics = self.train_batch(batch, targets)
-            outputs, loss, metrics = self.train_batch(outputs, targets)  # train more
-            self.update_pool(idxs, outputs, targets)
-            if hasattr(bar, "set_description"):
-                bar.set_description(f"Epoch {i}/{epochs}: loss:{loss:.5f}")
+        for i in progress:
+            batch, outputs, targets, loss, metrics = self._iteration(i, batch_size)
+            if hasattr(progress, "set_description"):
+                progress.set_description(f"iteration {i}/{epochs}  loss {loss:.5f}")
             if i % self.log_every == 0:
                 self.emit_metrics(i, batch, outputs, targets, loss, metrics)
             if self.visualiser is not None:

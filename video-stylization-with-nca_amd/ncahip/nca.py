@@ -43,25 +43,22 @@ class ConditionedNCA(nn.Module):
                  num_hidden_channels=16, use_living_channel: bool = True, living_channel_dim: Optional[int] = None,
                  alpha_living_threshold: float = 0.1, cell_fire_rate: float = 0.5, zero_bias=True):
         super().__init__()
-        self.target_shape = target_shape
-        self.num_target_channels = target_shape[0]
-        self.image_size = target_shape[-1]
-        self.num_hidden_channels = num_hidden_channels
-        self.use_living_channel = use_living_channel
-        self.living_channel_dim = self.num_target_channels if living_channel_dim is None else living_channel_dim
-        self.num_channels = self.num_target_channels + num_hidden_channels + 1
-        self.alpha_living_threshold = alpha_living_threshold
-        self.cell_fire_rate = cell_fire_rate
-        self.zero_bias = zero_bias
-        C = self.num_channels
-        self.perception_net = nn.Conv2d(C, 3 * C, 3, stride=1, padding=1, groups=C, bias=False)
-        self.update_net = UpdateNet(3 * C, C, zero_bias)
-        self.encoder = encoder if encoder is not None else ImageEncoder(num_hidden_channels, self.num_target_channels)
-        # 'torch': draw torch.rand_like(x[:,0:1]) per step on x's device, the reference's own RNG contract
-        # (nca.py:172).  'philox': draw in-kernel (counter-based, keyed (mask_seed, step counter, cell)).
-        self.mask_rng = "torch"
-        self.mask_seed = 0
-        self._mask_step = 0
+        n_target, hidden = target_shape[0], num_hidden_channels
+        # geometry: state = [target channels | alpha | hidden]; the goal encoding rides on the hidden channels
+        self.target_shape, self.image_size = target_shape, target_shape[-1]
+        self.num_target_channels, self.num_hidden_channels = n_target, hidden
+        self.num_channels = n_target + 1 + hidden
+        self.living_channel_dim = n_target if living_channel_dim is None else living_channel_dim
+        self.use_living_channel, self.alpha_living_threshold = use_living_channel, alpha_living_threshold
+        self.cell_fire_rate, self.zero_bias = cell_fire_rate, zero_bias
+        # parameters, under the reference's module names (state_dict compatibility, nca.py:99-110)
+        width = self.num_channels
+        self.perception_net = nn.Conv2d(width, 3 * width, kernel_size=3, padding=1, groups=width, bias=False)
+        self.update_net = UpdateNet(3 * width, width, zero_bias)
+        self.encoder = ImageEncoder(hidden, n_target) if encoder is None else encoder
+        # fire-mask source: 'torch' = one torch.rand_like(x[:, 0:1]) per step on x's device (the reference's RNG contract,
+        # nca.py:172); 'philox' = drawn inside the kernel, keyed by (mask_seed, running step counter, cell)
+        self.mask_rng, self.mask_seed, self._mask_step = "torch", 0, 0
 
     # ------------------------------------------------------------------ helpers
     def _alive_ch(self) -> int:
