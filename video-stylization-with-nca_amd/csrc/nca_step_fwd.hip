@@ -485,6 +485,9 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                         const float mk = MK[r0[n] * TW + q0[n]];
                         const size_t o0 = (size_t)b * C * plane + (size_t)gy * W + gx;
                         float* const ob = a.x_out + o0;
+                        (void)ob;
+                        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.x_out + (size_t)b * C * plane, 0, -1, 0x00020000);
+                        const unsigned ooff = (unsigned)(gy * W + gx) * 4u;
                         uint16_t* const ob16 = reinterpret_cast<uint16_t*>(a.x_out) + o0;
     #pragma unroll
                         for (int m2 = 0; m2 < K::M2T; ++m2)
@@ -495,7 +498,8 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                                     const float xo = Z[ch * K::CS + (r0[n] + 1) * K::RS + q0[n] + 4];
                                     const float xn = xo + acc2[m2][n][r] * mk;
                                     if constexpr (B16) ob16[ch * plane] = nca_f32_to_b16(xn);
-                                    else ob[ch * plane] = xn;
+                                    else   // write-through (sc1): no dirty lines left for the end-of-kernel L2 write-back
+                                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xn), orsrc, (int)((unsigned)ch * (unsigned)plane * 4u + ooff), 0, 16);
                                 }
                             }
                     }
