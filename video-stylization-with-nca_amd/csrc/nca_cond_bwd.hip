@@ -456,17 +456,36 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
 constexpr int SROWS = 8;
 struct Row6 { float v[6]; };   // columns x0-1 .. x0+4
 
-__device__ __forceinline__ Row6 load_row6(const float* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r) {
-    Row6 r;
-    const bool in = y >= 0 && y < H;
-    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* row = plane + (size_t)(in ? y : 0) * W;
-    if (in) c = *reinterpret_cast<const float4*>(row + x0);
-    float l = __shfl_up(c.w, 1), rr = __shfl_down(c.x, 1);
-    if (!has_l) l = (in && x0 > 0) ? row[x0 - 1] : 0.0f;
-    if (!has_r) rr = (in && x0 + 4 < W) ? row[x0 + 4] : 0.0f;
-    r.v[0] = l; r.v[1] = c.x; r.v[2] = c.y; r.v[3] = c.z; r.v[4] = c.w; r.v[5] = rr;
+// Two-stage row fetch: issue (raw 16-byte group + the two edge cells that have no neighbour lane) and finish (shuffle the
+// neighbours' edge values in).  Anything that touches the loaded value belongs to finish -- a shuffle at issue time waits
+// for the load and defeats the prefetch.
+struct RawRow {
+    float4 c;
+    float el, er;
+    bool in;
+};
+__device__ __forceinline__ RawRow issue_row6(const float* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r) {
+    RawRow r;
+    r.in = y >= 0 && y < H;
+    const float* const row = plane + (size_t)(r.in ? y : 0) * W;
+    r.c = *reinterpret_cast<const float4*>(row + x0);
+    r.el = 0.0f;
+    r.er = 0.0f;
+    if (!has_l && x0 > 0) r.el = row[x0 - 1];
+    if (!has_r && x0 + 4 < W) r.er = row[x0 + 4];
     return r;
+}
+__device__ __forceinline__ Row6 finish_row6(const RawRow& q, bool has_l, bool has_r) {
+    Row6 r;
+    const float z = q.in ? 1.0f : 0.0f;   // rows outside the image read row 0 and are zeroed here
+    float l = __shfl_up(q.c.w, 1), rr = __shfl_down(q.c.x, 1);
+    if (!has_l) l = q.el;
+    if (!has_r) rr = q.er;
+    r.v[0] = l * z; r.v[1] = q.c.x * z; r.v[2] = q.c.y * z; r.v[3] = q.c.z * z; r.v[4] = q.c.w * z; r.v[5] = rr * z;
+    return r;
+}
+__device__ __forceinline__ Row6 load_row6(const float* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r) {
+    return finish_row6(issue_row6(plane, H, W, y, x0, has_l, has_r), has_l, has_r);
 }
 
 __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCondBwdArgs ba) {
@@ -491,21 +510,25 @@ __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCon
 #pragma unroll
     for (int i = 0; i < 27; ++i) wsum[i] = 0.f;
     const int gch0 = C - a.goal_ch;
-    // window rows: index 0 = y-1, 1 = y, 2 = y+1
+    // window rows: index 0 = y-1, 1 = y, 2 = y+1; row y+2 (zn / pn) is loaded while row y is computed, so no load
+    // is consumed in the iteration that issues it
     Row6 zw[3], pw[3][3];
+    RawRow zn, pn[3];
     zw[0] = load_row6(zb, H, W, y0 - 1, x0, has_l, has_r);
     zw[1] = load_row6(zb, H, W, y0, x0, has_l, has_r);
+    zw[2] = load_row6(zb, H, W, y0 + 1, x0, has_l, has_r);
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         pw[f][0] = load_row6(p0 + (size_t)f * plane, H, W, y0 - 1, x0, has_l, has_r);
         pw[f][1] = load_row6(p0 + (size_t)f * plane, H, W, y0, x0, has_l, has_r);
+        pw[f][2] = load_row6(p0 + (size_t)f * plane, H, W, y0 + 1, x0, has_l, has_r);
     }
 #pragma unroll 1
     for (int k = 0; k < SROWS; ++k) {
         const int y = y0 + k;
-        zw[2] = load_row6(zb, H, W, y + 1, x0, has_l, has_r);
+        zn = issue_row6(zb, H, W, y + 2, x0, has_l, has_r);
 #pragma unroll
-        for (int f = 0; f < 3; ++f) pw[f][2] = load_row6(p0 + (size_t)f * plane, H, W, y + 1, x0, has_l, has_r);
+        for (int f = 0; f < 3; ++f) pn[f] = issue_row6(p0 + (size_t)f * plane, H, W, y + 2, x0, has_l, has_r);
         if (active && y < H) {
             // dz[x] = sum_f sum_{ty,tx} Wp[f][ty][tx] * dP[f][y-(ty-1)][x-(tx-1)]      (transpose of the zero-padded correlation)
             float dz[4] = {0.f, 0.f, 0.f, 0.f};
@@ -544,9 +567,9 @@ __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCon
                 *dg = o;
             }
         }
-        zw[0] = zw[1]; zw[1] = zw[2];
+        zw[0] = zw[1]; zw[1] = zw[2]; zw[2] = finish_row6(zn, has_l, has_r);
 #pragma unroll
-        for (int f = 0; f < 3; ++f) { pw[f][0] = pw[f][1]; pw[f][1] = pw[f][2]; }
+        for (int f = 0; f < 3; ++f) { pw[f][0] = pw[f][1]; pw[f][1] = pw[f][2]; pw[f][2] = finish_row6(pn[f], has_l, has_r); }
     }
     // block reduction of the 27 partial sums, fixed order (deterministic)
     __shared__ float red[4][27];
