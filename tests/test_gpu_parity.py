@@ -458,3 +458,67 @@ def test_dynca_c32_forward(ops):
     gotb, _ = ops.dynca_nsteps(xb.to(DEV), 1, cond.to(DEV), us[0][None].to(DEV), w, "circular", 0.5)
     refb = O.dynca_step(xb.float(), cond, us[0], prm, "circular", 0.5).bfloat16().float()
     assert float(((gotb.float().cpu() - refb).abs() / refb.abs().clamp_min(1.0)).max()) <= 2.0 ** -7
+
+
+def test_cond_step_shape_fuzz(ops):
+    """Seeded random shapes / channel counts / goal widths / alive settings / fire rates, pending inputs included: one
+    teacher-forced step each against the oracle (nca.py:181-195).  Covers tiles that straddle every image edge and the
+    aligned / unaligned dispatch boundary (W % 4)."""
+    rng = np.random.RandomState(1234)
+    for case in range(24):
+        C = int(rng.choice([5, 8, 12, 13, 16]))
+        B = int(rng.randint(1, 4)); H = int(rng.randint(1, 41)); W = int(rng.randint(1, 53))
+        if rng.rand() < 0.6:
+            W = max(4, (W // 4) * 4)                               # exercise the aligned kernels more often
+        alive = int(rng.choice([-1, 3, min(4, C - 1)]))
+        gch = int(rng.choice([0, 1, max(1, C - 4), C]))
+        rate = float(rng.choice([0.0, 0.5, 1.0]))
+        gen = torch.Generator().manual_seed(1000 + case)
+        prm = rand_cond_prm(C, seed=case, out_scale=2.0)
+        x = torch.rand(B, C, H, W, generator=gen) * 1.4 - 0.2
+        if alive >= 0:
+            x[:, alive] = torch.rand(B, H, W, generator=gen) * 0.4
+        goal = torch.randn(B, gch, H, W, generator=gen) if gch else None
+        u = torch.rand(B, 1, H, W, generator=gen)
+        gpad = O.cond_pad_goal(goal, C) if goal is not None else torch.zeros_like(x)
+        d = O.cond_step(x, gpad, u, prm, max(alive, 0), 0.1, rate, use_living_channel=alive >= 0, return_all=True)
+        w = cond_w(ops, prm, x.to(DEV))
+        xp, pre = ops.cond_step(x.to(DEV), None, None if goal is None else goal.to(DEV), u.to(DEV), w, alive, 0.1, rate)
+        tag = (case, C, B, H, W, alive, gch, rate)
+        assert rel_err(xp.cpu(), d["x1"]) < REL_TOL, tag
+        if alive >= 0:
+            assert torch.equal(pre.cpu().bool(), d["pre"][:, 0]), tag
+        # second step from the pending state == oracle step from the resolved state (pending protocol)
+        u2 = torch.rand(B, 1, H, W, generator=gen)
+        x2ref = d["x2"]
+        ac = max(alive, 0)
+        near = (_near_threshold(torch.nn.functional.max_pool2d(d["x1"][:, ac:ac + 1], 3, 1, 1), 0.1)
+                if alive >= 0 else torch.zeros(B, 1, H, W, dtype=torch.bool))
+        if bool(near.any()):
+            continue                                               # a cell on the life threshold: trajectories may split
+        d2 = O.cond_step(x2ref, gpad, u2, prm, max(alive, 0), 0.1, rate, use_living_channel=alive >= 0, return_all=True)
+        xp2, _ = ops.cond_step(xp, pre, None if goal is None else goal.to(DEV), u2.to(DEV), w, alive, 0.1, rate)
+        assert rel_err(xp2.cpu(), d2["x1"]) < REL_TOL, tag
+
+
+def test_dynca_step_shape_fuzz(ops):
+    """Seeded random shapes / pad modes / conditioning widths for the DyNCA step (dynca.py:117-138)."""
+    rng = np.random.RandomState(4321)
+    pads = ["replicate", "circular", "reflect", "constant"]
+    for case in range(16):
+        C, fc = [(12, 96), (16, 128), (8, 64), (16, 96), (32, 128)][int(rng.randint(0, 5))]
+        cc = int(rng.choice([0, 2, 3]))
+        B = int(rng.randint(1, 3)); H = int(rng.randint(2, 37)); W = int(rng.randint(2, 45))
+        pad = pads[int(rng.randint(0, 4))]
+        gen = torch.Generator().manual_seed(2000 + case)
+        k1 = 4 * C + cc
+        prm = {"w1.weight": torch.randn(fc, k1, 1, 1, generator=gen) * (0.5 / k1 ** 0.5), "w1.bias": torch.randn(fc, generator=gen) * 0.1,
+               "w2.weight": torch.randn(C, fc, 1, 1, generator=gen) * (0.3 / fc ** 0.5), "w2.bias": torch.randn(C, generator=gen) * 0.02}
+        x = torch.rand(B, C, H, W, generator=gen) - 0.5
+        cond = (torch.rand(B, cc, H, W, generator=gen) * 2 - 1) if cc else None
+        u = torch.rand(B, 1, H, W, generator=gen)
+        rate = float(rng.choice([0.25, 0.5, 1.0]))
+        ref = O.dynca_step(x, cond, u, prm, pad, rate)
+        w = ops.DyncaWeights(prm["w1.weight"], prm["w1.bias"], prm["w2.weight"], prm["w2.bias"], x.to(DEV))
+        got, _ = ops.dynca_nsteps(x.to(DEV), 1, None if cond is None else cond.to(DEV), u[None].to(DEV), w, pad, rate)
+        assert rel_err(got.cpu(), ref) < REL_TOL, (case, C, fc, cc, B, H, W, pad, rate)
