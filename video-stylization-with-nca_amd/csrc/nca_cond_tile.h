@@ -731,6 +731,10 @@ __device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, const float
         b1[m] = ld4(WS + K::OFF_B1 + 16 * m + 4 * g);
         b2[m] = ld4(WS + K::OFF_B2 + 16 * m + 4 * g);
     }
+    // LDS offsets of the residual read-modify-write, computed (and pinned) here: left to the compiler their integer
+    // multiplies land inside the MFMA stream next to the reads
+    int xoff = 4 * g * XRS + n0 * WTW + ci, moff = n0 * WTW + ci;
+    asm volatile("" : "+v"(xoff), "+v"(moff));
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc2[4][NT], acc1[NT], acc1n[NT];
 #pragma unroll
@@ -771,13 +775,13 @@ __device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, const float
     float xr[NT][K::M3T][4], mk[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        mk[n] = MK[(n0 + n) * WTW + ci];
+        mk[n] = MK[moff + n * WTW];
 #pragma unroll
         for (int m3 = 0; m3 < K::M3T; ++m3)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // XR holds 16*M3T channel rows (rows >= CP are scratch): no per-lane guard, no exec masking
-                xr[n][m3][r] = XR[(16 * m3 + 4 * g + r) * XRS + (n0 + n) * WTW + ci];
+                xr[n][m3][r] = XR[xoff + (16 * m3 + r) * XRS + n * WTW];
             }
     }
     float h2[4][NT][4];
@@ -809,7 +813,7 @@ __device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, const float
         for (int m3 = 0; m3 < K::M3T; ++m3)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                XR[(16 * m3 + 4 * g + r) * XRS + (n0 + n) * WTW + ci] = fmaf(mk[n], acc3[m3][n][r], xr[n][m3][r]);
+                XR[xoff + (16 * m3 + r) * XRS + n * WTW] = fmaf(mk[n], acc3[m3][n][r], xr[n][m3][r]);
             }
 }
 
