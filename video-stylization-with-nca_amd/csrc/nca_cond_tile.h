@@ -263,7 +263,7 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
     const __amdgpu_buffer_rsrc_t rx = nca_rsrc(xb);
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
-    const int hl = lane >> 5, l5 = lane & 31, q4 = lane >> 4, ci = lane & 15;
+    const int hl = (lane >> 5) & 1, l5 = lane & 31, q4 = (lane >> 4) & 3, ci = lane & 15;   // masked: the opaque lane id has no known range, and index * constant would become a quarter-rate 32-bit multiply
     const bool chk = CHK < 0 ? !t.inner : (CHK != 0);
     if (STATE && use_alive) {
         const __amdgpu_buffer_rsrc_t ra = nca_rsrc(xb + (size_t)a.alive_ch * plane4);
@@ -369,7 +369,7 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
     const bool pending = a.pre_in != nullptr, use_alive = a.alive_ch >= 0, has_goal = a.goal_ch > 0;
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
-    const int hl = lane >> 5, l5 = lane & 31, q4 = lane >> 4, ci = lane & 15;
+    const int hl = (lane >> 5) & 1, l5 = lane & 31, q4 = (lane >> 4) & 3, ci = lane & 15;   // masked: the opaque lane id has no known range, and index * constant would become a quarter-rate 32-bit multiply
 
     NCA_STAMP(8);
     // ---- S1: alpha' (-inf outside the image == max_pool2d padding) -----------------------------
@@ -495,7 +495,7 @@ __device__ __forceinline__ void perceive_tile(const float* __restrict__ WS, cons
     int lane = lane_in;
     asm volatile("" : "+v"(lane));  // per pass: re-read the 27 taps from LDS instead of holding 4x28 registers
     const float* const WPL = WS + K::OFF_WP;
-    const int g = lane >> 4, ci = lane & 15;
+    const int g = (lane >> 4) & 3, ci = lane & 15;
 #pragma unroll
     for (int c4 = 0; c4 < CP / 4; ++c4) {
         const float* const zc = Z + (4 * c4 + g) * CS + n0 * RS + ci + 3;
@@ -541,7 +541,7 @@ __device__ __forceinline__ void perceive_tile_pipe(const float* __restrict__ WS,
     static_assert(NT == 2, "row pairs");
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
-    const int g = lane >> 4, ci = lane & 15;
+    const int g = (lane >> 4) & 3, ci = lane & 15;
     constexpr int NG = CP / 4;
     f32x4 wt[2][7];
     f32x2 nb[2][9];
@@ -608,7 +608,7 @@ __device__ __forceinline__ void mlp_tile(const NcaCondArgs& a, const float* __re
     const f32x4* const W3V = reinterpret_cast<const f32x4*>(WS + K::OFF_W3) + lane_o;   // [M3T][4 m][64]
     const float* const B1L = WS + K::OFF_B1;
     const float* const B2L = WS + K::OFF_B2;
-    const int g = lane_o >> 4, ci = lane_o & 15;
+    const int g = (lane_o >> 4) & 3, ci = lane_o & 15;
     f32x4 acc2[4][NT];
 #pragma unroll
     for (int m2 = 0; m2 < 4; ++m2) {
@@ -698,7 +698,7 @@ __device__ __forceinline__ void mlp_load_regs(const float* __restrict__ WS, int 
     const f32x4* const W1V = reinterpret_cast<const f32x4*>(WS + K::OFF_W1) + lane;
     const f32x4* const W2V = reinterpret_cast<const f32x4*>(WS + K::OFF_W2) + lane;
     const f32x4* const W3V = reinterpret_cast<const f32x4*>(WS + K::OFF_W3) + lane;
-    const int g = lane >> 4;
+    const int g = (lane >> 4) & 3;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -722,7 +722,7 @@ __device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, const float
     using K = WCfg<CP>;
     int lane_o = lane_in;
     asm volatile("" : "+v"(lane_o));
-    const int g = lane_o >> 4, ci = lane_o & 15;
+    const int g = (lane_o >> 4) & 3, ci = lane_o & 15;
     // accumulator seeds: eight LDS reads issued together before the MFMA stream (they live only during this phase, so
     // the perception before it has the registers to pipeline its own reads)
     f32x4 b1[4], b2[4];
@@ -874,7 +874,7 @@ __device__ __forceinline__ void mlp_tile_bf16(const MlpRegsBf<CP>& Wr, const flo
     using K = MlpRegsBf<CP>;
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
-    const int g = lane >> 4, ci = lane & 15;
+    const int g = (lane >> 4) & 3, ci = lane & 15;
     s16x4 pb[NT][K::KS1];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -977,7 +977,7 @@ __device__ __forceinline__ void mlp_tile_split(const MlpRegsSplit<CP>& Wr, const
     using K = MlpRegsBf<CP>;
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
-    const int g = lane >> 4, ci = lane & 15;
+    const int g = (lane >> 4) & 3, ci = lane & 15;
     s16x4 ph[NT][K::KS1], pl[NT][K::KS1];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -1050,7 +1050,7 @@ __device__ __forceinline__ void store_tile(const NcaCondArgs& a, const WTile& t,
     asm volatile("" : "+s"(plane4));   // see issue_loads
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
-    const int q4 = lane >> 4, row = (lane >> 2) & 3, ff = lane & 3;
+    const int q4 = (lane >> 4) & 3, row = (lane >> 2) & 3, ff = lane & 3;
     const int gy = t.ty0 + row, gx = t.tx0 + 4 * ff;
     const bool ok = !CHECK || (gy < H && gx + 3 < W);
     const __amdgpu_buffer_rsrc_t ro = nca_rsrc(reinterpret_cast<char*>(a.x_out) + (size_t)t.b * C * plane * SB);
