@@ -216,7 +216,9 @@ int ncahip_cond_grow_fwd_f32(float *states, uint8_t *pre, int ring, int T, float
  *   the T steps, nca.py:207-208 reuse the same encoding), and the weight gradients in the reference layouts
  *   (g_wp [3C,9], g_w1 [hidden,3C], g_b1, g_w2 [hidden,hidden], g_b2, g_w3 [C,hidden]); masks carry no
  *   gradient; clamp passes gradient on the closed interval (torch.clamp).  Deterministic (no float atomics).
- *   Requires W % 4 == 0 and 16-byte aligned buffers.  `workspace`: ncahip_cond_grow_bwd_workspace() bytes. */
+ *   Requires W % 4 == 0 and 16-byte aligned buffers.  `workspace`: ncahip_cond_grow_bwd_workspace() bytes.
+ *   T = 1 is the backward of one ncahip_cond_step_fwd_f32 + ncahip_cond_finalize_f32 pair (slot 0 = x_t, slot 1 = the
+ *   pending x'_t the step wrote): there is no separate per-step entry point.                                       */
 size_t ncahip_cond_grow_bwd_workspace(int B, int C, int H, int W, int hidden);
 int ncahip_cond_grow_bwd_f32(const float *states, const uint8_t *pre, int T,
                              const float *goal, int goal_ch, const float *u,
