@@ -263,3 +263,33 @@ def test_webgl_interchange_and_video_loop():
     assert len(outs) == 6 and outs[0].shape == (3, 32, 48)
     assert all(float(o.min()) >= 0.0 and float(o.max()) <= 1.0 for o in outs)
     assert not torch.equal(outs[0], outs[-1])
+
+
+def test_dynca_c32_trains_through_composed_path():
+    """C = 32 (BASELINE configs[4]): inference on the fused kernel, a differentiable pass through HIP stencil + library
+    GEMMs; both agree, gradients match the oracle's autograd."""
+    from ncahip.models.dynca import DyNCA
+    torch.manual_seed(0)
+    m = DyNCA(32, 3, fc_dim=96, padding_mode="circular", conditioning="edges", device=torch.device(DEV))
+    m.mask_rng = "philox"
+    x = torch.rand(1, 32, 24, 32, device=DEV) - 0.5
+    img = torch.rand(1, 1, 24, 32, device=DEV) * 2 - 1
+    with torch.no_grad():
+        m._mask_step = 0
+        y_fused, _ = m.forward_nsteps(x, 3, cond_img=img)
+    m._mask_step = 0
+    xg = x.clone().requires_grad_(True)
+    y_comp, rgb = m.forward_nsteps(xg, 3, cond_img=img)
+    assert rel_err(y_comp.detach().cpu(), y_fused.cpu()) < REL_TOL
+    rgb.square().mean().backward()
+    # oracle autograd on the same inputs / uniforms
+    prm = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items() if k.startswith("w")}
+    us = [torch.from_numpy(O.philox_uniform(m.mask_seed, t, 1, 24, 32)) for t in range(3)]
+    xo = x.cpu().clone().requires_grad_(True)
+    cond = O.edge_extractor(img.cpu(), "tanh")
+    yo = xo
+    for u in us:
+        yo = O.dynca_step(yo, cond, u, prm, "circular", 0.5)
+    (yo[:, :3] * 2.0).square().mean().backward()
+    assert rel_err(xg.grad.cpu(), xo.grad) < 2e-4
+    assert rel_err(m.w1.weight.grad.cpu(), prm["w1.weight"].grad) < 2e-4

@@ -117,6 +117,14 @@ class DyNCA(nn.Module):
     def _multiscale(self) -> bool:
         return list(self.perception_scales) != [0]
 
+    def _composed(self, x) -> bool:
+        """True when the step runs as HIP stencil + library GEMMs instead of the fused kernels: multi-scale perception, or
+        a differentiable pass at 16 < C <= 32 (the fused backward kernels cover C <= 16; BASELINE configs[4] trains at C = 32)."""
+        if self._multiscale():
+            return True
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        return self.c_in > 16 and needs_grad
+
     # ------------------------------------------------------------------ reference surface
     def perceive_torch(self, x, scale=0):
         """dynca.py:75-100: [x, Sx*x, Sy*x, L*x]; scale > 0: bilinear down by 2^scale, perceive, bilinear up.  The stencil
@@ -154,7 +162,7 @@ class DyNCA(nn.Module):
 
     def forward(self, x, update_rate=0.5, return_perception=False, cond_img=None):
         cond = self._cond(x, cond_img)
-        if self._multiscale():
+        if self._composed(x):
             out = self._step_multiscale(x.float(), cond, update_rate, self._draw_one(x))
         else:
             out, _ = dynca_nsteps_autograd(self, x, cond, 1, update_rate)
@@ -183,7 +191,7 @@ class DyNCA(nn.Module):
 
     def forward_nsteps(self, input_state, step_n, update_rate=0.5, return_middle_feature=False, cond_img=None):
         cond = self._cond(input_state, cond_img)
-        if self._multiscale():
+        if self._composed(input_state):
             x, mids = input_state.float(), []
             for _ in range(step_n):
                 x = self._step_multiscale(x, cond, update_rate, self._draw_one(x))
