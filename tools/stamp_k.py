@@ -75,3 +75,12 @@ L.nca_debug_set_stamp_buffer_pc(None)
 k = buf[NWG * 8 * 8 * 16:].cpu().numpy().reshape(NWG, 8, 8).astype(np.float64)
 wl = (k[:, 0, 3] - k[:, 0, 0])
 print("   whole: min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f   (max/median %.3f)" % (wl.min(), np.percentile(wl, 10), np.median(wl), np.percentile(wl, 90), wl.max(), wl.max() / np.median(wl)))
+print("---- store on the critical path?")
+run("f32 normal", 0, False)
+run("f32 normal, no store", 0xD1AE, False)
+print("---- fp32 consumer alone")
+run("f32 consumer alone", 0xD1A6, False)
+run("f32 consumer alone, no perception", 0xD1AA, False)
+run("f32 consumer alone, no MLP", 0xD1AB, False)
+run("f32 consumer alone, no store", 0xD1AC, False)
+run("f32 consumer alone, nothing", 0xD1AD, False)

@@ -107,27 +107,33 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
     // workgroup across the columns of the image -- with the plain stride a workgroup whose first tile sits on the left or
     // right image border gets ONLY border tiles (nloc = 32 is a multiple of the 16 super-tile columns at 256^2) and
     // finishes ~8 % after the others.
-    struct Pos { int k, t, sx, sy, b; };
+    // Coordinates advance incrementally (no integer division per tile: on this target a runtime division is a ~40-instruction
+    // vector sequence, and both roles walk the tiles): t_{k+1} - t_k is nloc + 1, or 1 when the rotation wraps.
+    struct Pos { int k, r, t, sx, sy, b; };   // r = (local + k) mod nloc
     const int n_rounds = (tw.end - tw.base + tw.stride - 1) / tw.stride;
-    auto pos_of = [&](int k) -> Pos {
-        Pos p{k, tw.end, 0, 0, 0};
-        if (k < n_rounds) {
-            int r = tw.local + k;
-            while (r >= tw.stride) r -= tw.stride;
-            p.t = tw.base + k * tw.stride + r;
-            if (p.t < tw.end) {
-                p.sx = p.t % st_x;
-                const int q = p.t / st_x;
-                p.sy = q % st_y;
-                p.b = q / st_y;
-            }
+    auto pos_first = [&]() -> Pos {
+        Pos p{0, tw.local, tw.base + tw.local, 0, 0, 0};
+        p.sx = p.t % st_x;                      // the only divisions of the launch
+        const int q = p.t / st_x;
+        p.sy = q % st_y;
+        p.b = q / st_y;
+        return p;
+    };
+    auto advance = [&](Pos p) -> Pos {
+        ++p.k;
+        int delta = tw.stride + 1;
+        if (++p.r == tw.stride) { p.r = 0; delta = 1; }
+        p.t += delta;
+        p.sx += delta;
+        while (p.sx >= st_x) {
+            p.sx -= st_x;
+            if (++p.sy == st_y) { p.sy = 0; ++p.b; }
         }
         return p;
     };
-    auto advance = [&](const Pos& p) -> Pos { return pos_of(p.k + 1); };
     auto tile_of = [&](const Pos& p) -> WTile {
         WTile w{0, 0, 0, false, false};
-        if (p.t < tw.end) {
+        if (p.k < n_rounds && p.t < tw.end) {
             w.b = p.b;
             w.ty0 = p.sy * PSTH + pair * WTH;
             w.tx0 = p.sx * PSTW;
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
         }
         NCA_STAMP(7);
 #ifdef NCA_STAMPS
-        if (a.seed == 0xD1ACull || a.seed == 0xD1ADull) return;   // diagnostic knob: no store
+        if (a.seed == 0xD1ACull || a.seed == 0xD1ADull || a.seed == 0xD1AEull) return;   // diagnostic knob: no store (0xD1AE: nothing else changed)
 #endif
         if (t.inner) store_tile<CP, false, EXACT, kNtStore && !BF, ST>(a, t, L.XR, lane);   // bf16 rows are 32-byte segments: let the L2 merge them
         else store_tile<CP, true, EXACT, kNtStore && !BF, ST>(a, t, L.XR, lane);
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
     };
 
     int which = 0;
-    Pos pos = pos_of(0);
+    Pos pos = pos_first();
     WTile cur = tile_of(pos);
     // The two roles run separate loops with the same barrier count (all branches are wave-uniform): the consumer's
     // 128 weight registers are then not live in the producer's code and vice versa.
