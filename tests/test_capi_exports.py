@@ -64,6 +64,22 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"goal" in L.ncahip_last_error()
     with pytest.raises(_capi.NcaHipError):
         _capi.check(rc, "cond_step")
+    # bf16-storage entry points: W % 4 and 8-byte alignment are refused up front (there is no any-shape bf16 kernel)
+    two = ctypes.c_void_p(0x2000)
+    rc = L.ncahip_cond_step_fwd_bf16(one, None, two, one, None, 0, None, one, one, one, one, one, one,
+                                     1, 16, 8, 10, 64, 3, 0.1, 0.5, -10.0, 10.0, 0, 0, None)
+    assert rc == -2 and b"W % 4" in L.ncahip_last_error()
+    rc = L.ncahip_cond_step_fwd_bf16(ctypes.c_void_p(0x1002), None, two, one, None, 0, None, one, one, one, one, one, one,
+                                     1, 16, 8, 8, 64, 3, 0.1, 0.5, -10.0, 10.0, 0, 0, None)
+    assert rc == -2
+    # DyNCA forward accepts 16 < C <= 32, the backward does not
+    rc = L.ncahip_dynca_step_fwd_f32(one, two, None, None, one, one, one, one, 1, 33, 8, 8, 96, 0, 1, 0.5, 0, 0, None)
+    assert rc == -2
+    rc = L.ncahip_dynca_step_bwd_f32(one, None, None, one, one, one, one, 1, 32, 8, 8, 96, 0, 1, 0.5, 0, 0,
+                                     one, two, one, one, one, None)
+    assert rc == -2 and b"backward" in L.ncahip_last_error()
+    # precision switch: only 0 (exact) and 1 (bf16x3)
+    assert L.ncahip_cond_precision(0) == 0 and L.ncahip_cond_precision(5) == -1
 
 
 def test_hot_path_refuses_cpu_tensors():
