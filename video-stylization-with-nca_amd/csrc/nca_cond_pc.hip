@@ -27,7 +27,8 @@ struct PCfg {
     static constexpr int SCR_A3 = 2 * BUF;                         // producer scratch, not double-buffered
     static constexpr int SCR_LIFE = SCR_A3 + (WTH + 6) * RS;
     static constexpr int SCR_A2 = SCR_LIFE + (WTH + 4) * RS;
-    static constexpr int PAIR = SCR_A2 + (WTH + 4) * RS;
+    static constexpr int SCR_FLAG = SCR_A2 + (WTH + 4) * RS;       // [0] last round staged, [1] last round consumed (ints)
+    static constexpr int PAIR = SCR_FLAG + 4;
     static constexpr int LDS_FLOATS = F::SHARED + 4 * PAIR;
     static_assert(BUF % 4 == 0 && PAIR % 4 == 0 && BUF_XR % 4 == 0, "16-byte carve");
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
@@ -206,24 +207,46 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
     int which = 0;
     Pos pos = pos_first();
     WTile cur = tile_of(pos);
-    // The two roles run separate loops with the same barrier count (all branches are wave-uniform): the consumer's
-    // 128 weight registers are then not live in the producer's code and vice versa.
+    // Hand-off between the two waves of a pair: two monotonic round counters in LDS instead of a workgroup barrier per
+    // tile.  A workgroup barrier keeps the four pairs of a CU in lock-step, so their perception phases (LDS-bandwidth-bound)
+    // and their stores all collide; with pair-local hand-offs the pairs drift apart.  LDS operations of one wave execute in
+    // order, so "data, then counter" on the writer side and "counter, then data" on the reader side is all the ordering
+    // needed.  The polls are bounded (a broken hand-off gives wrong numbers, never a hung device).
+    int* const flags = reinterpret_cast<int*>(PR + PK::SCR_FLAG);
+    auto post = [&](int idx, int round) {
+        wave_sync();
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS traffic for the round is done
+        if (lane == 0) __hip_atomic_store(flags + idx, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto await = [&](int idx, int round) {
+        int spins = 0;
+        while (__hip_atomic_load(flags + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < round && ++spins < (1 << 20))
+            __builtin_amdgcn_s_sleep(1);
+        wave_sync();
+    };
+    // The two roles run separate loops (all branches are wave-uniform): the consumer's 128 weight registers are then not
+    // live in the producer's code and vice versa.
     if (producer) {
+        if (lane == 0) { flags[0] = -1; flags[1] = -1; }
         // At equal priority the (older) consumer waves win every arbitration and the producer only issues in the gaps
         // of their MFMA stream; its instructions are few: let them go first.
         __builtin_amdgcn_s_setprio(3);
         produce(cur, 0);              // overlaps the weight-image fill of the consumer waves
+        post(0, 0);
         NCA_KSTAMP(1);
-        __syncthreads();              // weight image + first tile ready
+        __syncthreads();              // weight image complete, counters initialised
         NCA_KSTAMP(2);
-        while (pos.k < n_rounds) {    // uniform over the workgroup
+        while (pos.k + 1 < n_rounds) {
             const Pos pn = advance(pos);
             const WTile nxt = tile_of(pn);
+            __builtin_amdgcn_s_setprio(0);
+            await(1, pn.k - 2);       // the consumer is done with the round that used this buffer
+            __builtin_amdgcn_s_setprio(3);
 #ifdef NCA_STAMPS
             if (a.seed != 0xD1A6ull && (a.seed < 0xD1AAull || a.seed > 0xD1ADull))  // diagnostic knob (stamps build only): idle producers
 #endif
             produce(nxt, which ^ 1);
-            __syncthreads();          // tile buffers change hands
+            post(0, pn.k);
             cur = nxt;
             pos = pn;
             which ^= 1;
@@ -240,18 +263,16 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
         while (pos.k < n_rounds) {
             const Pos pn = advance(pos);
             const WTile nxt = tile_of(pn);
-            NCA_STAMP(0);
+            await(0, pos.k);          // this round's tile has been staged
+            if (tile_no == 2) NCA_KSTAMP(4);            // light stamps around one steady-state tile
 #ifdef NCA_STAMPS
             if (a.seed != 0xD1A7ull)  // diagnostic knob: idle consumers
 #endif
-            if (tile_no == 2) NCA_KSTAMP(4);            // light stamps around one steady-state tile: top / consumed / barrier passed
             consume(cur, which);
             if (tile_no == 2) NCA_KSTAMP(5);
-            NCA_STAMP(1);
-            __syncthreads();   // (workgroup scope: lgkmcnt(0) + s_barrier -- the tile's global stores are not waited for)
+            post(1, pos.k);
             if (tile_no == 2) NCA_KSTAMP(6);
             if (tile_no == 3) NCA_KSTAMP(7);
-            NCA_STAMP(2);
             cur = nxt;
             pos = pn;
             which ^= 1;
