@@ -16,6 +16,10 @@
 // One wave per SIMD (the persistent accumulators need the registers); 4 waves / workgroup / CU.
 #include "nca_cond_tile.h"
 
+#if defined(NCA_STAMPS)
+unsigned long long* nca_debug_stamp_ptr();
+#endif
+
 namespace {
 
 constexpr int kBwdWaves = 4, kBwdThreads = 256;
@@ -44,6 +48,48 @@ __host__ __device__ inline int slab_off_b1(int C, int hid) { return slab_off_w3(
 __host__ __device__ inline int slab_off_b2(int C, int hid) { return slab_off_b1(C, hid) + hid; }
 __host__ __device__ inline int slab_floats(int C, int hid) { return slab_off_b2(C, hid) + hid; }
 
+// Operand streaming for one wave per SIMD: with nobody to switch to, an LDS read issued right before its MFMAs costs the
+// whole LDS round trip (and that is where the compiler's scheduler puts it, to save registers).  piped() runs N steps with
+// the operands of step i+1 requested before the MFMAs of step i are issued; the scheduling fences keep that order, and the
+// compiler's own wait insertion then only waits for the older request.
+// d * 1[h > 0], with the compare pinned to the point of use: left free, the compiler evaluates all 64 compares of a layer
+// where h is produced and carries the lane masks in SGPR pairs across the layer (spilled, one VALU op each way).
+__device__ __forceinline__ float gate_pos(float h, float d) {
+    asm volatile("" : "+v"(h));
+    return h > 0.0f ? d : 0.0f;
+}
+template <int GSZ>
+struct OpN { float v[GSZ]; };
+#define NCA_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <int N, typename LD, typename MM>
+__device__ __forceinline__ void piped(LD&& ld, MM&& mm) {
+    auto cur = ld(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        auto nxt = cur;
+        if (i + 1 < N) nxt = ld(i + 1);
+        NCA_FENCE();
+        mm(i, cur);
+        NCA_FENCE();
+        cur = nxt;
+    }
+}
+
+#if defined(NCA_STAMPS)
+// diagnostic build: cycles per phase, summed over the wave's tiles -> dbg[(wg*4+wave)*16 + phase]
+#define NCA_BPHASE(i)                                                                       \
+    do {                                                                                    \
+        unsigned long long t_;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        ph_acc[i] += t_ - ph_last;                                                          \
+        ph_last = t_;                                                                       \
+    } while (0)
+#else
+#define NCA_BPHASE(i) do { } while (0)
+#endif
+
 template <int CP>
 __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const NcaCondBwdArgs ba) {
     using K = BCfg<CP>;
@@ -57,37 +103,60 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
     const unsigned plane = (unsigned)(H * W);
     const int g = lane >> 4, ci = lane & 15;
 
+#if defined(NCA_STAMPS)
+    unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_last, ph_real0, ph_t0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_real0)::"memory");
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_last)::"memory");
+    ph_t0 = ph_last;
+#endif
     // ---- forward A-operand images (identical to the forward kernel) + transposed images --------------------
-    fill_image_w<4 * FK::K1S * 64, kBwdThreads>(smem + FK::OFF_W1, a.w1, tid, [&](int idx) -> long {
-        const int l = idx & 63, s = (idx >> 6) % FK::K1S, m = (idx >> 6) / FK::K1S;
-        const int gg = l >> 4, o = 16 * m + (l & 15);
-        const int ch = 4 * (s / 3) + gg, f = s % 3;
-        return (ch < C && o < hid) ? (long)o * K1 + 3 * ch + f : -1;
-    });
-    fill_image_w<4 * 16 * 64, kBwdThreads>(smem + FK::OFF_W2, a.w2, tid, [&](int idx) -> long {
-        const int l = idx & 63, s = (idx >> 6) % 16, m = (idx >> 6) / 16;
-        const int gg = l >> 4, o = 16 * m + (l & 15);
-        const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
-        return (o < hid && k < hid) ? (long)o * hid + k : -1;
-    });
-    fill_image_w<FK::HID, kBwdThreads>(smem + FK::OFF_B1, a.b1, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
-    fill_image_w<FK::HID, kBwdThreads>(smem + FK::OFF_B2, a.b2, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
-    fill_image_w<CP * FK::WPS, kBwdThreads>(smem + FK::OFF_WP, a.wp, tid, [&](int idx) -> long {
-        const int ch = idx / FK::WPS, j = idx % FK::WPS;
-        return (ch < C && j < 27) ? (long)ch * 27 + j : -1;
-    });
-    // W3^T: lane (gg,i) of (m, s) holds W3[ch = 4gg+s][h2 = 16m+i]
-    fill_image_w<4 * 4 * 64, kBwdThreads>(smem + K::OFF_W3T, a.w3, tid, [&](int idx) -> long {
-        const int l = idx & 63, s = (idx >> 6) % 4, m = (idx >> 6) / 4;
-        const int ch = 4 * (l >> 4) + s, h2 = 16 * m + (l & 15);
-        return (ch < C && h2 < hid) ? (long)ch * hid + h2 : -1;
-    });
-    // W1^T: lane (gg,i) of (mj, s) holds W1[h1 = 16(s/4)+4gg+s%4][j = 16mj+i]
-    fill_image_w<K::MJ * 16 * 64, kBwdThreads>(smem + K::OFF_W1T, a.w1, tid, [&](int idx) -> long {
-        const int l = idx & 63, s = (idx >> 6) % 16, mj = (idx >> 6) / 16;
-        const int h1 = 16 * (s >> 2) + 4 * (l >> 4) + (s & 3), j = 16 * mj + (l & 15);
-        return (h1 < hid && j < K1) ? (long)h1 * K1 + j : -1;
-    });
+    // Two-phase: all gathers are requested before the first is waited for (one cold round trip instead of ten).
+    {
+        FillRegs<4 * FK::K1S * 64, kBwdThreads> fr0;
+        FillRegs<4 * 16 * 64, kBwdThreads> fr1;
+        FillRegs<FK::HID, kBwdThreads> fr2;
+        FillRegs<FK::HID, kBwdThreads> fr3;
+        FillRegs<CP * FK::WPS, kBwdThreads> fr4;
+        FillRegs<4 * 4 * 64, kBwdThreads> fr5;
+        FillRegs<K::MJ * 16 * 64, kBwdThreads> fr6;
+        fill_load(fr0, a.w1, tid, [&](int idx) -> long {
+            const int l = idx & 63, s = (idx >> 6) % FK::K1S, m = (idx >> 6) / FK::K1S;
+            const int gg = l >> 4, o = 16 * m + (l & 15);
+            const int ch = 4 * (s / 3) + gg, f = s % 3;
+            return (ch < C && o < hid) ? (long)o * K1 + 3 * ch + f : -1;
+        });
+        fill_load(fr1, a.w2, tid, [&](int idx) -> long {
+            const int l = idx & 63, s = (idx >> 6) % 16, m = (idx >> 6) / 16;
+            const int gg = l >> 4, o = 16 * m + (l & 15);
+            const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
+            return (o < hid && k < hid) ? (long)o * hid + k : -1;
+        });
+        fill_load(fr2, a.b1, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
+        fill_load(fr3, a.b2, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
+        fill_load(fr4, a.wp, tid, [&](int idx) -> long {
+            const int ch = idx / FK::WPS, j = idx % FK::WPS;
+            return (ch < C && j < 27) ? (long)ch * 27 + j : -1;
+        });
+        // W3^T: lane (gg,i) of (m, s) holds W3[ch = 4gg+s][h2 = 16m+i]
+        fill_load(fr5, a.w3, tid, [&](int idx) -> long {
+            const int l = idx & 63, s = (idx >> 6) % 4, m = (idx >> 6) / 4;
+            const int ch = 4 * (l >> 4) + s, h2 = 16 * m + (l & 15);
+            return (ch < C && h2 < hid) ? (long)ch * hid + h2 : -1;
+        });
+        // W1^T: lane (gg,i) of (mj, s) holds W1[h1 = 16(s/4)+4gg+s%4][j = 16mj+i]
+        fill_load(fr6, a.w1, tid, [&](int idx) -> long {
+            const int l = idx & 63, s = (idx >> 6) % 16, mj = (idx >> 6) / 16;
+            const int h1 = 16 * (s >> 2) + 4 * (l >> 4) + (s & 3), j = 16 * mj + (l & 15);
+            return (h1 < hid && j < K1) ? (long)h1 * K1 + j : -1;
+        });
+        fill_store(fr0, smem + FK::OFF_W1, tid);
+        fill_store(fr1, smem + FK::OFF_W2, tid);
+        fill_store(fr2, smem + FK::OFF_B1, tid);
+        fill_store(fr3, smem + FK::OFF_B2, tid);
+        fill_store(fr4, smem + FK::OFF_WP, tid);
+        fill_store(fr5, smem + K::OFF_W3T, tid);
+        fill_store(fr6, smem + K::OFF_W1T, tid);
+    }
     __syncthreads();
 
     const float* const W1L = smem + FK::OFF_W1;
@@ -116,6 +185,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
         for (int j = 0; j < K::MJ; ++j) aW1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    NCA_BPHASE(10);  // start-up: weight images, accumulators
     // ---- tile walk: super-tiles of 16 x 16 (4 waves stacked vertically) ------------------------------------
     constexpr int BSTH = 16, BSTW = 16;
     const int st_x = (W + BSTW - 1) / BSTW, st_y = (H + BSTH - 1) / BSTH;
@@ -131,36 +201,46 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
         t.inner = t.ty0 >= halo && t.ty0 + WTH + halo <= H && t.tx0 >= halo && t.tx0 + WTW + halo <= W;
         const int ty0 = t.ty0, tx0 = t.tx0;
 
-        // ---- forward staging: s_t (XR), pre_t (PN), z_t (Z), fire mask (MK) -------------------------------
+        NCA_BPHASE(0);   // loop overhead / previous tile's tail
+        // ---- all global loads of the tile are requested up front (one HBM round trip per tile instead of two: with one
+        //      wave per SIMD nothing else hides it): forward operands, pending x'_t (alpha halo 1 + interior), incoming gradient
         TileRegs<CP> R;
         issue_loads<CP, true, true>(a, t, lane, R);
+        const float* const xn = ba.x_next + (size_t)t.b * C * plane;
+        const float* const gn = ba.g_next + (size_t)t.b * C * plane;
+        const int hl = (lane >> 5) & 1, l5 = lane & 31;
+        const int row = (lane >> 2) & 3, ff = lane & 3;
+        const bool ok = ty0 + row < H && tx0 + 4 * ff + 3 < W;
+        const unsigned off = ok ? (unsigned)((ty0 + row) * W + tx0 + 4 * ff) : 0u;
+        float av[3];
+        bool aok[3];
+        if (use_alive) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int gy = ty0 - 1 + 2 * k + hl, gx = tx0 - 1 + l5;
+                aok[k] = l5 < 18 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                av[k] = xn[(unsigned)a.alive_ch * plane + (aok[k] ? (unsigned)(gy * W + gx) : 0u)];
+            }
+        }
+        f32x4 xv[CP / 4], gv[CP / 4];
+#pragma unroll
+        for (int k = 0; k < CP / 4; ++k) {
+            const unsigned ch = (unsigned)min(4 * k + g, C - 1);
+            xv[k] = ld4(xn + ch * plane + off);
+            gv[k] = ld4(gn + ch * plane + off);
+        }
+        // ---- forward staging: s_t (XR), pre_t (PN), z_t (Z), fire mask (MK) -------------------------------
         const TileLds L = wave_private_lds<CP>(PWR);
         if (t.inner) stage_tile<CP, false>(a, t, L, lane, R, 0);
         else stage_tile<CP, true>(a, t, L, lane, R, 0);
+        NCA_BPHASE(1);   // forward staging
 
         // ---- pending x'_t: alpha halo 1 -> A1 (post mask), interior -> XR; incoming gradient -> TB --------
-        const float* const xn = ba.x_next + (size_t)t.b * C * plane;
-        const float* const gn = ba.g_next + (size_t)t.b * C * plane;
         {
-            const int hl = lane >> 5, l5 = lane & 31;
             if (use_alive) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int r = 2 * k + hl, gy = ty0 - 1 + r, gx = tx0 - 1 + l5;
-                    const bool ok = l5 < 18 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-                    const float v = xn[(unsigned)a.alive_ch * plane + (ok ? (unsigned)(gy * W + gx) : 0u)];
-                    if (l5 < 18) A1[r * RS + l5 + 3] = ok ? v : NCA_NEG_INF;
-                }
-            }
-            const int row = (lane >> 2) & 3, ff = lane & 3, gy = ty0 + row, gx = tx0 + 4 * ff;
-            const bool ok = gy < H && gx + 3 < W;
-            const unsigned off = ok ? (unsigned)(gy * W + gx) : 0u;
-            f32x4 xv[CP / 4], gv[CP / 4];
-#pragma unroll
-            for (int k = 0; k < CP / 4; ++k) {
-                const unsigned ch = (unsigned)min(4 * k + g, C - 1);
-                xv[k] = ld4(xn + ch * plane + off);
-                gv[k] = ld4(gn + ch * plane + off);
+                for (int k = 0; k < 3; ++k)
+                    if (l5 < 18) A1[(2 * k + hl) * RS + l5 + 3] = aok[k] ? av[k] : NCA_NEG_INF;
             }
             // z_t interior out (kernel B needs it for the perception-weight gradient)
             float* const zo = ba.zbuf + (size_t)t.b * C * plane + off;
@@ -181,6 +261,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             wave_sync();
         }
 
+        NCA_BPHASE(2);   // x'/g loads, z out
         // ---- dL/dx'_t = G * 1[lo <= x'*life <= hi] * life (nca.py:191-194);  d out = . * fire mask.  All four
         //      rows now: TB (the staged incoming gradient) is reused for the transposes inside the pass loop.
         float dOall[WTH][4];
@@ -202,47 +283,70 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
                 dOall[row][r] = gxv * mk;
             }
         }
+        NCA_BPHASE(3);   // gate
 #pragma unroll 1
         for (int pass = 0; pass < WTH / NT; ++pass) {
             const int n0 = pass * NT;
             // ---- forward recompute: P, h1, h2 kept in registers ------------------------------------------
             float P[NT][K::K1S];
             perceive_tile<CP, NT>(smem, Z, lane, n0, P);
+            NCA_BPHASE(4);   // perception
             f32x4 h1[4][NT], h2[4][NT];
+            constexpr int G1 = 3, NG1 = K::K1S / G1;   // layer-1 k-steps in groups of 3 (K1S = 9 or 12)
+            static_assert(K::K1S % G1 == 0, "layer-1 operand groups");
+            piped<4 * NG1>(
+                [&](int i) {
+                    const int m = i / NG1, sg = i % NG1;
+                    OpN<G1> o;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const f32x4 bias = ld4(B1L + 16 * m + 4 * g);
+                    for (int q = 0; q < G1; ++q) o.v[q] = W1L[(m * K::K1S + G1 * sg + q) * 64 + lane];
+                    return o;
+                },
+                [&](int i, const OpN<G1>& o) {
+                    const int m = i / NG1, sg = i % NG1;
+                    if (sg == 0) {
+                        const f32x4 bias = ld4(B1L + 16 * m + 4 * g);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) h1[m][n] = bias;
-#pragma unroll
-                for (int s = 0; s < K::K1S; ++s) {
-                    const float wa = W1L[(m * K::K1S + s) * 64 + lane];
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) h1[m][n] = nca_mfma(wa, P[n][s], h1[m][n]);
-                }
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) h1[m][n][r] = relu(h1[m][n][r]);
-            }
-#pragma unroll
-            for (int m2 = 0; m2 < 4; ++m2) {
-                const f32x4 bias = ld4(B2L + 16 * m2 + 4 * g);
-#pragma unroll
-                for (int n = 0; n < NT; ++n) h2[m2][n] = bias;
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float wa = W2L[(m2 * 16 + 4 * m + r) * 64 + lane];
-#pragma unroll
-                        for (int n = 0; n < NT; ++n) h2[m2][n] = nca_mfma(wa, h1[m][n][r], h2[m2][n]);
+                        for (int n = 0; n < NT; ++n) h1[m][n] = bias;
                     }
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
+                    for (int q = 0; q < G1; ++q)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) h2[m2][n][r] = relu(h2[m2][n][r]);
-            }
+                        for (int n = 0; n < NT; ++n) h1[m][n] = nca_mfma(o.v[q], P[n][G1 * sg + q], h1[m][n]);
+                    if (sg == NG1 - 1) {
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) h1[m][n][r] = relu(h1[m][n][r]);
+                    }
+                });
+            piped<16>(
+                [&](int i) {
+                    const int m2 = i >> 2, m = i & 3;
+                    OpN<4> o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o.v[r] = W2L[(m2 * 16 + 4 * m + r) * 64 + lane];
+                    return o;
+                },
+                [&](int i, const OpN<4>& o) {
+                    const int m2 = i >> 2, m = i & 3;
+                    if (m == 0) {
+                        const f32x4 bias = ld4(B2L + 16 * m2 + 4 * g);
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) h2[m2][n] = bias;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) h2[m2][n] = nca_mfma(o.v[r], h1[m][n][r], h2[m2][n]);
+                    if (m == 3) {
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) h2[m2][n][r] = relu(h2[m2][n][r]);
+                    }
+                });
+            NCA_BPHASE(5);   // forward recompute
             float dO[NT][4];
 #pragma unroll
             for (int n = 0; n < NT; ++n)
@@ -265,28 +369,39 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
 #pragma unroll
                 for (int m = 0; m < 4; ++m) st4(tw_ + 16 + 16 * m, h2[m][n]);
                 wave_sync();
+                piped<4>(
+                    [&](int s_) {
+                        OpN<5> o;
+                        o.v[0] = tr_[4 * s_ * TBS];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float av = tr_[4 * s * TBS];
+                        for (int nb = 0; nb < 4; ++nb) o.v[1 + nb] = tr_[4 * s_ * TBS + 16 + 16 * nb];
+                        return o;
+                    },
+                    [&](int, const OpN<5>& o) {
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) aW3[nb] = nca_mfma(av, tr_[4 * s * TBS + 16 + 16 * nb], aW3[nb]);
-                }
+                        for (int nb = 0; nb < 4; ++nb) aW3[nb] = nca_mfma(o.v[0], o.v[1 + nb], aW3[nb]);
+                    });
             }
+            piped<4>(
+                [&](int m) {
+                    OpN<4> o;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+                    for (int s_ = 0; s_ < 4; ++s_) o.v[s_] = W3T[(m * 4 + s_) * 64 + lane];
+                    return o;
+                },
+                [&](int m, const OpN<4>& o) {
 #pragma unroll
-                for (int n = 0; n < NT; ++n) d2[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int n = 0; n < NT; ++n) d2[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float wa = W3T[(m * 4 + s) * 64 + lane];
+                    for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) d2[m][n] = nca_mfma(wa, dO[n][s], d2[m][n]);
-                }
+                        for (int n = 0; n < NT; ++n) d2[m][n] = nca_mfma(o.v[s_], dO[n][s_], d2[m][n]);
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
+                    for (int n = 0; n < NT; ++n)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) d2[m][n][r] = h2[m][n][r] > 0.0f ? d2[m][n][r] : 0.0f;
-            }
+                        for (int r = 0; r < 4; ++r) d2[m][n][r] = gate_pos(h2[m][n][r], d2[m][n][r]);
+                });
+            NCA_BPHASE(6);   // layer 3
             // ---- layer 2: dW2 = d2 (rows 0..63) x h1 (rows 64..127);  d1 = (W2^T d2) * 1[h1 > 0] ---------------------------
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -297,43 +412,53 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
                     st4(tw_ + 64 + 16 * m, h1[m][n]);
                 }
                 wave_sync();
+                piped<4>(
+                    [&](int s_) {
+                        OpN<8> o;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    float bv[4];
+                        for (int k = 0; k < 4; ++k) {
+                            o.v[k] = tr_[4 * s_ * TBS + 16 * k];
+                            o.v[4 + k] = tr_[4 * s_ * TBS + 64 + 16 * k];
+                        }
+                        return o;
+                    },
+                    [&](int, const OpN<8>& o) {
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) bv[nb] = tr_[4 * s * TBS + 64 + 16 * nb];
+                        for (int ma = 0; ma < 4; ++ma)
 #pragma unroll
-                    for (int ma = 0; ma < 4; ++ma) {
-                        const float av = tr_[4 * s * TBS + 16 * ma];
-#pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) aW2[ma][nb] = nca_mfma(av, bv[nb], aW2[ma][nb]);
-                    }
-                }
+                            for (int nb = 0; nb < 4; ++nb) aW2[ma][nb] = nca_mfma(o.v[ma], o.v[4 + nb], aW2[ma][nb]);
+                    });
             }
             const int w2t_lane = (ci & 3) * 64 + (ci >> 2) * 16 + 4 * g;  // transposed read of the forward W2 image
+            piped<16>(
+                [&](int i) {   // W2[h2 = 16mp+4g+r][h1 = 16m+ci], r = 0..3: one 16-byte read
+                    const int m = i >> 2, mp = i & 3;
+                    return ld4(W2L + (mp * 16 + 4 * m) * 64 + w2t_lane);
+                },
+                [&](int i, const f32x4& o) {
+                    const int m = i >> 2, mp = i & 3;
+                    if (mp == 0) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-#pragma unroll
-                for (int n = 0; n < NT; ++n) d1[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int mp = 0; mp < 4; ++mp)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float wa = W2L[(mp * 16 + 4 * m) * 64 + w2t_lane + r];  // W2[h2 = 16mp+4g+r][h1 = 16m+ci]
-#pragma unroll
-                        for (int n = 0; n < NT; ++n) d1[m][n] = nca_mfma(wa, d2[mp][n][r], d1[m][n]);
+                        for (int n = 0; n < NT; ++n) d1[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) d1[m][n][r] = h1[m][n][r] > 0.0f ? d1[m][n][r] : 0.0f;
-            }
+                        for (int n = 0; n < NT; ++n) d1[m][n] = nca_mfma(o[r], d2[mp][n][r], d1[m][n]);
+                    if (mp == 3) {
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) d1[m][n][r] = gate_pos(h1[m][n][r], d1[m][n][r]);
+                    }
+                });
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) { db1[m][r] += d1[m][n][r]; db2[m][r] += d2[m][n][r]; }
+            NCA_BPHASE(7);   // layer 2
             // ---- layer 1: dW1 = d1 (rows 0..63) x P (rows 64.., natural perception index j = 3c+f);  dp = W1^T d1 ---------
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -345,32 +470,42 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
 #pragma unroll
                     for (int f = 0; f < 3; ++f) TB[ci * TBS + 64 + 3 * (4 * c4 + g) + f] = P[n][3 * c4 + f];
                 wave_sync();
+                piped<4>(
+                    [&](int s_) {
+                        OpN<4 + K::MJ> o;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    float bv[K::MJ];
+                        for (int k = 0; k < 4; ++k) o.v[k] = tr_[4 * s_ * TBS + 16 * k];
 #pragma unroll
-                    for (int nb = 0; nb < K::MJ; ++nb) bv[nb] = tr_[4 * s * TBS + 64 + 16 * nb];
+                        for (int nb = 0; nb < K::MJ; ++nb) o.v[4 + nb] = tr_[4 * s_ * TBS + 64 + 16 * nb];
+                        return o;
+                    },
+                    [&](int, const OpN<4 + K::MJ>& o) {
 #pragma unroll
-                    for (int ma = 0; ma < 4; ++ma) {
-                        const float av = tr_[4 * s * TBS + 16 * ma];
+                        for (int ma = 0; ma < 4; ++ma)
 #pragma unroll
-                        for (int nb = 0; nb < K::MJ; ++nb) aW1[ma][nb] = nca_mfma(av, bv[nb], aW1[ma][nb]);
-                    }
-                }
+                            for (int nb = 0; nb < K::MJ; ++nb) aW1[ma][nb] = nca_mfma(o.v[ma], o.v[4 + nb], aW1[ma][nb]);
+                    });
             }
+            piped<4 * K::MJ>(
+                [&](int i) {
+                    const int mj = i >> 2, mp = i & 3;
+                    OpN<4> o;
 #pragma unroll
-            for (int mj = 0; mj < K::MJ; ++mj) {
+                    for (int r = 0; r < 4; ++r) o.v[r] = W1T[(mj * 16 + 4 * mp + r) * 64 + lane];
+                    return o;
+                },
+                [&](int i, const OpN<4>& o) {
+                    const int mj = i >> 2, mp = i & 3;
+                    if (mp == 0) {
 #pragma unroll
-                for (int n = 0; n < NT; ++n) dp[mj][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int mp = 0; mp < 4; ++mp)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float wa = W1T[(mj * 16 + 4 * mp + r) * 64 + lane];
-#pragma unroll
-                        for (int n = 0; n < NT; ++n) dp[mj][n] = nca_mfma(wa, d1[mp][n][r], dp[mj][n]);
+                        for (int n = 0; n < NT; ++n) dp[mj][n] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
-            }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) dp[mj][n] = nca_mfma(o.v[r], d1[mp][n][r], dp[mj][n]);
+                });
+            NCA_BPHASE(8);   // layer 1
             // ---- dL/dperception out: [j][2 rows][16] via TB, 16-byte stores -----------------------------------
             wave_sync();
 #pragma unroll
@@ -392,6 +527,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
                     if (ok && j < K1) st4(po + (unsigned)j * plane, v);
                 }
             }
+            NCA_BPHASE(9);   // dP out
         }
         // ---- dL/dx'_t out (XR), 16-byte stores ---------------------------------------------------------------
         wave_sync();
@@ -408,8 +544,21 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
         wave_sync();
     }
 
-    // ---- flush this wave's partial weight gradients into its slab (+=) -------------------------------------------
-    float* const slab = ba.slabs + (size_t)(blockIdx.x * kBwdWaves + wave) * slab_floats(C, hid);
+#if defined(NCA_STAMPS)
+    if (a.dbg && lane == 0) {
+        for (int i = 0; i < 12; ++i) a.dbg[(size_t)(blockIdx.x * kBwdWaves + wave) * 16 + i] = ph_acc[i];
+        unsigned long long r1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1)::"memory");
+        a.dbg[(size_t)(blockIdx.x * kBwdWaves + wave) * 16 + 12] = r1 - ph_real0;    // 100 MHz ticks
+        a.dbg[(size_t)(blockIdx.x * kBwdWaves + wave) * 16 + 13] = ph_last - ph_t0;  // shader-clock ticks over the same span
+    }
+#endif
+    // ---- weight-gradient partials: the four waves' accumulators are summed through LDS (tiles and weight images are dead
+    //      by now) and added to the WORKGROUP's slab with coalesced accesses; fixed summation order (deterministic).
+    const int sf = slab_floats(C, hid);
+    static_assert(kBwdWaves * (64 * 3 * CP + 64 * 64 + CP * 64 + 128) <= K::LDS_FLOATS, "slab staging fits the LDS carve");
+    __syncthreads();
+    float* const sw = smem + wave * sf;
 #pragma unroll
     for (int ma = 0; ma < 4; ++ma)
 #pragma unroll
@@ -418,10 +567,10 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             if (o < hid) {
 #pragma unroll
                 for (int nb = 0; nb < K::MJ; ++nb)
-                    if (16 * nb + ci < K1) slab[o * K1 + 16 * nb + ci] += aW1[ma][nb][r];
+                    if (16 * nb + ci < K1) sw[o * K1 + 16 * nb + ci] = aW1[ma][nb][r];
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
-                    if (16 * nb + ci < hid) slab[slab_off_w2(C, hid) + o * hid + 16 * nb + ci] += aW2[ma][nb][r];
+                    if (16 * nb + ci < hid) sw[slab_off_w2(C, hid) + o * hid + 16 * nb + ci] = aW2[ma][nb][r];
             }
         }
 #pragma unroll
@@ -430,7 +579,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
         if (ch < C) {
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
-                if (16 * nb + ci < hid) slab[slab_off_w3(C, hid) + ch * hid + 16 * nb + ci] += aW3[nb][r];
+                if (16 * nb + ci < hid) sw[slab_off_w3(C, hid) + ch * hid + 16 * nb + ci] = aW3[nb][r];
         }
     }
 #pragma unroll
@@ -442,10 +591,18 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             for (int d = 1; d < 16; d <<= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
             const int o = 16 * m + 4 * g + r;
             if (ci == 0 && o < hid) {
-                slab[slab_off_b1(C, hid) + o] += s1;
-                slab[slab_off_b2(C, hid) + o] += s2;
+                sw[slab_off_b1(C, hid) + o] = s1;
+                sw[slab_off_b2(C, hid) + o] = s2;
             }
         }
+    __syncthreads();
+    float* const slab = ba.slabs + (size_t)blockIdx.x * sf;
+    for (int i = tid; i < sf; i += kBwdThreads)
+        slab[i] += (smem[i] + smem[sf + i]) + (smem[2 * sf + i] + smem[3 * sf + i]);
+#if defined(NCA_STAMPS)
+    NCA_BPHASE(11);  // slab flush
+    if (a.dbg && lane == 0) a.dbg[(size_t)(blockIdx.x * kBwdWaves + wave) * 16 + 11] = ph_acc[11];
+#endif
 }
 
 // Kernel B: dL/ds_t = dL/dx'_t + stencil^T(dL/dP);  dL/dgoal += dz * pre_t;  perception-weight partials.
@@ -587,12 +744,16 @@ __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCon
 }
 
 // dst[j] = sum_i src[i*m + j] (fixed order -> deterministic)
+// dst[j] = sum_i src[i][j]: a block owns 64 columns, its four waves take every fourth row each (fixed order: deterministic)
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int m) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= m) return;
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6, j = blockIdx.x * 64 + c;
     float acc = 0.0f;
-    for (int i = 0; i < n; ++i) acc += src[(size_t)i * m + j];
-    dst[j] = acc;
+    if (j < m)
+        for (int i = rg; i < n; i += 4) acc += src[(size_t)i * m + j];
+    part[rg][c] = acc;
+    __syncthreads();
+    if (rg == 0 && j < m) dst[j] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
 // perception-weight partials [B*C*bpp][27] -> grad [C][27]
 __global__ __launch_bounds__(64) void reduce_wp_kernel(const float* __restrict__ part, float* __restrict__ dst, int B, int C, int bpp) {
@@ -618,8 +779,14 @@ hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
     }
     const NcaCondArgs& a = ba.f;
     const int nst = a.B * ((a.W + 15) / 16) * ((a.H + 15) / 16);
-    const int grid = nst < ba.nslab / kBwdWaves ? nst : ba.nslab / kBwdWaves;
+    const int grid = nst < ba.nslab ? nst : ba.nslab;   // one slab per workgroup
+#if defined(NCA_STAMPS)
+    NcaCondBwdArgs bd = ba;
+    bd.f.dbg = nca_debug_stamp_ptr();
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), lds, st, bd);
+#else
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), lds, st, ba);
+#endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(cond_step_bwd_stencil_kernel, dim3(ba.nblk), dim3(256), 0, st, ba);
@@ -634,7 +801,7 @@ int nca_cond_bwd_nslab() {
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
         cus = v;
-    return cus * kBwdWaves;
+    return cus;   // one persistent workgroup (and one slab) per CU
 }
 int nca_cond_bwd_nblk(int B, int C, int H, int W) { return B * C * ((((H + SROWS - 1) / SROWS) * (W / 4) + 255) / 256); }
 
@@ -646,7 +813,7 @@ hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
 }
 
 hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((m + 255) / 256), dim3(256), 0, st, src, dst, n, m);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((m + 63) / 64), dim3(256), 0, st, src, dst, n, m);
     return hipGetLastError();
 }
 hipError_t nca_launch_reduce_wp(const float* part, float* dst, int B, int C, int H, int W, hipStream_t st) {

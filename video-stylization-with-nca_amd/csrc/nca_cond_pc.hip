@@ -313,6 +313,9 @@ hipError_t launch_cond_pc(const NcaCondArgs& a, hipStream_t st) {
 extern "C" void nca_debug_set_stamp_buffer_pc(void* p);
 static unsigned long long* g_stamp_pc = nullptr;
 extern "C" void nca_debug_set_stamp_buffer_pc(void* p) { g_stamp_pc = (unsigned long long*)p; }
+#if defined(NCA_STAMPS)
+unsigned long long* nca_debug_stamp_ptr() { return g_stamp_pc; }
+#endif
 static int g_cond_precision = 0;
 void nca_set_cond_precision(int mode) { g_cond_precision = mode; }
 hipError_t nca_launch_cond_step_fwd_pc(const NcaCondArgs& a_in, hipStream_t st) {

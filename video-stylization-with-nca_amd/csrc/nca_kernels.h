@@ -47,7 +47,7 @@ struct NcaCondBwdArgs {
     float* dP;              // scratch: dL/d perception                         [B,3C,H,W]
     float* zbuf;            // scratch: z_t = s_t + goal*pre_t                  [B,C,H,W]
     float* dgoal;           // accumulated over steps                           [B,goal_ch,H,W]
-    float* slabs;           // per-wave weight-gradient partials, accumulated   [nslab, slab_floats]
+    float* slabs;           // per-workgroup weight-gradient partials, accumulated   [nslab, slab_floats]
     float* wp_partials;     // per-block perception-weight partials             [nblk, 27] accumulated
     int nslab, nblk;
 };
