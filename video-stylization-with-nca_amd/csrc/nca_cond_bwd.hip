@@ -186,6 +186,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
     }
 
     NCA_BPHASE(10);  // start-up: weight images, accumulators
+    float l2warm = 0.0f;   // landing register of the L2 warm-up reads (never consumed)
     // ---- tile walk: super-tiles of 16 x 16 (4 waves stacked vertically) ------------------------------------
     constexpr int BSTH = 16, BSTW = 16;
     const int st_x = (W + BSTW - 1) / BSTW, st_y = (H + BSTH - 1) / BSTH;
@@ -261,27 +262,64 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             wave_sync();
         }
 
+        // ---- warm the L2 for the NEXT tile: one 4-byte read per row segment it will load (state and goal rows with halo 1,
+        //      pending state and gradient rows), ~5 instructions.  There are no registers to hold the real loads a tile ahead
+        //      (one wave per SIMD, 256 + 200 in use), but these only need ONE landing register: they are issued here, return
+        //      during the pass loop, and the tile's real requests then meet the L2 instead of HBM.
+        if (tw.t + tw.stride < tw.end) {
+            const int tnx = tw.t + tw.stride, gch = a.goal_ch;
+            const int nb = tnx / (st_x * st_y), ny0 = ((tnx / st_x) % st_y) * BSTH + wave * WTH, nx0 = (tnx % st_x) * BSTW;
+            const float* const bx = a.x_in + (size_t)nb * C * plane;
+            const float* const bg = gch ? a.goal + (size_t)nb * gch * plane : bx;
+            const float* const bn = ba.x_next + (size_t)nb * C * plane;
+            const float* const bq = ba.g_next + (size_t)nb * C * plane;
+            const unsigned col = (unsigned)min(nx0, W - 1);
+            // state + goal planes: 8 rows each (ty0-1 ..; two more than needed keeps the index arithmetic to shifts)
+            for (int base = 0; base < 8 * (C + gch); base += 64) {
+                const int i = min(base + lane, 8 * (C + gch) - 1), pl = i >> 3;
+                const unsigned rowo = (unsigned)min(max(ny0 + (i & 7) - 1, 0), H - 1) * (unsigned)W + col;
+                const float* const p = (pl < C ? bx + (unsigned)pl * plane : bg + (unsigned)(pl - C) * plane) + rowo;
+                asm volatile("global_load_dword %0, %1, off" : "+v"(l2warm) : "v"(p) : "memory");
+            }
+            // pending state + incoming gradient: 4 rows each
+            for (int base = 0; base < 8 * C; base += 64) {
+                const int i = min(base + lane, 8 * C - 1), pl = i >> 2;
+                const unsigned rowo = (unsigned)min(ny0 + (i & 3), H - 1) * (unsigned)W + col;
+                const float* const p = (pl < C ? bn + (unsigned)pl * plane : bq + (unsigned)(pl - C) * plane) + rowo;
+                asm volatile("global_load_dword %0, %1, off" : "+v"(l2warm) : "v"(p) : "memory");
+            }
+        }
         NCA_BPHASE(2);   // x'/g loads, z out
         // ---- dL/dx'_t = G * 1[lo <= x'*life <= hi] * life (nca.py:191-194);  d out = . * fire mask.  All four
         //      rows now: TB (the staged incoming gradient) is reused for the transposes inside the pass loop.
         float dOall[WTH][4];
+        {
+            // reads of all four rows first, then the arithmetic and the XR write-back: with the write-back inside the row loop
+            // every row's reads waited behind the previous row's stores (possible aliases) -- four exposed LDS round trips
+            float lifev[WTH], mkv[WTH], xr[WTH][4], gr[WTH][4];
 #pragma unroll
-        for (int row = 0; row < WTH; ++row) {
-            float life = PN[(row + 1) * RS + ci + 4];
-            if (use_alive) life = (life != 0.0f && max3x3(A1 + (row + 1) * RS + ci + 4) > a.thr) ? 1.0f : 0.0f;
-            const float mk = MK[row * WTW + ci];
+            for (int row = 0; row < WTH; ++row) {
+                float life = PN[(row + 1) * RS + ci + 4];
+                if (use_alive) life = (life != 0.0f && max3x3(A1 + (row + 1) * RS + ci + 4) > a.thr) ? 1.0f : 0.0f;
+                lifev[row] = life;
+                mkv[row] = MK[row * WTW + ci];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ch = 4 * g + r;
-                float gxv = 0.0f;
-                if (ch < CP) {  // XR / TB hold CP channel planes
-                    float* const xp = XR + ch * XRS + row * WTW + ci;
-                    const float y = *xp * life;
-                    if (ch < C && y >= a.lo && y <= a.hi) gxv = TB[ch * XRS + row * WTW + ci] * life;
-                    *xp = gxv;  // XR now carries dL/dx'_t for the 16-byte store pass
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = 4 * g + r;
+                    xr[row][r] = ch < CP ? XR[ch * XRS + row * WTW + ci] : 0.0f;   // XR / TB hold CP channel planes
+                    gr[row][r] = ch < CP ? TB[ch * XRS + row * WTW + ci] : 0.0f;
                 }
-                dOall[row][r] = gxv * mk;
             }
+#pragma unroll
+            for (int row = 0; row < WTH; ++row)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = 4 * g + r;
+                    const float y = xr[row][r] * lifev[row];
+                    const float gxv = (ch < C && y >= a.lo && y <= a.hi) ? gr[row][r] * lifev[row] : 0.0f;
+                    if (ch < CP) XR[ch * XRS + row * WTW + ci] = gxv;  // XR now carries dL/dx'_t for the 16-byte store pass
+                    dOall[row][r] = gxv * mkv[row];
+                }
         }
         NCA_BPHASE(3);   // gate
 #pragma unroll 1
@@ -597,8 +635,19 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
         }
     __syncthreads();
     float* const slab = ba.slabs + (size_t)blockIdx.x * sf;
-    for (int i = tid; i < sf; i += kBwdThreads)
-        slab[i] += (smem[i] + smem[sf + i]) + (smem[2 * sf + i] + smem[3 * sf + i]);
+    constexpr int PER = (64 * 3 * CP + 64 * 64 + CP * 64 + 128 + kBwdThreads - 1) / kBwdThreads;
+    float cur[PER];   // all reads of the read-modify-write in flight at once (one round trip, not PER)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tid + kBwdThreads * k;
+        cur[k] = i < sf ? slab[i] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tid + kBwdThreads * k;
+        if (i < sf) slab[i] = cur[k] + ((smem[i] + smem[sf + i]) + (smem[2 * sf + i] + smem[3 * sf + i]));
+    }
+    asm volatile("" ::"v"(l2warm));   // the landing register stays reserved until every warm-up read has returned
 #if defined(NCA_STAMPS)
     NCA_BPHASE(11);  // slab flush
     if (a.dbg && lane == 0) a.dbg[(size_t)(blockIdx.x * kBwdWaves + wave) * 16 + 11] = ph_acc[11];
