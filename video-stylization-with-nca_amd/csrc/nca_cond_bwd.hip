@@ -659,7 +659,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
 // three-row sliding window held in registers: every row of z / dL/dP is loaded once per thread (16-byte loads,
 // left/right neighbours by wavefront shuffle with a scalar fallback at row/wave edges), and the 27 perception-weight
 // sums are reduced across the block once per strip.  A block never spans two channels.
-constexpr int SROWS = 8;
+constexpr int SROWS = 16;
 struct Row6 { float v[6]; };   // columns x0-1 .. x0+4
 
 // Two-stage row fetch: issue (raw 16-byte group + the two edge cells that have no neighbour lane) and finish (shuffle the
@@ -729,12 +729,30 @@ __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCon
         pw[f][1] = load_row6(p0 + (size_t)f * plane, H, W, y0, x0, has_l, has_r);
         pw[f][2] = load_row6(p0 + (size_t)f * plane, H, W, y0 + 1, x0, has_l, has_r);
     }
+    // the row's own read-modify-write operands (dL/dx', dL/dgoal, pre mask) are requested one row ahead as well
+    const bool goal_ch = c >= gch0, use_pre = goal_ch && a.alive_ch >= 0;
+    const float* const gxp = ba.gx + ((size_t)b * C + c) * plane + x0;
+    float* const gop = ba.g_out + ((size_t)b * C + c) * plane + x0;
+    float* const dgp = goal_ch ? ba.dgoal + ((size_t)b * a.goal_ch + (c - gch0)) * plane + x0 : nullptr;
+    const uint8_t* const prp = use_pre ? ba.pre_t + (size_t)b * plane + x0 : nullptr;
+    float4 gxn = make_float4(0.f, 0.f, 0.f, 0.f), dgn = gxn;
+    uchar4 pbn = make_uchar4(1, 1, 1, 1);
+    auto issue_rmw = [&](int y) {
+        const size_t ro = (size_t)min(y, H - 1) * W;
+        gxn = *reinterpret_cast<const float4*>(gxp + ro);
+        if (goal_ch) dgn = *reinterpret_cast<const float4*>(dgp + ro);
+        if (use_pre) pbn = *reinterpret_cast<const uchar4*>(prp + ro);
+    };
+    issue_rmw(y0);
 #pragma unroll 1
     for (int k = 0; k < SROWS; ++k) {
         const int y = y0 + k;
         zn = issue_row6(zb, H, W, y + 2, x0, has_l, has_r);
 #pragma unroll
         for (int f = 0; f < 3; ++f) pn[f] = issue_row6(p0 + (size_t)f * plane, H, W, y + 2, x0, has_l, has_r);
+        const float4 gx = gxn, dgc = dgn;
+        const uchar4 pb = pbn;
+        issue_rmw(y + 1);
         if (active && y < H) {
             // dz[x] = sum_f sum_{ty,tx} Wp[f][ty][tx] * dP[f][y-(ty-1)][x-(tx-1)]      (transpose of the zero-padded correlation)
             float dz[4] = {0.f, 0.f, 0.f, 0.f};
@@ -757,20 +775,12 @@ __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCon
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             wsum[9 * f + 3 * ty + tx] = fmaf(pw[f][1].v[j + 1], zw[ty].v[j + tx], wsum[9 * f + 3 * ty + tx]);
-            const size_t off = (size_t)y * W + x0;
-            const float4 gx = *reinterpret_cast<const float4*>(ba.gx + ((size_t)b * C + c) * plane + off);
-            *reinterpret_cast<float4*>(ba.g_out + ((size_t)b * C + c) * plane + off) =
-                make_float4(gx.x + dz[0], gx.y + dz[1], gx.z + dz[2], gx.w + dz[3]);
-            if (c >= gch0) {
-                float pre[4] = {1.f, 1.f, 1.f, 1.f};
-                if (a.alive_ch >= 0) {
-                    const uchar4 pb = *reinterpret_cast<const uchar4*>(ba.pre_t + (size_t)b * plane + off);
-                    pre[0] = pb.x; pre[1] = pb.y; pre[2] = pb.z; pre[3] = pb.w;
-                }
-                float4* const dg = reinterpret_cast<float4*>(ba.dgoal + ((size_t)b * a.goal_ch + (c - gch0)) * plane + off);
-                float4 o = *dg;
-                o.x += dz[0] * pre[0]; o.y += dz[1] * pre[1]; o.z += dz[2] * pre[2]; o.w += dz[3] * pre[3];
-                *dg = o;
+            const size_t ro = (size_t)y * W;
+            *reinterpret_cast<float4*>(gop + ro) = make_float4(gx.x + dz[0], gx.y + dz[1], gx.z + dz[2], gx.w + dz[3]);
+            if (goal_ch) {
+                float4 o = dgc;
+                o.x += dz[0] * (float)pb.x; o.y += dz[1] * (float)pb.y; o.z += dz[2] * (float)pb.z; o.w += dz[3] * (float)pb.w;
+                *reinterpret_cast<float4*>(dgp + ro) = o;
             }
         }
         zw[0] = zw[1]; zw[1] = zw[2]; zw[2] = finish_row6(zn, has_l, has_r);
