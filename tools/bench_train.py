@@ -30,6 +30,7 @@ def run(B, T, H=256, W=256, C=16, iters=3, warm=2):
         g = ops.cond_grow_backward(states, pre, goal, None, w, cot, T, 3, seed=1, step0=0); e[2].record()
         torch.cuda.synchronize()
         tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
+        del out, states, pre, g     # as a trainer does after optimizer.step(): the next forward reuses the cached ring
     tf /= iters; tb /= iters
     cells = B * H * W * T
     print(json.dumps({"B": B, "T": T, "fwd_ms": tf, "bwd_ms": tb, "fwd_us_per_step": tf / T * 1e3, "bwd_us_per_step": tb / T * 1e3,

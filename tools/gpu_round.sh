@@ -24,3 +24,22 @@ with open("$out/${tag}_kernel_stats.txt", "w") as o:
         line = "%-120s calls %6s avg_ns %12s pct %6s" % (r["Name"][:120], r["Calls"], r["AverageNs"], r["Percentage"])
         print(line); o.write(line + "\n")
 PY
+# training-shaped pass (forward with history + backward), bf16 / bf16x3 forward, backward phase accounting
+timeout -k 10 200 python tools/bench_train.py > $out/${tag}_train.json 2> $out/${tag}_train.err || { tail -20 $out/${tag}_train.err; exit 1; }
+timeout -k 10 200 python tools/bench_train.py cfg3 >> $out/${tag}_train.json 2>> $out/${tag}_train.err || { tail -20 $out/${tag}_train.err; exit 1; }
+timeout -k 10 200 python tools/bench_bf16.py > $out/${tag}_bf16.json 2> $out/${tag}_bf16.err || { tail -20 $out/${tag}_bf16.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/${tag}_trainprof -o stats --output-format csv -- python tools/bench_train.py > $out/${tag}_trainprof.log 2>&1 || { tail -20 $out/${tag}_trainprof.log; exit 1; }
+python - <<PY
+import csv, glob
+f = glob.glob("$out/${tag}_trainprof/**/*kernel_stats.csv", recursive=True)
+rows = list(csv.DictReader(open(f[0])))
+with open("$out/${tag}_train_kernel_stats.txt", "w") as o:
+    for r in rows[:10]:
+        line = "%-120s calls %6s avg_ns %12s pct %6s" % (r["Name"][:120], r["Calls"], r["AverageNs"], r["Percentage"])
+        print(line); o.write(line + "\n")
+PY
+if [ -f video-stylization-with-nca_amd/libncahip_stamps.so ]; then
+  timeout -k 10 200 python tools/stamp_bwd.py > $out/${tag}_bwd_phases.txt 2>&1 || { tail -20 $out/${tag}_bwd_phases.txt; exit 1; }
+  cat $out/${tag}_bwd_phases.txt
+fi
+cat $out/${tag}_train.json $out/${tag}_bf16.json
