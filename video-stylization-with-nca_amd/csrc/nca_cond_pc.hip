@@ -6,7 +6,7 @@
 // pipe idle half the time even with a second such wave on the SIMD.  Here each SIMD hosts ONE consumer wave
 // (perception -> MFMA chain -> 16-byte stores; nothing else) and ONE producer wave (global loads, pending
 // life-mask resolution, z tile, resolved-state copy, fire mask) that works one tile ahead through a
-// double-buffered LDS tile.  One workgroup barrier per tile hands the buffers over.
+// double-buffered LDS tile; the two hand tiles over through round counters in LDS (no workgroup barrier in the loop).
 //   workgroup = 8 waves = 4 pairs; pair p owns the 4x16 tiles at rows 4p..4p+3 of each 16x16 super-tile.
 #include "nca_cond_tile.h"
 
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
                        B + PK::BUF_MK};
     };
 
-    // every pair walks the SAME super-tile sequence (uniform trip count: the barrier below is workgroup-wide)
+    // every pair walks the same super-tile sequence
     constexpr int PSTH = 16, PSTW = 16;
     const int st_x = (W + PSTW - 1) / PSTW, st_y = (H + PSTH - 1) / PSTH;
     const int halo = a.alive_ch >= 0 ? 3 : 1;
