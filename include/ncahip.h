@@ -42,8 +42,10 @@ typedef void *ncahip_stream_t;   /* hipStream_t */
 int ncahip_version(void);
 const char *ncahip_last_error(void);
 
-/* Largest shapes the fused step kernels accept (C <= max_c, fc <= max_fc, hidden <= 64).  The DyNCA *forward* entry
- * points additionally take 16 < C <= 32 (BASELINE configs[4]); the backward kernels cover C <= max_c.                */
+/* Largest shapes the fused step kernels accept (C <= max_c, fc <= max_fc, hidden <= 64).  The fp32 DyNCA *forward* entry
+ * points additionally take 16 < C <= 32 (BASELINE configs[4]) and fc up to 1024 (one launch per 128-wide slice of the
+ * hidden layer, the later ones accumulating into x_out); the bf16-storage and backward kernels cover fc <= max_fc, the
+ * backward kernels C <= max_c.                                                                                          */
 int ncahip_limits(int *max_c, int *max_fc, int *max_hidden);
 
 /* Arithmetic of the UpdateNet products in ncahip_cond_step_fwd_f32 / ncahip_cond_grow_fwd_f32 (process-wide; C in {12,16},

@@ -78,6 +78,15 @@ def test_argument_validation_without_gpu():
     rc = L.ncahip_dynca_step_bwd_f32(one, None, None, one, one, one, one, 1, 32, 8, 8, 96, 0, 1, 0.5, 0, 0,
                                      one, two, one, one, one, None)
     assert rc == -2 and b"backward" in L.ncahip_last_error()
+    # wide hidden layers (fc > 128) are an fp32-forward feature (one launch per 128-wide slice): bf16 storage and the
+    # backward refuse them, and so does the forward beyond 1024
+    rc = L.ncahip_dynca_step_fwd_bf16(one, two, None, None, one, one, one, one, 1, 16, 8, 8, 256, 0, 1, 0.5, 0, 0, None)
+    assert rc == -2 and b"exceeds" in L.ncahip_last_error()
+    rc = L.ncahip_dynca_step_fwd_f32(one, two, None, None, one, one, one, one, 1, 16, 8, 8, 2048, 0, 1, 0.5, 0, 0, None)
+    assert rc == -2 and b"exceeds" in L.ncahip_last_error()
+    rc = L.ncahip_dynca_step_bwd_f32(one, None, None, one, one, one, one, 1, 16, 8, 8, 256, 0, 1, 0.5, 0, 0,
+                                     one, two, one, one, one, None)
+    assert rc == -2
     # precision switch: only 0 (exact) and 1 (bf16x3)
     assert L.ncahip_cond_precision(0) == 0 and L.ncahip_cond_precision(5) == -1
 

@@ -460,6 +460,32 @@ def test_dynca_c32_forward(ops):
     assert float(((gotb.float().cpu() - refb).abs() / refb.abs().clamp_min(1.0)).max()) <= 2.0 ** -7
 
 
+@pytest.mark.parametrize("C,fc,cc", [(32, 256, 3), (16, 192, 0), (12, 320, 2)])
+def test_dynca_wide_hidden_forward(ops, C, fc, cc):
+    """fc > 128 (SURVEY 8d's cfg5 shape: C = 32, fc = 8C = 256, 3 conditioning channels): one launch per 128-wide slice of
+    the hidden layer, the later ones accumulating into x_out -- against the oracle's single sum (dynca.py:117-138), with
+    explicit uniforms and with the in-kernel Philox mask (every slice must draw the same mask)."""
+    from oracle import nca_oracle as O
+    B, H, W = 2, 20, 36
+    g = torch.Generator().manual_seed(fc + C)
+    k1 = 4 * C + cc
+    prm = {"w1.weight": torch.randn(fc, k1, 1, 1, generator=g) * (0.5 / k1 ** 0.5), "w1.bias": torch.randn(fc, generator=g) * 0.1,
+           "w2.weight": torch.randn(C, fc, 1, 1, generator=g) * (0.3 / fc ** 0.5), "w2.bias": torch.randn(C, generator=g) * 0.02}
+    x = torch.rand(B, C, H, W, generator=g) - 0.5
+    cond = torch.rand(B, cc, H, W, generator=g) * 2 - 1 if cc else None
+    us = [torch.rand(B, 1, H, W, generator=g) for _ in range(3)]
+    w = ops.DyncaWeights(prm["w1.weight"], prm["w1.bias"], prm["w2.weight"], prm["w2.bias"], x.to(DEV))
+    cd = None if cond is None else cond.to(DEV)
+    for pad in ("circular", "reflect"):
+        ref = O.dynca_nsteps(x, cond, us, prm, pad, 0.5)
+        got, _ = ops.dynca_nsteps(x.to(DEV), 3, cd, torch.stack(us).to(DEV), w, pad, 0.5)
+        assert rel_err(got.cpu(), ref) < REL_TOL
+    u = ops.philox_uniform(B, H, W, 11, 5, DEV)
+    ref1 = O.dynca_step(x, cond, u.cpu(), prm, "replicate", 0.5)
+    got1, _ = ops.dynca_nsteps(x.to(DEV), 1, cd, None, w, "replicate", 0.5, seed=11, step0=5)
+    assert rel_err(got1.cpu(), ref1) < REL_TOL
+
+
 def test_cond_step_shape_fuzz(ops):
     """Seeded random shapes / channel counts / goal widths / alive settings / fire rates, pending inputs included: one
     teacher-forced step each against the oracle (nca.py:181-195).  Covers tiles that straddle every image edge and the

@@ -66,3 +66,5 @@ def run_dynca(B=8, C=16, fc=128, cc=3, H=256, W=256, T=32, pad="circular"):
 
 run_dynca()
 run_dynca(C=12, fc=96)
+run_dynca(B=2, C=32, fc=256, H=512, W=512, T=8)   # SURVEY 8d's cfg5 shape: two launches per step (fc slices of 128)
+run_dynca(B=2, C=32, fc=128, H=512, W=512, T=8)

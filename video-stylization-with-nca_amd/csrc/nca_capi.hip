@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int kMaxC = 16, kMaxCDynca = 32, kMaxFc = 128, kMaxHidden = 64, kMaxCond = 4;   // DyNCA forward: C <= 32 (configs[4])
+constexpr int kMaxC = 16, kMaxCDynca = 32, kMaxFc = 128, kMaxFcFwd = 1024, kMaxHidden = 64, kMaxCond = 4;   // DyNCA forward: C <= 32 (configs[4]), fc in 128-wide slices
 
 thread_local char g_err[512] = "";
 
@@ -32,14 +32,14 @@ bool dims_ok(int B, int C, int H, int W) {
 }
 
 int check_dynca(const void* x_in, const void* x_out, const void* cond, const void* w1, const void* b1, const void* w2,
-                const void* b2, int B, int C, int H, int W, int fc, int c_cond, int pad_mode) {
+                const void* b2, int B, int C, int H, int W, int fc, int c_cond, int pad_mode, int max_fc = kMaxFc) {
     if (!x_in || !x_out || !w1 || !b1 || !w2 || !b2) return fail(NCAHIP_EINVAL, "dynca step: null pointer");
     if (!dims_ok(B, C, H, W) || fc <= 0 || c_cond < 0) return fail(NCAHIP_EINVAL, "dynca step: bad size");
     if ((c_cond > 0) != (cond != nullptr)) return fail(NCAHIP_EINVAL, "dynca step: cond pointer / c_cond mismatch");
     if (pad_mode < 0 || pad_mode > 3) return fail(NCAHIP_EINVAL, "dynca step: bad pad_mode %d", pad_mode);
     if (pad_mode == NCAHIP_PAD_REFLECT && (H < 2 || W < 2)) return fail(NCAHIP_EINVAL, "reflect pad needs H,W >= 2");
-    if (C > kMaxCDynca || fc > kMaxFc || c_cond > kMaxCond)
-        return fail(NCAHIP_ERANGE, "dynca step: C=%d fc=%d c_cond=%d exceeds (%d,%d,%d)", C, fc, c_cond, kMaxCDynca, kMaxFc,
+    if (C > kMaxCDynca || fc > max_fc || c_cond > kMaxCond)
+        return fail(NCAHIP_ERANGE, "dynca step: C=%d fc=%d c_cond=%d exceeds (%d,%d,%d)", C, fc, c_cond, kMaxCDynca, max_fc,
                     kMaxCond);
     if (x_in == x_out) return fail(NCAHIP_EINVAL, "dynca step: x_in and x_out must not alias (halo reads)");
     return 0;
@@ -118,7 +118,7 @@ int ncahip_dynca_step_fwd_f32(const float* x_in, float* x_out, const float* cond
                               const float* b1, const float* w2, const float* b2, int B, int C, int H, int W, int fc,
                               int c_cond, int pad_mode, float update_rate, uint64_t seed, uint64_t step,
                               ncahip_stream_t stream) {
-    if (int rc = check_dynca(x_in, x_out, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
+    if (int rc = check_dynca(x_in, x_out, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, kMaxFcFwd)) return rc;
     NcaDyncaArgs a{x_in, x_out, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step};
     return hip_result(nca_launch_dynca_step_fwd(a, (hipStream_t)stream), "dynca_step_fwd");
 }
@@ -128,7 +128,7 @@ int ncahip_dynca_nsteps_fwd_f32(float* states, int ring, int T, const float* con
                                 int c_cond, int pad_mode, float update_rate, uint64_t seed, uint64_t step0,
                                 ncahip_stream_t stream) {
     if (ring < 2 || T < 0) return fail(NCAHIP_EINVAL, "dynca nsteps: ring >= 2 and T >= 0 required");
-    if (int rc = check_dynca(states, states + 1, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
+    if (int rc = check_dynca(states, states + 1, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, kMaxFcFwd)) return rc;
     const size_t slot = (size_t)B * C * H * W, uslot = (size_t)B * H * W;
     for (int t = 0; t < T; ++t) {
         NcaDyncaArgs a{states + (size_t)(t % ring) * slot, states + (size_t)((t + 1) % ring) * slot, cond,

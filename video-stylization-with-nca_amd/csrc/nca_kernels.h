@@ -19,6 +19,8 @@ struct NcaDyncaArgs {
     float* dhbuf;          // dL/d(pre-activation)           [B,fc,H,W]
     float* dybuf;          // dL/dy, first 4C rows           [B,4C,H,W]
     float* g_out;          // dL/dx_t                        [B,C,H,W]
+    // fc > 128 runs as several launches over 128-wide slices of the hidden layer (nca_launch_dynca_step_fwd):
+    int w2_ld;             // row stride of w2 (0: = fc); later slices run the accumulating instantiation (x_out += mask * slice)
 };
 
 struct NcaCondArgs {

@@ -203,9 +203,10 @@ struct DyncaCfg {
 // hidden layer, then dh = (W2^T (G*mask)) * 1[h>0] and dL/dy = W1^T dh on MFMA (accumulator tile == next B
 // operand, as in the forward); writes relu(h), dh and dL/dy[:4C].  The two weight-gradient GEMMs
 // (dW2 = (G*mask) h^T, dW1 = dh y^T, K = all cells) are plain library GEMMs on those buffers.
-template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT, bool VEC, bool BWD = false, bool B16 = false>
+template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT, bool VEC, bool BWD = false, bool B16 = false, bool ACC = false>
 __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(const NcaDyncaArgs a) {
     static_assert(!(BWD && B16), "the bf16-storage step is forward only");
+    static_assert(!ACC || (!BWD && !B16), "accumulating passes (fc slices beyond the first) exist for the fp32 forward only");
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
     using Pos = TilePos<TH, TW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -236,10 +237,10 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
         const int l = idx & 63, s = (idx >> 6) % K::K2S, m = (idx >> 6) / K::K2S;
         const int gg = l >> 4, o = 16 * m + (l & 15);
         const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
-        return (o < C && k < fc) ? (long)o * fc + k : -1;
+        return (o < C && k < fc) ? (long)o * (a.w2_ld ? a.w2_ld : fc) + k : -1;
     });
     fill_image<FC>(B1L, a.b1, tid, [&](int idx) -> long { return idx < fc ? idx : -1; });
-    fill_image<K::M2T * 16>(B2L, a.b2, tid, [&](int idx) -> long { return idx < C ? idx : -1; });
+    fill_image<K::M2T * 16>(B2L, a.b2, tid, [&](int idx) -> long { return (idx < C && !ACC) ? idx : -1; });
     const float* const W2T = smem + K::OFF_W2T;
     const float* const W1T = smem + K::OFF_W1T;
     if (BWD) {
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                     if (gy < H && gx < W) {
                         const float mk = MK[r0[n] * TW + q0[n]];
                         const size_t o0 = (size_t)b * C * plane + (size_t)gy * W + gx;
-                        float* const ob = a.x_out + o0;
+                        const float* const ob = a.x_out + o0;
                         (void)ob;
                         const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.x_out + (size_t)b * C * plane, 0, -1, 0x00020000);
                         const unsigned ooff = (unsigned)(gy * W + gx) * 4u;
@@ -495,7 +496,8 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                             for (int r = 0; r < 4; ++r) {
                                 const int ch = 16 * m2 + 4 * g + r;
                                 if (ch < C) {
-                                    const float xo = Z[ch * K::CS + (r0[n] + 1) * K::RS + q0[n] + 4];
+                                    float xo = Z[ch * K::CS + (r0[n] + 1) * K::RS + q0[n] + 4];
+                                    if constexpr (ACC) xo = ob[(size_t)ch * plane];   // later fc slice: add to the partial result
                                     const float xn = xo + acc2[m2][n][r] * mk;
                                     if constexpr (B16) ob16[ch * plane] = nca_f32_to_b16(xn);
                                     else   // write-through (sc1): no dirty lines left for the end-of-kernel L2 write-back
@@ -885,11 +887,11 @@ int grid_for(int ntiles, int wg_per_cu) {
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
-template <int CP, int FC, bool HAS_COND, bool VEC, bool B16 = false>
+template <int CP, int FC, bool HAS_COND, bool VEC, bool B16 = false, bool ACC = false>
 hipError_t launch_dynca_v(const NcaDyncaArgs& a, hipStream_t st) {
     constexpr int TH = 8, TW = 32, NT = CP > 16 ? 2 : 4;   // C = 32: 33 perception values per cell row -> two rows per pass
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
-    auto kern = dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, VEC, false, B16>;
+    auto kern = dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, VEC, false, B16, ACC>;
     const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
     static thread_local bool attr_done = false;
     if (!attr_done) {
@@ -903,10 +905,10 @@ hipError_t launch_dynca_v(const NcaDyncaArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <int CP, int FC, bool HAS_COND>
+template <int CP, int FC, bool HAS_COND, bool ACC = false>
 hipError_t launch_dynca(const NcaDyncaArgs& a, hipStream_t st) {
     const bool vec = (a.W % 4 == 0) && aligned16(a.x_in) && (((size_t)a.H * a.W) % 4 == 0);
-    return vec ? launch_dynca_v<CP, FC, HAS_COND, true>(a, st) : launch_dynca_v<CP, FC, HAS_COND, false>(a, st);
+    return vec ? launch_dynca_v<CP, FC, HAS_COND, true, false, ACC>(a, st) : launch_dynca_v<CP, FC, HAS_COND, false, false, ACC>(a, st);
 }
 
 template <int CP, int FC, bool HAS_COND>
@@ -1018,6 +1020,28 @@ hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st) {
     if (a.C <= 12 && a.fc <= 96) return hc ? launch_dynca<12, 96, true>(a, st) : launch_dynca<12, 96, false>(a, st);
     if (a.C <= 16 && a.fc <= 128) return hc ? launch_dynca<16, 128, true>(a, st) : launch_dynca<16, 128, false>(a, st);
     if (a.C <= 32 && a.fc <= 128) return hc ? launch_dynca<32, 128, true>(a, st) : launch_dynca<32, 128, false>(a, st);   // configs[4]
+    if (a.C <= 32) {
+        // fc > 128: the A-operand image of w1 no longer fits the LDS beside the tile.  w2 relu(w1 y + b1) is a sum over hidden
+        // units, so the step runs as one launch per 128-wide slice: the first writes x + mask*(slice + b2), the others add
+        // their slice to x_out (same mask: same explicit uniforms / Philox key).  Each launch recomputes the perception.
+        const int K1 = 4 * a.C + a.c_cond;
+        const bool c16 = a.C <= 16;
+        for (int h0 = 0; h0 < a.fc; h0 += 128) {
+            NcaDyncaArgs s = a;
+            s.w1 = a.w1 + (size_t)h0 * K1;
+            s.b1 = a.b1 + h0;
+            s.w2 = a.w2 + h0;
+            s.fc = a.fc - h0 < 128 ? a.fc - h0 : 128;
+            s.w2_ld = a.fc;
+            hipError_t e;
+            if (h0 == 0) e = c16 ? (hc ? launch_dynca<16, 128, true>(s, st) : launch_dynca<16, 128, false>(s, st))
+                                 : (hc ? launch_dynca<32, 128, true>(s, st) : launch_dynca<32, 128, false>(s, st));
+            else e = c16 ? (hc ? launch_dynca<16, 128, true, true>(s, st) : launch_dynca<16, 128, false, true>(s, st))
+                         : (hc ? launch_dynca<32, 128, true, true>(s, st) : launch_dynca<32, 128, false, true>(s, st));
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
     return hipErrorInvalidValue;
 }
 

@@ -119,11 +119,12 @@ class DyNCA(nn.Module):
 
     def _composed(self, x) -> bool:
         """True when the step runs as HIP stencil + library GEMMs instead of the fused kernels: multi-scale perception, or
-        a differentiable pass at 16 < C <= 32 (the fused backward kernels cover C <= 16; BASELINE configs[4] trains at C = 32)."""
+        a differentiable pass at 16 < C <= 32 or fc > 128 (the fused backward kernels cover C <= 16, fc <= 128; BASELINE
+        configs[4] trains at C = 32).  The forward alone stays fused: fc > 128 runs as one launch per 128-wide slice."""
         if self._multiscale():
             return True
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        return self.c_in > 16 and needs_grad
+        return (self.c_in > 16 or self.w1.out_channels > 128) and needs_grad
 
     # ------------------------------------------------------------------ reference surface
     def perceive_torch(self, x, scale=0):
