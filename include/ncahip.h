@@ -119,6 +119,18 @@ int ncahip_dynca_step_bwd_f32(const float *x_t, const float *cond, const float *
                               const float *g_next, float *g_x, float *h_out, float *dh_out,
                               float *dy_scratch, ncahip_stream_t stream);
 
+/* Weight-gradient products of the DyNCA backward with the cell axis as K (replaces the library GEMMs over transposed
+ * copies that autograd through dynca.py:127-128 amounts to):
+ *     out[i*nb + j] = sum over all B*HW cells of a[., i, .] * b[., j, .]     i < ma, j < nb = nb1 + nb2
+ *     out[ma*nb + i] = sum over all cells of a[., i, .]                       (the bias gradient of the same layer)
+ * a [B, ma, HW]; the b rows come from two tensors, b1 [B, nb1, HW] then b2 [B, nb2, HW] (b2 may be NULL with nb2 = 0):
+ * dW1 | db1 = gram(dh_out, perception, cond), dW2 | db2 = gram(g_next * mask, h_out).  Exact fp32 MFMA, per-workgroup
+ * partials summed in a fixed order (deterministic).  Shapes: ma <= 128 with nb <= 80, or ma <= 32 with nb <= 128
+ * (NCAHIP_ERANGE otherwise).  out holds ma*nb + ma floats and is overwritten.                                          */
+size_t ncahip_gram_rows_workspace(int ma, int nb, int B, int HW);
+int ncahip_gram_rows_f32(const float *a, int ma, const float *b1, int nb1, const float *b2, int nb2, int B, int HW,
+                         float *out, void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * ConditionedNCA fused step                 EncoderConditioning/nca.py:181-195
  *

@@ -486,6 +486,26 @@ def test_dynca_wide_hidden_forward(ops, C, fc, cc):
     assert rel_err(got1.cpu(), ref1) < REL_TOL
 
 
+@pytest.mark.parametrize("ma,nb1,nb2,B,H,W", [(128, 64, 3, 2, 16, 24), (96, 48, 3, 3, 9, 13), (16, 128, 0, 2, 16, 24),
+                                               (12, 96, 0, 1, 7, 5), (64, 80, 0, 1, 64, 64), (32, 100, 0, 2, 10, 10)])
+def test_gram_rows(ops, ma, nb1, nb2, B, H, W):
+    """ncahip_gram_rows_f32 (the DyNCA weight-gradient products, cell axis as K) against a float64 contraction: row counts
+    that do not fill the 16-row tiles, cell counts that do not fill the 64-cell chunks, the two-tensor B operand."""
+    g = torch.Generator().manual_seed(ma + nb1)
+    a = torch.randn(B, ma, H, W, generator=g)
+    b1 = torch.randn(B, nb1, H, W, generator=g)
+    b2 = torch.randn(B, nb2, H, W, generator=g) if nb2 else None
+    bb = b1 if b2 is None else torch.cat([b1, b2], dim=1)
+    ref = torch.einsum("bihw,bjhw->ij", a.double(), bb.double())
+    prod, rsum = ops.gram_rows(a.to(DEV), b1.to(DEV), None if b2 is None else b2.to(DEV))
+    scale = float(ref.abs().max())
+    assert float((prod.cpu().double() - ref).abs().max()) <= 1e-5 * scale
+    rs_ref = a.double().sum(dim=(0, 2, 3))
+    assert float((rsum.cpu().double() - rs_ref).abs().max()) <= 1e-5 * max(1.0, float(rs_ref.abs().max()))
+    prod2, _ = ops.gram_rows(a.to(DEV), b1.to(DEV), None if b2 is None else b2.to(DEV))
+    assert torch.equal(prod, prod2)                      # fixed summation order
+
+
 def test_cond_step_shape_fuzz(ops):
     """Seeded random shapes / channel counts / goal widths / alive settings / fire rates, pending inputs included: one
     teacher-forced step each against the oracle (nca.py:181-195).  Covers tiles that straddle every image edge and the

@@ -293,6 +293,24 @@ int ncahip_dynca_step_bwd_f32(const float* x_t, const float* cond, const float* 
     return hip_result(nca_launch_dynca_step_bwd(a, (hipStream_t)stream), "dynca_step_bwd");
 }
 
+// ---- weight-gradient products of the DyNCA backward (cell axis as K) -------------------------------------------------
+size_t ncahip_gram_rows_workspace(int ma, int nb, int B, int HW) {
+    if (ma <= 0 || nb <= 0 || B <= 0 || HW <= 0) return 0;
+    return (size_t)nca_gram_grid(B, HW) * ((size_t)ma * nb + ma) * sizeof(float);
+}
+
+int ncahip_gram_rows_f32(const float* a, int ma, const float* b1, int nb1, const float* b2, int nb2, int B, int HW,
+                         float* out, void* workspace, size_t workspace_bytes, ncahip_stream_t stream) {
+    if (!a || !b1 || !out || !workspace || (nb2 > 0) != (b2 != nullptr)) return fail(NCAHIP_EINVAL, "gram_rows: null pointer");
+    if (ma <= 0 || nb1 <= 0 || nb2 < 0 || B <= 0 || HW <= 0) return fail(NCAHIP_EINVAL, "gram_rows: bad size");
+    const int nb = nb1 + nb2;
+    if (!((ma <= 32 && nb <= 128) || (ma <= 128 && nb <= 80)))
+        return fail(NCAHIP_ERANGE, "gram_rows: ma=%d nb=%d outside (<=32 x <=128) / (<=128 x <=80)", ma, nb);
+    if (workspace_bytes < ncahip_gram_rows_workspace(ma, nb, B, HW)) return fail(NCAHIP_EINVAL, "gram_rows: workspace too small");
+    return hip_result(nca_launch_gram_rows(a, ma, b1, nb1, b2, nb2, B, HW, out, (float*)workspace, (hipStream_t)stream),
+                      "gram_rows");
+}
+
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 size_t ncahip_cond_grow_bwd_workspace(int B, int C, int H, int W, int hidden) {

@@ -1,0 +1,140 @@
+// nca_gram.hip -- weight-gradient products of the DyNCA backward with the CELL axis as K (gfx950, exact fp32 MFMA).
+//
+// One backward step of DyNCA (autograd through ConditioneDyNCA/models/dynca.py:117-138) needs
+//     dW1 = dh y^T   [fc, 4C+c_cond]      db1 = sum_cells dh          (dh, y: per-cell columns, K = B*H*W cells)
+//     dW2 = dO h^T   [C, fc]              db2 = sum_cells dO
+// i.e. products out[i][j] = sum_n A[i][n] * B[j][n] of two row sets stored channel-major ([B, rows, H*W], exactly as the
+// step kernels write them).  Library GEMMs see an M x N of ~128 x 67 with K = 524 288 and need transposed copies; here the
+// operands stream through LDS once, coalesced along the cell axis, and every wave keeps its share of the out tiles in
+// accumulator registers for the whole launch (per-workgroup partials, summed in fixed order afterwards: deterministic).
+// The B rows may come from two tensors (the perception [B,4C,HW] and the conditioning map [B,c_cond,HW]): no concatenation.
+#include "nca_common.h"
+#include "nca_kernels.h"
+
+namespace {
+
+constexpr int kGramThreads = 256, kGramChunk = 64, kGramLS = 68;   // 64 cells per chunk; LDS row stride 68 (68 % 32 == 4)
+
+struct GramArgs {
+    const float* a;    // [B, ma, HW]
+    const float* b1;   // [B, nb1, HW]
+    const float* b2;   // [B, nb2, HW] or null
+    float* ws;         // [grid, ma*nb + ma]
+    int ma, nb1, nb2, B, HW;
+};
+
+// ROWSPLIT: wave w owns out row tiles [w*RT, (w+1)*RT) x all CT column tiles; else all RT row tiles x column tiles
+// [w*CT, (w+1)*CT).  MA_T x NB_T 16-row tiles are staged per chunk.
+template <int RT, int CT, bool ROWSPLIT>
+__global__ __launch_bounds__(kGramThreads, 2) void gram_rows_kernel(const GramArgs a) {
+    constexpr int MA_T = ROWSPLIT ? 4 * RT : RT, NB_T = ROWSPLIT ? CT : 4 * CT;
+    constexpr int ROWS = 16 * (MA_T + NB_T), PER = ROWS / 4;   // rows staged per chunk; rows per wave
+    __shared__ float lds[ROWS * kGramLS];
+    const int tid = threadIdx.x, lane = tid & 63, g = (lane >> 4) & 3, ci = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = a.nb1 + a.nb2, HW = a.HW;
+    const int cpb = (HW + kGramChunk - 1) / kGramChunk, total = a.B * cpb;
+
+    f32x4 acc[RT][CT];
+    float rs[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        rs[i] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // row r of the staged set: r < 16*MA_T -> A row r, else B row r - 16*MA_T (rows beyond the real counts read as zero)
+    float pre[PER];
+    auto issue = [&](int c) {
+        const int bi = c / cpb, cell = (c - bi * cpb) * kGramChunk + lane;
+        const bool in = cell < HW;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int r = 4 * k + wave;
+            const float* p = nullptr;
+            if (r < 16 * MA_T) {
+                if (r < a.ma) p = a.a + ((size_t)bi * a.ma + r) * HW;
+            } else {
+                const int rb = r - 16 * MA_T;
+                if (rb < a.nb1) p = a.b1 + ((size_t)bi * a.nb1 + rb) * HW;
+                else if (rb < nb) p = a.b2 + ((size_t)bi * a.nb2 + (rb - a.nb1)) * HW;
+            }
+            pre[k] = (p && in) ? p[cell] : 0.0f;
+        }
+    };
+    int c = blockIdx.x;
+    if (c < total) issue(c);
+    for (; c < total; c += gridDim.x) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) lds[(4 * k + wave) * kGramLS + lane] = pre[k];
+        __syncthreads();
+        if (c + (int)gridDim.x < total) issue(c + gridDim.x);   // next chunk's rows fly during this chunk's products
+        const float* const ar = lds + (16 * (ROWSPLIT ? wave * RT : 0) + ci) * kGramLS + g;
+        const float* const br = lds + (16 * (MA_T + (ROWSPLIT ? 0 : wave * CT)) + ci) * kGramLS + g;
+#pragma unroll 4
+        for (int s = 0; s < kGramChunk / 4; ++s) {
+            float av[RT], bv[CT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) av[i] = ar[16 * i * kGramLS + 4 * s];
+#pragma unroll
+            for (int j = 0; j < CT; ++j) bv[j] = br[16 * j * kGramLS + 4 * s];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                rs[i] += av[i];
+#pragma unroll
+                for (int j = 0; j < CT; ++j) acc[i][j] = nca_mfma(av[i], bv[j], acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- this workgroup's partial: [ma x nb] products, then ma row sums ----------------------------------------------
+    float* const ws = a.ws + (size_t)blockIdx.x * ((size_t)a.ma * nb + a.ma);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int rt = ROWSPLIT ? wave * RT + i : i;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const int col = 16 * (ROWSPLIT ? j : wave * CT + j) + ci;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * rt + 4 * g + r;
+                if (o < a.ma && col < nb) ws[(size_t)o * nb + col] = acc[i][j][r];
+            }
+        }
+        float v = rs[i];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        const int o = 16 * rt + ci;
+        if (g == 0 && o < a.ma && (ROWSPLIT || wave == 0)) ws[(size_t)a.ma * nb + o] = v;
+    }
+}
+
+template <int RT, int CT, bool ROWSPLIT>
+hipError_t launch_gram(const GramArgs& a, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((gram_rows_kernel<RT, CT, ROWSPLIT>), dim3(grid), dim3(kGramThreads), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+int nca_gram_grid(int B, int HW) {
+    int dev = 0, v = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        v > 0)
+        cus = v;
+    const long total = (long)B * ((HW + kGramChunk - 1) / kGramChunk);
+    return (int)(total < 2L * cus ? total : 2L * cus);
+}
+
+// out[ma*nb + ma] = [products | row sums of A]; ws holds nca_gram_grid(B, HW) partials of that size.
+// Shapes: ma <= 128 with nb <= 80 (dW1-like: rows split over the waves), or ma <= 32 with nb <= 128 (dW2-like).
+hipError_t nca_launch_gram_rows(const float* a, int ma, const float* b1, int nb1, const float* b2, int nb2, int B, int HW,
+                                float* out, float* ws, hipStream_t st) {
+    const int nb = nb1 + nb2, grid = nca_gram_grid(B, HW);
+    const GramArgs ga{a, b1, b2, ws, ma, nb1, nb2, B, HW};
+    hipError_t e = hipErrorInvalidValue;
+    if (ma <= 32 && nb <= 128) e = ma <= 16 ? launch_gram<1, 2, false>(ga, grid, st) : launch_gram<2, 2, false>(ga, grid, st);
+    else if (ma <= 128 && nb <= 80) e = ma <= 64 ? launch_gram<1, 5, true>(ga, grid, st) : launch_gram<2, 5, true>(ga, grid, st);
+    if (e != hipSuccess) return e;
+    return nca_launch_reduce_rows(ws, out, grid, ma * nb + ma, st);
+}

@@ -260,12 +260,34 @@ def cond_grow_backward(states: torch.Tensor, pre: torch.Tensor, goal: Optional[t
     return g
 
 
+def gram_rows(a: torch.Tensor, b1: torch.Tensor, b2: Optional[torch.Tensor] = None):
+    """(sum_cells a_i * b_j  [ma, nb],  sum_cells a_i  [ma]) over all B*H*W cells, for a [B,ma,H,W] and b = [b1 | b2] rows
+    [B,nb1,H,W] / [B,nb2,H,W]: the weight and bias gradient of a 1x1 conv layer (ncahip_gram_rows_f32)."""
+    a, b1 = _dev(a, "a"), _dev(b1, "b1")
+    B, ma, H, W = a.shape
+    nb1, nb2 = b1.shape[1], 0
+    if b2 is not None:
+        b2 = _dev(b2, "b2")
+        nb2 = b2.shape[1]
+    nb = nb1 + nb2
+    out = torch.empty(ma * nb + ma, device=a.device, dtype=torch.float32)
+    nbytes = lib().ncahip_gram_rows_workspace(ma, nb, B, H * W)
+    ws = torch.empty(nbytes, device=a.device, dtype=torch.uint8)
+    check(lib().ncahip_gram_rows_f32(_p(a), ma, _p(b1), nb1, _p(b2), nb2, B, H * W, _p(out), _p(ws), nbytes, _stream()),
+          "gram_rows")
+    return out[:ma * nb].view(ma, nb), out[ma * nb:]
+
+
+def _gram_fits(ma: int, nb: int) -> bool:
+    return (ma <= 32 and nb <= 128) or (ma <= 128 and nb <= 80)
+
+
 def dynca_nsteps_backward(states: torch.Tensor, cond: Optional[torch.Tensor], us: Optional[torch.Tensor], w: DyncaWeights,
                           g_final: torch.Tensor, g_states: Optional[torch.Tensor], T: int, pad_mode: str = "replicate",
                           update_rate: float = 0.5, seed: int = 0, step0: int = 0):
     """Backward of dynca_nsteps (states = the keep_history=True buffer [T+1,B,C,H,W]).  Per step the HIP kernels
-    produce dL/dx_t and the GEMM operands (see ncahip_dynca_step_bwd_f32); the weight-gradient GEMMs with K = all
-    cells are evaluated by rocBLAS through torch.matmul.  g_states (optional, [T+1,...]) adds dL/dx_t cotangents of
+    produce dL/dx_t and the operands of the weight-gradient products (see ncahip_dynca_step_bwd_f32), which
+    ncahip_gram_rows_f32 evaluates with the cell axis as K.  g_states (optional, [T+1,...]) adds dL/dx_t cotangents of
     intermediate states (forward_nsteps' return_middle_feature).  Returns dict x0, w1 [fc,4C+cc], b1, w2 [C,fc], b2."""
     states, g = _dev(states, "states"), _dev(g_final, "g_final")
     _, B, C, H, W = states.shape
@@ -290,12 +312,17 @@ def dynca_nsteps_backward(states: torch.Tensor, cond: Optional[torch.Tensor], us
                                               _p(hbuf), _p(dhbuf), _p(dy), _stream()), "dynca_step_bwd")
         do = g * (u_t + update_rate).floor()
         y = dynca_perceive(x_t, pad_mode)
-        if cond is not None:
-            y = torch.cat([y, cond], dim=1)
-        gw2 += torch.matmul(do.transpose(0, 1).reshape(C, -1), hbuf.transpose(0, 1).reshape(fc, -1).t())
-        gb2 += do.sum(dim=(0, 2, 3))
-        gw1 += torch.matmul(dhbuf.transpose(0, 1).reshape(fc, -1), y.transpose(0, 1).reshape(k1, -1).t())
-        gb1 += dhbuf.sum(dim=(0, 2, 3))
+        if _gram_fits(C, fc) and _gram_fits(fc, k1):   # HIP products with the cell axis as K (csrc/nca_gram.hip)
+            w2g, b2g = gram_rows(do, hbuf)
+            w1g, b1g = gram_rows(dhbuf, y, cond)
+            gw2 += w2g; gb2 += b2g; gw1 += w1g; gb1 += b1g
+        else:                                           # shapes the fused backward does not reach anyway: library GEMMs
+            if cond is not None:
+                y = torch.cat([y, cond], dim=1)
+            gw2 += torch.matmul(do.transpose(0, 1).reshape(C, -1), hbuf.transpose(0, 1).reshape(fc, -1).t())
+            gb2 += do.sum(dim=(0, 2, 3))
+            gw1 += torch.matmul(dhbuf.transpose(0, 1).reshape(fc, -1), y.transpose(0, 1).reshape(k1, -1).t())
+            gb1 += dhbuf.sum(dim=(0, 2, 3))
         g = gx
         if g_states is not None:
             g = g + g_states[t]
