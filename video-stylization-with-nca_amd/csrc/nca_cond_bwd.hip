@@ -803,16 +803,28 @@ __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCon
 }
 
 // dst[j] = sum_i src[i*m + j] (fixed order -> deterministic)
-// dst[j] = sum_i src[i][j]: a block owns 64 columns, its four waves take every fourth row each (fixed order: deterministic)
+// dst[j] = sum_i src[i][j]: a block owns 16 columns, its 16 row groups take every sixteenth row each, partial sums combined
+// in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int m) {
-    __shared__ float part[4][64];
-    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6, j = blockIdx.x * 64 + c;
-    float acc = 0.0f;
-    if (j < m)
-        for (int i = rg; i < n; i += 4) acc += src[(size_t)i * m + j];
-    part[rg][c] = acc;
+    __shared__ float part[16][17];
+    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4, j = blockIdx.x * 16 + c;
+    float acc0 = 0.0f, acc1 = 0.0f;
+    if (j < m) {
+        int i = rg;
+        for (; i + 16 < n; i += 32) {
+            acc0 += src[(size_t)i * m + j];
+            acc1 += src[(size_t)(i + 16) * m + j];
+        }
+        if (i < n) acc0 += src[(size_t)i * m + j];
+    }
+    part[rg][c] = acc0 + acc1;
     __syncthreads();
-    if (rg == 0 && j < m) dst[j] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    if (rg == 0 && j < m) {
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += part[k][c];
+        dst[j] = v;
+    }
 }
 // perception-weight partials [B*C*bpp][27] -> grad [C][27]
 __global__ __launch_bounds__(64) void reduce_wp_kernel(const float* __restrict__ part, float* __restrict__ dst, int B, int C, int bpp) {
@@ -872,7 +884,7 @@ hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
 }
 
 hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((m + 63) / 64), dim3(256), 0, st, src, dst, n, m);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((m + 15) / 16), dim3(256), 0, st, src, dst, n, m);
     return hipGetLastError();
 }
 hipError_t nca_launch_reduce_wp(const float* part, float* dst, int B, int C, int H, int W, hipStream_t st) {

@@ -45,45 +45,68 @@ __global__ __launch_bounds__(kGramThreads, 2) void gram_rows_kernel(const GramAr
     }
     // row r of the staged set: r < 16*MA_T -> A row r, else B row r - 16*MA_T (rows beyond the real counts read as zero)
     float pre[PER];
+    // Loads are unconditional (row and cell indices clamped into the tensors); rows beyond the real counts and cells beyond
+    // HW are zeroed when the chunk is written to LDS -- per-row predicates at load time cost an exec-mask dance per row.
     auto issue = [&](int c) {
-        const int bi = c / cpb, cell = (c - bi * cpb) * kGramChunk + lane;
-        const bool in = cell < HW;
+        const int bi = c / cpb, cell = min((c - bi * cpb) * kGramChunk + lane, HW - 1);
+        // opaque per chunk: the row offsets r*HW are recomputed with a scalar multiply each instead of being hoisted out of
+        // the chunk loop as ~100 SGPRs of loop invariants (and spilled)
+        int hw = HW;
+        asm volatile("" : "+s"(hw));
+        const float* const pa = a.a + (size_t)bi * a.ma * hw + cell;
+        const float* const pb1 = a.b1 + (size_t)bi * a.nb1 * hw + cell;
+        const float* const pb2 = a.b2 ? a.b2 + (size_t)bi * a.nb2 * hw + cell : pb1;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int r = 4 * k + wave;
-            const float* p = nullptr;
-            if (r < 16 * MA_T) {
-                if (r < a.ma) p = a.a + ((size_t)bi * a.ma + r) * HW;
+            const float* p;
+            if (k < 4 * MA_T) {                       // compile-time split: the first 16*MA_T staged rows are A rows
+                p = pa + (size_t)((unsigned)min(r, a.ma - 1) * (unsigned)hw);
             } else {
                 const int rb = r - 16 * MA_T;
-                if (rb < a.nb1) p = a.b1 + ((size_t)bi * a.nb1 + rb) * HW;
-                else if (rb < nb) p = a.b2 + ((size_t)bi * a.nb2 + (rb - a.nb1)) * HW;
+                p = rb < a.nb1 ? pb1 + (size_t)((unsigned)rb * (unsigned)hw)
+                               : pb2 + (size_t)((unsigned)max(min(rb, nb - 1) - a.nb1, 0) * (unsigned)hw);
             }
-            pre[k] = (p && in) ? p[cell] : 0.0f;
+            pre[k] = *p;
         }
+    };
+    auto row_real = [&](int k) {
+        const int r = 4 * k + wave;
+        return k < 4 * MA_T ? r < a.ma : r - 16 * MA_T < nb;
     };
     int c = blockIdx.x;
     if (c < total) issue(c);
     for (; c < total; c += gridDim.x) {
+        const bool in = (c % cpb) * kGramChunk + lane < HW;
 #pragma unroll
-        for (int k = 0; k < PER; ++k) lds[(4 * k + wave) * kGramLS + lane] = pre[k];
+        for (int k = 0; k < PER; ++k) lds[(4 * k + wave) * kGramLS + lane] = (in && row_real(k)) ? pre[k] : 0.0f;
         __syncthreads();
         if (c + (int)gridDim.x < total) issue(c + gridDim.x);   // next chunk's rows fly during this chunk's products
         const float* const ar = lds + (16 * (ROWSPLIT ? wave * RT : 0) + ci) * kGramLS + g;
         const float* const br = lds + (16 * (MA_T + (ROWSPLIT ? 0 : wave * CT)) + ci) * kGramLS + g;
-#pragma unroll 4
+        // operand reads one k-step ahead of their MFMAs (an LDS read issued right before its use stalls the in-order pipe
+        // for the whole round trip; the fences keep the compiler from sinking the reads back down)
+        float av[2][RT], bv[2][CT];
+        auto fetch = [&](int s, int q) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i) av[q][i] = ar[16 * i * kGramLS + 4 * s];
+#pragma unroll
+            for (int j = 0; j < CT; ++j) bv[q][j] = br[16 * j * kGramLS + 4 * s];
+        };
+        fetch(0, 0);
+#pragma unroll
         for (int s = 0; s < kGramChunk / 4; ++s) {
-            float av[RT], bv[CT];
-#pragma unroll
-            for (int i = 0; i < RT; ++i) av[i] = ar[16 * i * kGramLS + 4 * s];
-#pragma unroll
-            for (int j = 0; j < CT; ++j) bv[j] = br[16 * j * kGramLS + 4 * s];
+            const int q = s & 1;
+            if (s + 1 < kGramChunk / 4) fetch(s + 1, q ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
-                rs[i] += av[i];
 #pragma unroll
-                for (int j = 0; j < CT; ++j) acc[i][j] = nca_mfma(av[i], bv[j], acc[i][j]);
+                for (int j = 0; j < CT; ++j) acc[i][j] = nca_mfma(av[q][i], bv[q][j], acc[i][j]);
             }
+#pragma unroll
+            for (int i = 0; i < RT; ++i) rs[i] += av[q][i];
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
