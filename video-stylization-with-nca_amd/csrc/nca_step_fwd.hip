@@ -933,15 +933,12 @@ hipError_t launch_dynca_bwd(const NcaDyncaArgs& a, hipStream_t st) {
 // dL/dx_t = G + dy[0:C] + adj(Sx)(dy[C:2C]) + adj(Sy)(dy[2C:3C]) + adj(L)(dy[3C:4C]), where adj is the adjoint of
 // "F.pad(mode) then 3x3 cross-correlation" (dynca.py:83-86): a cell p collects w[t] * dy[q] from every (q, t) whose
 // padded source index pad(q + t) equals p.  Candidates q lie in p's 3x3 neighbourhood (wrapped for 'circular').
-__global__ __launch_bounds__(256) void dynca_step_bwd_stencil_kernel(const NcaDyncaArgs a) {
+__device__ float dynca_bwd_cell(const NcaDyncaArgs& a, int b, int c, int py, int px) {
     const int C = a.C, H = a.H, W = a.W, pad = a.pad_mode;
     const size_t plane = (size_t)H * W;
-    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= (size_t)a.B * C * plane) return;
-    const int px = (int)(id % W), py = (int)((id / W) % H), c = (int)((id / plane) % C), b = (int)(id / (plane * C));
     const float* const dy = a.dybuf + (size_t)b * 4 * C * plane;
     const size_t off = (size_t)py * W + px;
-    float acc = a.g_next[id] + dy[(size_t)c * plane + off];
+    float acc = a.g_next[((size_t)b * C + c) * plane + off] + dy[(size_t)c * plane + off];
     // per axis: for candidate offset iq in {-1,0,1} and tap t in {-1,0,1}: does pad(q + t) land on p ?
     int qy[3], qx[3];
     bool hy[3][3], hx[3][3];
@@ -980,7 +977,57 @@ __global__ __launch_bounds__(256) void dynca_step_bwd_stencil_kernel(const NcaDy
             acc = fmaf(wsy, dy[(size_t)(2 * C + c) * plane + qo], acc);
             acc = fmaf(wl, dy[(size_t)(3 * C + c) * plane + qo], acc);
         }
-    a.g_out[id] = acc;
+    return acc;
+}
+
+// any shape: one thread per cell
+__global__ __launch_bounds__(256) void dynca_step_bwd_stencil_kernel(const NcaDyncaArgs a) {
+    const int C = a.C, H = a.H, W = a.W;
+    const size_t plane = (size_t)H * W;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)a.B * C * plane) return;
+    const int px = (int)(id % W), py = (int)((id / W) % H), c = (int)((id / plane) % C), b = (int)(id / (plane * C));
+    a.g_out[id] = dynca_bwd_cell(a, b, c, py, px);
+}
+
+// W % 4 == 0, 16-byte aligned planes: one thread per 4 W-contiguous cells.  Away from the image border the padding plays no
+// part and the adjoint is the correlation with the flipped filters (Sobel flips sign, the Laplacian is symmetric): three
+// rows of three planes, 16-byte loads plus the two edge cells (L1 hits: the neighbouring lanes fetch those lines).
+// The border band (two rows top and bottom, four columns left and right) is left to the kernel below: a few lanes of every
+// wave running the per-cell routine would hold the whole wave for its ~2000 instructions.
+__global__ __launch_bounds__(256) void dynca_step_bwd_stencil_vec_kernel(const NcaDyncaArgs a) {
+    const int C = a.C, H = a.H, W = a.W, W4 = W >> 2;
+    const size_t plane = (size_t)H * W;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)a.B * C * H * W4) return;
+    const int x0 = (int)(id % W4) * 4, py = (int)((id / W4) % H), c = (int)((id / ((size_t)W4 * H)) % C),
+              b = (int)(id / ((size_t)W4 * H * C));
+    float* const out = a.g_out + ((size_t)b * C + c) * plane + (size_t)py * W + x0;
+    // border band of two cells: with 'reflect' a border cell's out-of-range taps land one cell INSIDE the image
+    if (py < 2 || py > H - 3 || x0 < 4 || x0 + 8 > W) return;   // the border band belongs to dynca_step_bwd_stencil_border_kernel
+    const float* const dy = a.dybuf + (size_t)b * 4 * C * plane + (size_t)py * W + x0;
+    const float4 gv = *reinterpret_cast<const float4*>(a.g_next + ((size_t)b * C + c) * plane + (size_t)py * W + x0);
+    const float4 d0 = *reinterpret_cast<const float4*>(dy + (size_t)c * plane);
+    float acc[4] = {gv.x + d0.x, gv.y + d0.y, gv.z + d0.z, gv.w + d0.w};
+    float v[3][3][6];   // [filter plane][row y-1..y+1][col x0-1..x0+4]
+#pragma unroll
+    for (int f = 0; f < 3; ++f)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float* const row = dy + (size_t)((f + 1) * C + c) * plane + (ptrdiff_t)(r - 1) * W;
+            const float4 m = *reinterpret_cast<const float4*>(row);
+            v[f][r][0] = row[-1]; v[f][r][1] = m.x; v[f][r][2] = m.y; v[f][r][3] = m.z; v[f][r][4] = m.w; v[f][r][5] = row[4];
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // flipped Sobel-x: weight of dy1[p + (dyy, dxx)] is SX[1 - dyy][1 - dxx] = -SX[1 + dyy][1 + dxx]
+        const float sx = (v[0][0][j] - v[0][0][j + 2]) + 2.0f * (v[0][1][j] - v[0][1][j + 2]) + (v[0][2][j] - v[0][2][j + 2]);
+        const float sy = (v[1][0][j] + 2.0f * v[1][0][j + 1] + v[1][0][j + 2]) - (v[1][2][j] + 2.0f * v[1][2][j + 1] + v[1][2][j + 2]);
+        const float lp = (v[2][0][j] + v[2][0][j + 2] + v[2][2][j] + v[2][2][j + 2]) +
+                         2.0f * (v[2][0][j + 1] + v[2][1][j] + v[2][1][j + 2] + v[2][2][j + 1]) - 12.0f * v[2][1][j + 1];
+        acc[j] += sx + sy + lp;
+    }
+    *reinterpret_cast<float4*>(out) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
 template <int CP, bool VEC>
@@ -1047,6 +1094,26 @@ hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st) {
 
 // bf16 state storage: x_in / x_out point at bf16 data (cond, uniforms, weights stay f32); same kernel, exact f32 compute,
 // round-to-nearest-even on store.  The 8-byte vector path needs W % 4 == 0 and 8-byte aligned planes.
+// the border band of every (b, c) plane, one thread per cell: 4 full rows + 8 columns of the H - 4 rows between them
+__global__ __launch_bounds__(256) void dynca_step_bwd_stencil_border_kernel(const NcaDyncaArgs a) {
+    const int C = a.C, H = a.H, W = a.W;
+    const int per_plane = 4 * W + 8 * (H - 4);
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)a.B * C * per_plane) return;
+    const int k = (int)(id % per_plane), c = (int)((id / per_plane) % C), b = (int)(id / ((size_t)per_plane * C));
+    int py, px;
+    if (k < 4 * W) {
+        const int r = k / W;
+        py = r < 2 ? r : H - 4 + r;
+        px = k - r * W;
+    } else {
+        const int q = k - 4 * W, j = q & 7;
+        py = 2 + (q >> 3);
+        px = j < 4 ? j : W - 8 + j;
+    }
+    a.g_out[((size_t)b * C + c) * (size_t)H * W + (size_t)py * W + px] = dynca_bwd_cell(a, b, c, py, px);
+}
+
 template <int CP, int FC, bool HAS_COND>
 static hipError_t launch_dynca_b16(const NcaDyncaArgs& a, hipStream_t st) {
     const bool vec = (a.W % 4 == 0) && (((uintptr_t)a.x_in & 7u) == 0) && (((size_t)a.H * a.W) % 4 == 0);
@@ -1067,7 +1134,14 @@ hipError_t nca_launch_dynca_step_bwd(const NcaDyncaArgs& a, hipStream_t st) {
     else if (a.C <= 16 && a.fc <= 128) e = hc ? launch_dynca_bwd<16, 128, true>(a, st) : launch_dynca_bwd<16, 128, false>(a, st);
     if (e != hipSuccess) return e;
     const size_t n = (size_t)a.B * a.C * a.H * a.W;
-    hipLaunchKernelGGL(dynca_step_bwd_stencil_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    const bool vec = (a.W % 4 == 0) && a.W >= 12 && a.H >= 3 && aligned16(a.g_next) && aligned16(a.g_out) && aligned16(a.dybuf);
+    if (vec && a.H >= 5) {
+        hipLaunchKernelGGL(dynca_step_bwd_stencil_vec_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, a);
+        const size_t nb = (size_t)a.B * a.C * (4 * a.W + 8 * (a.H - 4));
+        hipLaunchKernelGGL(dynca_step_bwd_stencil_border_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(dynca_step_bwd_stencil_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    }
     return hipGetLastError();
 }
 
