@@ -107,8 +107,8 @@ int ncahip_dynca_nsteps_fwd_f32(float *states, int ring, int T, const float *con
 /* Backward of ONE DyNCA step (autograd through dynca.py:117-138; dynca.py:123: no gradient into cond).
  *   In : x_t (the step's input state), the same cond / u (or seed, step) / weights, g_next = dL/dx_{t+1}.
  *   Out: g_x = dL/dx_t (data path through W2^T, relu', W1^T on MFMA, then the adjoint of "F.pad(mode) + fixed 3x3
- *        filters", plus the residual path), and the two operand pairs of the weight-gradient GEMMs, which the
- *        caller evaluates with a library GEMM over all cells:
+ *        filters", plus the residual path), and the two operand pairs of the weight-gradient products, which the
+ *        caller evaluates over all cells with ncahip_gram_rows_f32 (below):
  *            h_out  = relu(w1 y + b1)            [B,fc,H,W]     dW2 += (g_next*mask) h^T ,  db2 += sum(g_next*mask)
  *            dh_out = dL/d(w1 y + b1)            [B,fc,H,W]     dW1 += dh y^T            ,  db1 += sum(dh)
  *        (y = [ncahip_dynca_perceive_f32(x_t) | cond], mask = floor(u + rate)).  dy_scratch: [B,4C,H,W] floats. */

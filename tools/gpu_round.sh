@@ -42,4 +42,5 @@ if [ -f video-stylization-with-nca_amd/libncahip_stamps.so ]; then
   timeout -k 10 200 python tools/stamp_bwd.py > $out/${tag}_bwd_phases.txt 2>&1 || { tail -20 $out/${tag}_bwd_phases.txt; exit 1; }
   cat $out/${tag}_bwd_phases.txt
 fi
+timeout -k 10 200 python tools/bench_dynca_train.py >> $out/${tag}_train.json 2>> $out/${tag}_train.err || { tail -20 $out/${tag}_train.err; exit 1; }
 cat $out/${tag}_train.json $out/${tag}_bf16.json
