@@ -47,27 +47,33 @@ __global__ __launch_bounds__(kGramThreads, 2) void gram_rows_kernel(const GramAr
     float pre[PER];
     // Loads are unconditional (row and cell indices clamped into the tensors); rows beyond the real counts and cells beyond
     // HW are zeroed when the chunk is written to LDS -- per-row predicates at load time cost an exec-mask dance per row.
+    // Buffer loads: the lane's cell offset is the only vector operand, every row's offset is a scalar (no vector address
+    // arithmetic per load: it would sit in the same issue slots as the exact-f32 MFMAs).  Needs each batch item's rows
+    // within 4 GiB, which the launcher checks.
     auto issue = [&](int c) {
-        const int bi = c / cpb, cell = min((c - bi * cpb) * kGramChunk + lane, HW - 1);
+        const int bi = c / cpb;
+        const unsigned vo = (unsigned)min((c - bi * cpb) * kGramChunk + lane, HW - 1) * 4u;
         // opaque per chunk: the row offsets r*HW are recomputed with a scalar multiply each instead of being hoisted out of
         // the chunk loop as ~100 SGPRs of loop invariants (and spilled)
-        int hw = HW;
-        asm volatile("" : "+s"(hw));
-        const float* const pa = a.a + (size_t)bi * a.ma * hw + cell;
-        const float* const pb1 = a.b1 + (size_t)bi * a.nb1 * hw + cell;
-        const float* const pb2 = a.b2 ? a.b2 + (size_t)bi * a.nb2 * hw + cell : pb1;
+        unsigned hw4 = (unsigned)HW * 4u;
+        asm volatile("" : "+s"(hw4));
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.a + (size_t)bi * a.ma * HW), 0, -1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.b1 + (size_t)bi * a.nb1 * HW), 0, -1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb2 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.b2 ? a.b2 + (size_t)bi * a.nb2 * HW : a.b1 + (size_t)bi * a.nb1 * HW), 0, -1, 0x00020000);
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int r = 4 * k + wave;
-            const float* p;
             if (k < 4 * MA_T) {                       // compile-time split: the first 16*MA_T staged rows are A rows
-                p = pa + (size_t)((unsigned)min(r, a.ma - 1) * (unsigned)hw);
+                pre[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)vo, (int)((unsigned)min(r, a.ma - 1) * hw4), 0));
             } else {
                 const int rb = r - 16 * MA_T;
-                p = rb < a.nb1 ? pb1 + (size_t)((unsigned)rb * (unsigned)hw)
-                               : pb2 + (size_t)((unsigned)max(min(rb, nb - 1) - a.nb1, 0) * (unsigned)hw);
+                if (rb < a.nb1)
+                    pre[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb1, (int)vo, (int)((unsigned)rb * hw4), 0));
+                else
+                    pre[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        rb2, (int)vo, (int)((unsigned)max(min(rb, nb - 1) - a.nb1, 0) * hw4), 0));
             }
-            pre[k] = *p;
         }
     };
     auto row_real = [&](int k) {
@@ -156,6 +162,8 @@ hipError_t nca_launch_gram_rows(const float* a, int ma, const float* b1, int nb1
     const int nb = nb1 + nb2, grid = nca_gram_grid(B, HW);
     const GramArgs ga{a, b1, b2, ws, ma, nb1, nb2, B, HW};
     hipError_t e = hipErrorInvalidValue;
+    const size_t lim = (size_t)1 << 32;   // scalar byte offsets inside one batch item
+    if ((size_t)ma * HW * 4 >= lim || (size_t)nb1 * HW * 4 >= lim || (size_t)nb2 * HW * 4 >= lim) return hipErrorInvalidValue;
     if (ma <= 32 && nb <= 128) e = ma <= 16 ? launch_gram<1, 2, false>(ga, grid, st) : launch_gram<2, 2, false>(ga, grid, st);
     else if (ma <= 128 && nb <= 80) e = ma <= 64 ? launch_gram<1, 5, true>(ga, grid, st) : launch_gram<2, 5, true>(ga, grid, st);
     if (e != hipSuccess) return e;
