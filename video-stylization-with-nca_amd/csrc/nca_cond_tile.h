@@ -323,7 +323,9 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
             for (int k = 0; k < CP / 2; ++k) {
                 // goal channel 2k + hl - gch0; lanes below gch0 never use the value and read channel 0 instead
                 const int d = 2 * k - gch0;   // uniform
-                R.gf[k] = ST::template ld4<0>(rg, d >= 0 ? vox : pix4, d >= 0 ? (unsigned)d * plane4 : 0u);
+                if (EXACT) R.gf[k] = ST::template ld4<0>(rg, d >= 0 ? vox : pix4, d >= 0 ? (unsigned)d * plane4 : 0u);
+                else   // C < CP: the padded channels 2k + hl >= C must not index past the goal tensor's last plane
+                    R.gf[k] = ST::template ld4<0>(rg, pix4 + __umul24((unsigned)min(max(d + hl, 0), a.goal_ch - 1), plane4), 0u);
             }
         }
     }
@@ -343,8 +345,9 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
 #pragma unroll
             for (int k = 0; k < CP / 4; ++k) {
                 const int d = 4 * k - gch0;   // uniform
-                if (d >= 0) R.gh[k] = ST::template ld1<0>(rg, voh, (unsigned)d * plane4);
-                else R.gh[k] = ST::template ld1<0>(rg, pix4 + __umul24((unsigned)max(4 * k + q4 - gch0, 0), plane4), 0u);
+                if (EXACT && d >= 0) R.gh[k] = ST::template ld1<0>(rg, voh, (unsigned)d * plane4);
+                else   // (C < CP: clamp to the goal tensor's last plane, as above)
+                    R.gh[k] = ST::template ld1<0>(rg, pix4 + __umul24((unsigned)min(max(4 * k + q4 - gch0, 0), a.goal_ch - 1), plane4), 0u);
             }
         }
     }
