@@ -367,25 +367,47 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                 for (int mj = 0; mj < K::MJ; ++mj)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) dY[mj][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // A operands are read from LDS a whole section ahead of their MFMAs (one wave per SIMD: a read issued right
+                // before its use costs the full LDS round trip each time): layer-1 operands of hidden tile m+1 during the
+                // dL/dy products of tile m, the transposed operands of tile m during its layer-1 chain.  The fences keep the
+                // compiler from sinking the reads back to their uses.
+                float wa1[K::K1S], wt2[4], wt1[4][K::MJ];
+                f32x4 bias1;
+                auto fetch1 = [&](int m) {
+                    const float* const w1m = W1L + m * K::K1S * 64 + lane;
+#pragma unroll
+                    for (int s = 0; s < K::K1S; ++s) wa1[s] = w1m[s * 64];
+                    bias1 = *reinterpret_cast<const f32x4*>(B1L + 16 * m + 4 * g);
+                };
+                auto fetch_t = [&](int m) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) wt2[s] = W2T[(m * 4 + s) * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int mj = 0; mj < K::MJ; ++mj) wt1[r][mj] = W1T[(mj * K::K2S + 4 * m + r) * 64 + lane];
+                };
+                fetch1(0);
 #pragma unroll 1
                 for (int m = 0; m < K::M1T; ++m) {
-                    const float* const w1m = W1L + m * K::K1S * 64 + lane;
-                    const f32x4 bias = *reinterpret_cast<const f32x4*>(B1L + 16 * m + 4 * g);
                     f32x4 acc1[NT], dacc[NT];
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) { acc1[n] = bias; dacc[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    for (int n = 0; n < NT; ++n) { acc1[n] = bias1; dacc[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    fetch_t(m);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int s = 0; s < K::K1S; ++s) {
-                        const float wa = w1m[s * 64];
 #pragma unroll
-                        for (int n = 0; n < NT; ++n) acc1[n] = nca_mfma(wa, P[n][s], acc1[n]);
+                        for (int n = 0; n < NT; ++n) acc1[n] = nca_mfma(wa1[s], P[n][s], acc1[n]);
                     }
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        const float wa = W2T[(m * 4 + s) * 64 + lane];
 #pragma unroll
-                        for (int n = 0; n < NT; ++n) dacc[n] = nca_mfma(wa, dO[n][s], dacc[n]);
+                        for (int n = 0; n < NT; ++n) dacc[n] = nca_mfma(wt2[s], dO[n][s], dacc[n]);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m + 1 < K::M1T) fetch1(m + 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
                         const size_t cell = live[n] ? (size_t)(ty0 + r0[n]) * W + tx0 + q0[n] : 0;
@@ -405,9 +427,8 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int mj = 0; mj < K::MJ; ++mj) {
-                            const float wa = W1T[(mj * K::K2S + 4 * m + r) * 64 + lane];
 #pragma unroll
-                            for (int n = 0; n < NT; ++n) dY[mj][n] = nca_mfma(wa, dacc[n][r], dY[mj][n]);
+                            for (int n = 0; n < NT; ++n) dY[mj][n] = nca_mfma(wt1[r][mj], dacc[n][r], dY[mj][n]);
                         }
                 }
 #pragma unroll
