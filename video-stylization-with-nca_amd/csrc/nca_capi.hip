@@ -288,6 +288,8 @@ int ncahip_dynca_step_bwd_f32(const float* x_t, const float* cond, const float* 
     if (int rc = check_dynca(x_t, g_x, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
     if (g_next == g_x) return fail(NCAHIP_EINVAL, "dynca step bwd: g_next and g_x must not alias");
     if (C > kMaxC) return fail(NCAHIP_ERANGE, "dynca step bwd: C=%d exceeds %d (the backward kernels cover C <= 16)", C, kMaxC);
+    if ((size_t)(fc > 4 * C ? fc : 4 * C) * H * W * sizeof(float) >= ((size_t)1 << 32))
+        return fail(NCAHIP_ERANGE, "dynca step bwd: fc*H*W*4 must stay below 4 GiB (32-bit store offsets inside a batch item)");
     NcaDyncaArgs a{x_t, nullptr, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step,
                    g_next, h_out, dh_out, dy_scratch, g_x};
     return hip_result(nca_launch_dynca_step_bwd(a, (hipStream_t)stream), "dynca_step_bwd");

@@ -362,6 +362,18 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                         dO[n][r] = (live[n] && ch < C) ? gv * mk : 0.0f;
                     }
                 }
+                // Output addressing: the lane's part (cell, 4g rows) is ONE vector offset per n, the (16m + r) row of each store a
+                // scalar offset -- per-store 64-bit vector address arithmetic was ~1300 VALU instructions per pass, in the same
+                // issue slots as the exact-f32 MFMAs.  (Launcher: fc*H*W*4 and 4C*H*W*4 below 4 GiB.)
+                const unsigned plane4 = (unsigned)plane * 4u;
+                const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(a.hbuf + (size_t)b * fc * plane, 0, -1, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rdh = __builtin_amdgcn_make_buffer_rsrc(a.dhbuf + (size_t)b * fc * plane, 0, -1, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(a.dybuf + (size_t)b * 4 * C * plane, 0, -1, 0x00020000);
+                unsigned vo[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    vo[n] = (live[n] ? (unsigned)((ty0 + r0[n]) * W + tx0 + q0[n]) * 4u : 0u) + (unsigned)(4 * g) * plane4;
+                const int lim_h = fc - 4 * g, lim_y = 4 * C - 4 * g;   // row 16m + 4g + r exists <=> 16m + r < lim
                 f32x4 dY[K::MJ][NT];
 #pragma unroll
                 for (int mj = 0; mj < K::MJ; ++mj)
@@ -410,16 +422,15 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        const size_t cell = live[n] ? (size_t)(ty0 + r0[n]) * W + tx0 + q0[n] : 0;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int hid = 16 * m + 4 * g + r;
                             const float hv = fmaxf(acc1[n][r], 0.0f);
                             const float dv = acc1[n][r] > 0.0f ? dacc[n][r] : 0.0f;   // relu' = 0 at exactly 0
                             dacc[n][r] = dv;
-                            if (live[n] && hid < fc) {
-                                a.hbuf[((size_t)b * fc + hid) * plane + cell] = hv;
-                                a.dhbuf[((size_t)b * fc + hid) * plane + cell] = dv;
+                            if (live[n] && 16 * m + r < lim_h) {
+                                const int so = (int)((unsigned)(16 * m + r) * plane4);
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), rh, (int)vo[n], so, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv), rdh, (int)vo[n], so, 0);
                             }
                         }
                     }
@@ -434,13 +445,13 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     if (!live[n]) continue;
-                    const size_t cell = (size_t)(ty0 + r0[n]) * W + tx0 + q0[n];
 #pragma unroll
                     for (int mj = 0; mj < K::MJ; ++mj)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int j = 16 * mj + 4 * g + r;
-                            if (j < 4 * C) a.dybuf[((size_t)b * 4 * C + j) * plane + cell] = dY[mj][n][r];
+                            if (16 * mj + r < lim_y)
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dY[mj][n][r]), rdy, (int)vo[n],
+                                                                      (int)((unsigned)(16 * mj + r) * plane4), 0);
                         }
                 }
             } else {
