@@ -119,6 +119,18 @@ int ncahip_dynca_step_bwd_f32(const float *x_t, const float *cond, const float *
                               const float *g_next, float *g_x, float *h_out, float *dh_out,
                               float *dy_scratch, ncahip_stream_t stream);
 
+/* The same backward step with the layer-2 weight gradient fused in: h is kept in registers and never written; the kernel
+ * accumulates dW2 = (g_next*mask) h^T and db2 = sum(g_next*mask) on MFMA (cell axis as K, operands transposed through LDS)
+ * and gw2_out [C*fc + C] receives [dW2 | db2] of THIS step (overwritten; per-workgroup partials summed in fixed order).
+ * dh_out / dy_scratch / g_x as above; dW1 | db1 = ncahip_gram_rows_f32(dh_out, perception, cond).                     */
+size_t ncahip_dynca_step_bwd_w2_workspace(int B, int C, int H, int W, int fc);
+int ncahip_dynca_step_bwd_w2_f32(const float *x_t, const float *cond, const float *u,
+                                 const float *w1, const float *b1, const float *w2, const float *b2,
+                                 int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                                 float update_rate, uint64_t seed, uint64_t step,
+                                 const float *g_next, float *g_x, float *dh_out, float *dy_scratch,
+                                 float *gw2_out, void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
+
 /* Weight-gradient products of the DyNCA backward with the cell axis as K (replaces the library GEMMs over transposed
  * copies that autograd through dynca.py:127-128 amounts to):
  *     out[i*nb + j] = sum over all B*HW cells of a[., i, .] * b[., j, .]     i < ma, j < nb = nb1 + nb2

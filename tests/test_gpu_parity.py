@@ -506,6 +506,42 @@ def test_gram_rows(ops, ma, nb1, nb2, B, H, W):
     assert torch.equal(prod, prod2)                      # fixed summation order
 
 
+@pytest.mark.parametrize("C,fc,cc,H,W", [(16, 128, 3, 24, 40), (12, 96, 0, 13, 36), (8, 64, 2, 9, 20)])
+def test_dynca_bwd_fused_w2_matches_buffers(ops, C, fc, cc, H, W):
+    """The two backward entry points agree: ncahip_dynca_step_bwd_w2_f32 (layer-2 gradient accumulated inside the step kernel,
+    h never written) against ncahip_dynca_step_bwd_f32 + ncahip_gram_rows_f32 on its h / dh buffers, and both against a
+    float64 contraction of those buffers."""
+    from ncahip import _capi
+    B = 2
+    g_ = torch.Generator().manual_seed(C * fc)
+    prm = rand_dynca_prm(C, fc, cc, seed=5, scale=3.0)
+    x = (torch.rand(B, C, H, W, generator=g_) - 0.5).to(DEV)
+    cond = torch.rand(B, cc, H, W, generator=g_).to(DEV) if cc else None
+    u = torch.rand(B, 1, H, W, generator=g_).to(DEV)
+    gn = torch.randn(B, C, H, W, generator=g_).to(DEV)
+    w = dyn_w(ops, prm, x)
+    L, P = ops.lib(), ops._p
+    hb, dh, dy = (torch.empty(B, fc, H, W, device=DEV), torch.empty(B, fc, H, W, device=DEV), torch.empty(B, 4 * C, H, W, device=DEV))
+    gx = torch.empty_like(gn)
+    _capi.check(L.ncahip_dynca_step_bwd_f32(P(x), P(cond), P(u), P(w.w1), P(w.b1), P(w.w2), P(w.b2), B, C, H, W, fc, cc, 2, 0.5,
+                                            0, 0, P(gn), P(gx), P(hb), P(dh), P(dy), None), "bwd")
+    do = gn * (u + 0.5).floor()
+    w2_a, b2_a = ops.gram_rows(do, hb)
+    dh2, dy2, gx2 = torch.empty_like(dh), torch.empty_like(dy), torch.empty_like(gn)
+    out = torch.empty(C * fc + C, device=DEV)
+    nws = L.ncahip_dynca_step_bwd_w2_workspace(B, C, H, W, fc)
+    ws = torch.empty(nws, device=DEV, dtype=torch.uint8)
+    _capi.check(L.ncahip_dynca_step_bwd_w2_f32(P(x), P(cond), P(u), P(w.w1), P(w.b1), P(w.w2), P(w.b2), B, C, H, W, fc, cc, 2, 0.5,
+                                               0, 0, P(gn), P(gx2), P(dh2), P(dy2), P(out), P(ws), nws, None), "bwd_w2")
+    assert torch.equal(gx, gx2) and torch.equal(dh, dh2)
+    ref = torch.einsum("bihw,bjhw->ij", do.double().cpu(), hb.double().cpu())
+    scale = max(1e-6, float(ref.abs().max()))
+    assert float((out[:C * fc].view(C, fc).cpu().double() - ref).abs().max()) <= 2e-5 * scale
+    assert float((w2_a.cpu().double() - ref).abs().max()) <= 2e-5 * scale
+    rs = do.double().sum(dim=(0, 2, 3)).cpu()
+    assert float((out[C * fc:].cpu().double() - rs).abs().max()) <= 2e-5 * max(1.0, float(rs.abs().max()))
+
+
 def test_cond_step_shape_fuzz(ops):
     """Seeded random shapes / channel counts / goal widths / alive settings / fire rates, pending inputs included: one
     teacher-forced step each against the oracle (nca.py:181-195).  Covers tiles that straddle every image edge and the

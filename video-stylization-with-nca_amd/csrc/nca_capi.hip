@@ -295,6 +295,32 @@ int ncahip_dynca_step_bwd_f32(const float* x_t, const float* cond, const float* 
     return hip_result(nca_launch_dynca_step_bwd(a, (hipStream_t)stream), "dynca_step_bwd");
 }
 
+// ---- backward of one DyNCA step with the layer-2 weight gradient fused in (no h buffer) ---------------------------------
+size_t ncahip_dynca_step_bwd_w2_workspace(int B, int C, int H, int W, int fc) {
+    if (!dims_ok(B, C, H, W) || fc <= 0) return 0;
+    return (size_t)nca_dynca_bwd_grid(B, H, W) * ((size_t)C * fc + C) * sizeof(float);
+}
+
+int ncahip_dynca_step_bwd_w2_f32(const float* x_t, const float* cond, const float* u, const float* w1, const float* b1,
+                                 const float* w2, const float* b2, int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                                 float update_rate, uint64_t seed, uint64_t step, const float* g_next, float* g_x,
+                                 float* dh_out, float* dy_scratch, float* gw2_out, void* workspace, size_t workspace_bytes,
+                                 ncahip_stream_t stream) {
+    if (!g_next || !g_x || !dh_out || !dy_scratch || !gw2_out || !workspace) return fail(NCAHIP_EINVAL, "dynca step bwd_w2: null pointer");
+    if (int rc = check_dynca(x_t, g_x, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
+    if (g_next == g_x) return fail(NCAHIP_EINVAL, "dynca step bwd_w2: g_next and g_x must not alias");
+    if (C > kMaxC) return fail(NCAHIP_ERANGE, "dynca step bwd_w2: C=%d exceeds %d (the backward kernels cover C <= 16)", C, kMaxC);
+    if ((size_t)(fc > 4 * C ? fc : 4 * C) * H * W * sizeof(float) >= ((size_t)1 << 32))
+        return fail(NCAHIP_ERANGE, "dynca step bwd_w2: fc*H*W*4 must stay below 4 GiB (32-bit store offsets inside a batch item)");
+    if (workspace_bytes < ncahip_dynca_step_bwd_w2_workspace(B, C, H, W, fc)) return fail(NCAHIP_EINVAL, "dynca step bwd_w2: workspace too small");
+    NcaDyncaArgs a{x_t, nullptr, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step,
+                   g_next, nullptr, dh_out, dy_scratch, g_x};
+    a.gw2_ws = (float*)workspace;
+    if (int rc = hip_result(nca_launch_dynca_step_bwd(a, (hipStream_t)stream), "dynca_step_bwd_w2")) return rc;
+    return hip_result(nca_launch_reduce_rows((const float*)workspace, gw2_out, nca_dynca_bwd_grid(B, H, W), C * fc + C,
+                                             (hipStream_t)stream), "dynca_step_bwd_w2 reduce");
+}
+
 // ---- weight-gradient products of the DyNCA backward (cell axis as K) -------------------------------------------------
 size_t ncahip_gram_rows_workspace(int ma, int nb, int B, int HW) {
     if (ma <= 0 || nb <= 0 || B <= 0 || HW <= 0) return 0;

@@ -21,6 +21,7 @@ struct NcaDyncaArgs {
     float* g_out;          // dL/dx_t                        [B,C,H,W]
     // fc > 128 runs as several launches over 128-wide slices of the hidden layer (nca_launch_dynca_step_fwd):
     int w2_ld;             // row stride of w2 (0: = fc); later slices run the accumulating instantiation (x_out += mask * slice)
+    float* gw2_ws;         // backward, fused dW2: per-workgroup partials [grid][C*fc + C] (dW2 | db2); hbuf is then not written
 };
 
 struct NcaCondArgs {
@@ -59,6 +60,7 @@ int nca_cond_bwd_nblk(int B, int C, int H, int W);
 hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& a, hipStream_t st);
 hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st);
 // nca_gram.hip: out[ma*nb + ma] = [sum_n a[i][n] * b[j][n] | sum_n a[i][n]] over all B*HW cells; b rows from two tensors
+int nca_dynca_bwd_grid(int B, int H, int W);   // workgroups of the DyNCA backward kernel (= partial slabs of its fused dW2)
 int nca_gram_grid(int B, int HW);
 hipError_t nca_launch_gram_rows(const float* a, int ma, const float* b1, int nb1, const float* b2, int nb2, int B, int HW,
                                 float* out, float* ws, hipStream_t st);

@@ -192,6 +192,9 @@ struct DyncaCfg {
     static constexpr int OFF_W2T = LDS_FLOATS;                        // [M1T][4][64]:  W2[ch=4gg+s][h=16m+i]
     static constexpr int OFF_W1T = OFF_W2T + M1T * 4 * 64;            // [MJ][K2S][64]: W1[h=k(s,gg)][j=16mj+i]
     static constexpr int LDS_FLOATS_BWD = OFF_W1T + MJ * K2S * 64;
+    static constexpr int TBS = 20;                                    // transposition tiles [16 cells][TBS] (16-byte rows)
+    static constexpr int OFF_TB = LDS_FLOATS_BWD;                     // fused dW2: per wave NT tiles
+    static constexpr int LDS_FLOATS_BWD_W2 = OFF_TB + 4 * NT * 16 * TBS;
     static_assert(FC % 16 == 0 && CP % 4 == 0 && TW % 16 == 0, "shape");
     static_assert(NTILES16 % (4 * NT) == 0, "tile must split evenly over 4 waves x NT");
     static_assert(OFF_Z % 4 == 0 && CS % 4 == 0 && TH * TW == kThreads, "16-byte carve; one cell per thread");
@@ -203,8 +206,9 @@ struct DyncaCfg {
 // hidden layer, then dh = (W2^T (G*mask)) * 1[h>0] and dL/dy = W1^T dh on MFMA (accumulator tile == next B
 // operand, as in the forward); writes relu(h), dh and dL/dy[:4C].  The two weight-gradient GEMMs
 // (dW2 = (G*mask) h^T, dW1 = dh y^T, K = all cells) are plain library GEMMs on those buffers.
-template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT, bool VEC, bool BWD = false, bool B16 = false, bool ACC = false>
+template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT, bool VEC, bool BWD = false, bool B16 = false, bool ACC = false, bool W2F = false>
 __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(const NcaDyncaArgs a) {
+    static_assert(!W2F || (BWD && CP <= 16), "fused dW2 is an option of the backward kernel (one 16-row channel tile)");
     static_assert(!(BWD && B16), "the bf16-storage step is forward only");
     static_assert(!ACC || (!BWD && !B16), "accumulating passes (fc slices beyond the first) exist for the fp32 forward only");
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
@@ -259,6 +263,13 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int ntiles = a.B * tiles_x * tiles_y;
     const size_t plane = (size_t)H * W;
+    // fused dW2 (W2F): dW2[ch][hid] = sum_cells dO[ch][cell] * h[hid][cell] accumulated over the whole launch, one 16x16
+    // tile per hidden tile m (rows = channels 4g+r, column = hidden 16m+ci), and db2 = sum_cells dO
+    f32x4 w2acc[W2F ? K::M1T : 1];
+    float b2acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < (W2F ? K::M1T : 1); ++m) w2acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* const TBW = smem + K::OFF_TB + wave * (NT * 16 * K::TBS);
 
     for (NcaTileWalk tw = nca_tile_walk(ntiles); tw.t < tw.end; tw.t += tw.stride) {
         const int txi = tw.t % tiles_x, tyi = (tw.t / tiles_x) % tiles_y, b = tw.t / (tiles_x * tiles_y);
@@ -374,6 +385,23 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                 for (int n = 0; n < NT; ++n)
                     vo[n] = (live[n] ? (unsigned)((ty0 + r0[n]) * W + tx0 + q0[n]) * 4u : 0u) + (unsigned)(4 * g) * plane4;
                 const int lim_h = fc - 4 * g, lim_y = 4 * C - 4 * g;   // row 16m + 4g + r exists <=> 16m + r < lim
+                // fused dW2: the A operands dO[ch = ci][cell 4s+g] of every n, transposed once per pass through the wave's
+                // LDS tiles (lane (g,ci) writes its four channel rows of cell ci with one 16-byte store)
+                float doT[W2F ? NT : 1][4];
+                if constexpr (W2F) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        *reinterpret_cast<f32x4*>(TBW + n * 16 * K::TBS + ci * K::TBS + 4 * g) = f32x4{dO[n][0], dO[n][1], dO[n][2], dO[n][3]};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) b2acc[r] += dO[n][r];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int s_ = 0; s_ < 4; ++s_) doT[n][s_] = TBW[n * 16 * K::TBS + (4 * s_ + g) * K::TBS + ci];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                }
                 f32x4 dY[K::MJ][NT];
 #pragma unroll
                 for (int mj = 0; mj < K::MJ; ++mj)
@@ -400,7 +428,8 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                         for (int mj = 0; mj < K::MJ; ++mj) wt1[r][mj] = W1T[(mj * K::K2S + 4 * m + r) * 64 + lane];
                 };
                 fetch1(0);
-#pragma unroll 1
+                float hT[W2F ? NT : 1][4];
+#pragma unroll (W2F ? K::M1T : 1)
                 for (int m = 0; m < K::M1T; ++m) {
                     f32x4 acc1[NT], dacc[NT];
 #pragma unroll
@@ -429,10 +458,20 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                             dacc[n][r] = dv;
                             if (live[n] && 16 * m + r < lim_h) {
                                 const int so = (int)((unsigned)(16 * m + r) * plane4);
-                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), rh, (int)vo[n], so, 0);
+                                if constexpr (!W2F) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), rh, (int)vo[n], so, 0);
                                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv), rdh, (int)vo[n], so, 0);
                             }
+                            if constexpr (W2F) acc1[n][r] = (live[n] && 16 * m + r < lim_h) ? hv : 0.0f;   // h, zero outside the image / fc
                         }
+                        if constexpr (W2F) *reinterpret_cast<f32x4*>(TBW + n * 16 * K::TBS + ci * K::TBS + 4 * g) = acc1[n];
+                    }
+                    if constexpr (W2F) {   // B operands h[cell 4s+g][hid ci]: requested here, consumed after the dL/dy products
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+#pragma unroll
+                            for (int s_ = 0; s_ < 4; ++s_) hT[n][s_] = TBW[n * 16 * K::TBS + (4 * s_ + g) * K::TBS + ci];
+                        __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -441,6 +480,14 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
 #pragma unroll
                             for (int n = 0; n < NT; ++n) dY[mj][n] = nca_mfma(wt1[r][mj], dacc[n][r], dY[mj][n]);
                         }
+                    if constexpr (W2F) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+#pragma unroll
+                            for (int s_ = 0; s_ < 4; ++s_) w2acc[m] = nca_mfma(doT[n][s_], hT[n][s_], w2acc[m]);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the tiles are rewritten by the next hidden tile
+                    }
                 }
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
@@ -540,6 +587,33 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                 }
 
             }
+        }
+    }
+    if constexpr (W2F) {
+        // the four waves' dW2 / db2 partials are summed through LDS (weight images and tiles are dead) into the workgroup's slab
+        constexpr int SW = 16 * FC + 16;
+        __syncthreads();
+        float* const sw = smem + wave * SW;
+#pragma unroll
+        for (int m = 0; m < K::M1T; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sw[(4 * g + r) * FC + 16 * m + ci] = w2acc[m][r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = b2acc[r];
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) v += __shfl_xor(v, d);
+            if (ci == 0) sw[16 * FC + 4 * g + r] = v;
+        }
+        __syncthreads();
+        float* const slab = a.gw2_ws + (size_t)blockIdx.x * ((size_t)C * fc + C);
+        for (int i = tid; i < C * fc; i += kThreads) {
+            const int ch = i / fc, hid = i - ch * fc, o = ch * FC + hid;
+            slab[i] = (smem[o] + smem[SW + o]) + (smem[2 * SW + o] + smem[3 * SW + o]);
+        }
+        if (tid < C) {
+            const int o = 16 * FC + tid;
+            slab[(size_t)C * fc + tid] = (smem[o] + smem[SW + o]) + (smem[2 * SW + o] + smem[3 * SW + o]);
         }
     }
 }
@@ -958,6 +1032,18 @@ hipError_t launch_dynca_bwd(const NcaDyncaArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, a);
         return hipGetLastError();
     };
+    if (a.gw2_ws) {   // fused dW2 | db2: per-workgroup partials, h is not written
+        static_assert(K::LDS_FLOATS_BWD_W2 * 4 <= 160 * 1024 && 4 * (16 * FC + 16) <= K::LDS_FLOATS_BWD_W2, "LDS budget (fused dW2)");
+        const size_t lds2 = (size_t)K::LDS_FLOATS_BWD_W2 * sizeof(float);
+        auto go2 = [&](auto kern) -> hipError_t {
+            hipError_t e = set_lds(kern, lds2);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds2, st, a);
+            return hipGetLastError();
+        };
+        return vec ? go2(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, true, true, false, false, true>)
+                   : go2(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, false, true, false, false, true>);
+    }
     return vec ? go(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, true, true>)
                : go(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, false, true>);
 }
@@ -1157,6 +1243,11 @@ hipError_t nca_launch_dynca_step_fwd_bf16(const NcaDyncaArgs& a, hipStream_t st)
     if (a.C <= 16 && a.fc <= 128) return hc ? launch_dynca_b16<16, 128, true>(a, st) : launch_dynca_b16<16, 128, false>(a, st);
     if (a.C <= 32 && a.fc <= 128) return hc ? launch_dynca_b16<32, 128, true>(a, st) : launch_dynca_b16<32, 128, false>(a, st);
     return hipErrorInvalidValue;
+}
+
+int nca_dynca_bwd_grid(int B, int H, int W) {
+    const int ntiles = B * ((W + 31) / 32) * ((H + 7) / 8);
+    return grid_for(ntiles, 1);
 }
 
 hipError_t nca_launch_dynca_step_bwd(const NcaDyncaArgs& a, hipStream_t st) {

@@ -298,8 +298,13 @@ def dynca_nsteps_backward(states: torch.Tensor, cond: Optional[torch.Tensor], us
         us = _dev(us, "us")
     dev = states.device
     fc, k1 = w.fc, 4 * C + c_cond
-    hbuf = torch.empty(B, fc, H, W, device=dev)
+    fused = _gram_fits(fc, k1)      # layer-2 gradient fused into the step kernel, layer-1 gradient through gram_rows
+    hbuf = None if fused else torch.empty(B, fc, H, W, device=dev)
     dhbuf = torch.empty(B, fc, H, W, device=dev)
+    if fused:
+        w2g = torch.empty(C * fc + C, device=dev)
+        nws = lib().ncahip_dynca_step_bwd_w2_workspace(B, C, H, W, fc)
+        ws2 = torch.empty(nws, device=dev, dtype=torch.uint8)
     dy = torch.empty(B, 4 * C, H, W, device=dev)
     gw1, gb1 = torch.zeros(fc, k1, device=dev), torch.zeros(fc, device=dev)
     gw2, gb2 = torch.zeros(C, fc, device=dev), torch.zeros(C, device=dev)
@@ -307,22 +312,29 @@ def dynca_nsteps_backward(states: torch.Tensor, cond: Optional[torch.Tensor], us
         x_t = states[t]
         u_t = us[t].reshape(B, 1, H, W) if us is not None else philox_uniform(B, H, W, seed, step0 + t, dev)
         gx = torch.empty_like(g)
+        y = dynca_perceive(x_t, pad_mode)
+        if fused:
+            check(lib().ncahip_dynca_step_bwd_w2_f32(_p(x_t), _p(cond), _p(u_t), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C, H,
+                                                     W, fc, c_cond, PAD_MODES[pad_mode], update_rate, seed, step0 + t, _p(g),
+                                                     _p(gx), _p(dhbuf), _p(dy), _p(w2g), _p(ws2), nws, _stream()),
+                  "dynca_step_bwd_w2")
+            w1g, b1g = gram_rows(dhbuf, y, cond)         # HIP product with the cell axis as K (csrc/nca_gram.hip)
+            gw2 += w2g[:C * fc].view(C, fc); gb2 += w2g[C * fc:]; gw1 += w1g; gb1 += b1g
+            g = gx
+            if g_states is not None:
+                g = g + g_states[t]
+            continue
         check(lib().ncahip_dynca_step_bwd_f32(_p(x_t), _p(cond), _p(u_t), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C, H, W,
                                               fc, c_cond, PAD_MODES[pad_mode], update_rate, seed, step0 + t, _p(g), _p(gx),
                                               _p(hbuf), _p(dhbuf), _p(dy), _stream()), "dynca_step_bwd")
+        # shapes the HIP products do not cover (none the fused backward kernels reach today): library GEMMs on the device
         do = g * (u_t + update_rate).floor()
-        y = dynca_perceive(x_t, pad_mode)
-        if _gram_fits(C, fc) and _gram_fits(fc, k1):   # HIP products with the cell axis as K (csrc/nca_gram.hip)
-            w2g, b2g = gram_rows(do, hbuf)
-            w1g, b1g = gram_rows(dhbuf, y, cond)
-            gw2 += w2g; gb2 += b2g; gw1 += w1g; gb1 += b1g
-        else:                                           # shapes the fused backward does not reach anyway: library GEMMs
-            if cond is not None:
-                y = torch.cat([y, cond], dim=1)
-            gw2 += torch.matmul(do.transpose(0, 1).reshape(C, -1), hbuf.transpose(0, 1).reshape(fc, -1).t())
-            gb2 += do.sum(dim=(0, 2, 3))
-            gw1 += torch.matmul(dhbuf.transpose(0, 1).reshape(fc, -1), y.transpose(0, 1).reshape(k1, -1).t())
-            gb1 += dhbuf.sum(dim=(0, 2, 3))
+        if cond is not None:
+            y = torch.cat([y, cond], dim=1)
+        gw2 += torch.matmul(do.transpose(0, 1).reshape(C, -1), hbuf.transpose(0, 1).reshape(fc, -1).t())
+        gb2 += do.sum(dim=(0, 2, 3))
+        gw1 += torch.matmul(dhbuf.transpose(0, 1).reshape(fc, -1), y.transpose(0, 1).reshape(k1, -1).t())
+        gb1 += dhbuf.sum(dim=(0, 2, 3))
         g = gx
         if g_states is not None:
             g = g + g_states[t]
