@@ -45,8 +45,8 @@ __global__ __launch_bounds__(kGramThreads, 2) void gram_rows_kernel(const GramAr
     }
     // row r of the staged set: r < 16*MA_T -> A row r, else B row r - 16*MA_T (rows beyond the real counts read as zero)
     float pre[PER];
-    // Loads are unconditional (row and cell indices clamped into the tensors); rows beyond the real counts and cells beyond
-    // HW are zeroed when the chunk is written to LDS -- per-row predicates at load time cost an exec-mask dance per row.
+    // Loads are unconditional (row and cell indices clamped into the tensors) -- per-row predicates cost an exec-mask dance or
+    // a branch per row.
     // Buffer loads: the lane's cell offset is the only vector operand, every row's offset is a scalar (no vector address
     // arithmetic per load: it would sit in the same issue slots as the exact-f32 MFMAs).  Needs each batch item's rows
     // within 4 GiB, which the launcher checks.
@@ -76,16 +76,20 @@ __global__ __launch_bounds__(kGramThreads, 2) void gram_rows_kernel(const GramAr
             }
         }
     };
-    auto row_real = [&](int k) {
-        const int r = 4 * k + wave;
-        return k < 4 * MA_T ? r < a.ma : r - 16 * MA_T < nb;
-    };
     int c = blockIdx.x;
     if (c < total) issue(c);
     for (; c < total; c += gridDim.x) {
-        const bool in = (c % cpb) * kGramChunk + lane < HW;
+        // Rows beyond the real counts hold copies of the last real row: they only reach output rows / columns that are never
+        // written.  Cells beyond HW (last chunk of a batch item) would reach every output: zeroed here.
+        const int cell0 = (c % cpb) * kGramChunk;
+        if (cell0 + kGramChunk <= HW) {
 #pragma unroll
-        for (int k = 0; k < PER; ++k) lds[(4 * k + wave) * kGramLS + lane] = (in && row_real(k)) ? pre[k] : 0.0f;
+            for (int k = 0; k < PER; ++k) lds[(4 * k + wave) * kGramLS + lane] = pre[k];
+        } else {
+            const bool in = cell0 + lane < HW;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) lds[(4 * k + wave) * kGramLS + lane] = in ? pre[k] : 0.0f;
+        }
         __syncthreads();
         if (c + (int)gridDim.x < total) issue(c + gridDim.x);   // next chunk's rows fly during this chunk's products
         const float* const ar = lds + (16 * (ROWSPLIT ? wave * RT : 0) + ci) * kGramLS + g;
