@@ -38,6 +38,16 @@ with open("$out/${tag}_train_kernel_stats.txt", "w") as o:
         line = "%-120s calls %6s avg_ns %12s pct %6s" % (r["Name"][:120], r["Calls"], r["AverageNs"], r["Percentage"])
         print(line); o.write(line + "\n")
 PY
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/${tag}_dyprof -o stats --output-format csv -- python tools/bench_dynca_train.py > $out/${tag}_dyprof.log 2>&1 || { tail -20 $out/${tag}_dyprof.log; exit 1; }
+python - <<PY
+import csv, glob
+f = glob.glob("$out/${tag}_dyprof/**/*kernel_stats.csv", recursive=True)
+rows = list(csv.DictReader(open(f[0])))
+with open("$out/${tag}_dynca_train_kernel_stats.txt", "w") as o:
+    for r in rows[:14]:
+        line = "%-120s calls %6s avg_ns %12s pct %6s" % (r["Name"][:120], r["Calls"], r["AverageNs"], r["Percentage"])
+        print(line); o.write(line + "\n")
+PY
 if [ -f video-stylization-with-nca_amd/libncahip_stamps.so ]; then
   timeout -k 10 200 python tools/stamp_bwd.py > $out/${tag}_bwd_phases.txt 2>&1 || { tail -20 $out/${tag}_bwd_phases.txt; exit 1; }
   cat $out/${tag}_bwd_phases.txt
