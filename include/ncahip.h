@@ -121,7 +121,8 @@ int ncahip_dynca_step_bwd_f32(const float *x_t, const float *cond, const float *
 
 /* The same backward step with the layer-2 weight gradient fused in: h is kept in registers and never written; the kernel
  * accumulates dW2 = (g_next*mask) h^T and db2 = sum(g_next*mask) on MFMA (cell axis as K, operands transposed through LDS)
- * and gw2_out [C*fc + C] receives [dW2 | db2] of THIS step (overwritten; per-workgroup partials summed in fixed order).
+ * and gw2_out [C*fc + C] receives [dW2 | db2] of THIS step (accumulate = 0: overwritten, 1: added; per-workgroup partials
+ * summed in fixed order).
  * dh_out / dy_scratch / g_x as above; dW1 | db1 = ncahip_gram_rows_f32(dh_out, perception, cond).                     */
 size_t ncahip_dynca_step_bwd_w2_workspace(int B, int C, int H, int W, int fc);
 int ncahip_dynca_step_bwd_w2_f32(const float *x_t, const float *cond, const float *u,
@@ -129,7 +130,8 @@ int ncahip_dynca_step_bwd_w2_f32(const float *x_t, const float *cond, const floa
                                  int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
                                  float update_rate, uint64_t seed, uint64_t step,
                                  const float *g_next, float *g_x, float *dh_out, float *dy_scratch,
-                                 float *gw2_out, void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
+                                 float *gw2_out, int accumulate, void *workspace, size_t workspace_bytes,
+                                 ncahip_stream_t stream);
 
 /* Weight-gradient products of the DyNCA backward with the cell axis as K (replaces the library GEMMs over transposed
  * copies that autograd through dynca.py:127-128 amounts to):
@@ -138,10 +140,11 @@ int ncahip_dynca_step_bwd_w2_f32(const float *x_t, const float *cond, const floa
  * a [B, ma, HW]; the b rows come from two tensors, b1 [B, nb1, HW] then b2 [B, nb2, HW] (b2 may be NULL with nb2 = 0):
  * dW1 | db1 = gram(dh_out, perception, cond), dW2 | db2 = gram(g_next * mask, h_out).  Exact fp32 MFMA, per-workgroup
  * partials summed in a fixed order (deterministic).  Shapes: ma <= 128 with nb <= 80, or ma <= 32 with nb <= 128
- * (NCAHIP_ERANGE otherwise).  out holds ma*nb + ma floats and is overwritten.                                          */
+ * (NCAHIP_ERANGE otherwise).  out holds ma*nb + ma floats; accumulate = 0 overwrites it, 1 adds to it (the sum over the
+ * steps of a backward pass without a separate add per step).                                                          */
 size_t ncahip_gram_rows_workspace(int ma, int nb, int B, int HW);
 int ncahip_gram_rows_f32(const float *a, int ma, const float *b1, int nb1, const float *b2, int nb2, int B, int HW,
-                         float *out, void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
+                         float *out, int accumulate, void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * ConditionedNCA fused step                 EncoderConditioning/nca.py:181-195

@@ -504,6 +504,9 @@ def test_gram_rows(ops, ma, nb1, nb2, B, H, W):
     assert float((rsum.cpu().double() - rs_ref).abs().max()) <= 1e-5 * max(1.0, float(rs_ref.abs().max()))
     prod2, _ = ops.gram_rows(a.to(DEV), b1.to(DEV), None if b2 is None else b2.to(DEV))
     assert torch.equal(prod, prod2)                      # fixed summation order
+    acc = torch.ones(ma * (nb1 + nb2) + ma, device=DEV)   # accumulate mode adds to the caller's vector
+    ops.gram_rows(a.to(DEV), b1.to(DEV), None if b2 is None else b2.to(DEV), out=acc)
+    assert torch.allclose(acc[:ma * (nb1 + nb2)].view(ma, -1), prod + 1.0, rtol=0, atol=1e-5 * scale)
 
 
 @pytest.mark.parametrize("C,fc,cc,H,W", [(16, 128, 3, 24, 40), (12, 96, 0, 13, 36), (8, 64, 2, 9, 20)])
@@ -532,7 +535,7 @@ def test_dynca_bwd_fused_w2_matches_buffers(ops, C, fc, cc, H, W):
     nws = L.ncahip_dynca_step_bwd_w2_workspace(B, C, H, W, fc)
     ws = torch.empty(nws, device=DEV, dtype=torch.uint8)
     _capi.check(L.ncahip_dynca_step_bwd_w2_f32(P(x), P(cond), P(u), P(w.w1), P(w.b1), P(w.w2), P(w.b2), B, C, H, W, fc, cc, 2, 0.5,
-                                               0, 0, P(gn), P(gx2), P(dh2), P(dy2), P(out), P(ws), nws, None), "bwd_w2")
+                                               0, 0, P(gn), P(gx2), P(dh2), P(dy2), P(out), 0, P(ws), nws, None), "bwd_w2")
     assert torch.equal(gx, gx2) and torch.equal(dh, dh2)
     ref = torch.einsum("bihw,bjhw->ij", do.double().cpu(), hb.double().cpu())
     scale = max(1e-6, float(ref.abs().max()))

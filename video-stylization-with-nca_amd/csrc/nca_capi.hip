@@ -304,8 +304,8 @@ size_t ncahip_dynca_step_bwd_w2_workspace(int B, int C, int H, int W, int fc) {
 int ncahip_dynca_step_bwd_w2_f32(const float* x_t, const float* cond, const float* u, const float* w1, const float* b1,
                                  const float* w2, const float* b2, int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
                                  float update_rate, uint64_t seed, uint64_t step, const float* g_next, float* g_x,
-                                 float* dh_out, float* dy_scratch, float* gw2_out, void* workspace, size_t workspace_bytes,
-                                 ncahip_stream_t stream) {
+                                 float* dh_out, float* dy_scratch, float* gw2_out, int accumulate, void* workspace,
+                                 size_t workspace_bytes, ncahip_stream_t stream) {
     if (!g_next || !g_x || !dh_out || !dy_scratch || !gw2_out || !workspace) return fail(NCAHIP_EINVAL, "dynca step bwd_w2: null pointer");
     if (int rc = check_dynca(x_t, g_x, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
     if (g_next == g_x) return fail(NCAHIP_EINVAL, "dynca step bwd_w2: g_next and g_x must not alias");
@@ -318,7 +318,7 @@ int ncahip_dynca_step_bwd_w2_f32(const float* x_t, const float* cond, const floa
     a.gw2_ws = (float*)workspace;
     if (int rc = hip_result(nca_launch_dynca_step_bwd(a, (hipStream_t)stream), "dynca_step_bwd_w2")) return rc;
     return hip_result(nca_launch_reduce_rows((const float*)workspace, gw2_out, nca_dynca_bwd_grid(B, H, W), C * fc + C,
-                                             (hipStream_t)stream), "dynca_step_bwd_w2 reduce");
+                                             (hipStream_t)stream, accumulate != 0), "dynca_step_bwd_w2 reduce");
 }
 
 // ---- weight-gradient products of the DyNCA backward (cell axis as K) -------------------------------------------------
@@ -328,15 +328,15 @@ size_t ncahip_gram_rows_workspace(int ma, int nb, int B, int HW) {
 }
 
 int ncahip_gram_rows_f32(const float* a, int ma, const float* b1, int nb1, const float* b2, int nb2, int B, int HW,
-                         float* out, void* workspace, size_t workspace_bytes, ncahip_stream_t stream) {
+                         float* out, int accumulate, void* workspace, size_t workspace_bytes, ncahip_stream_t stream) {
     if (!a || !b1 || !out || !workspace || (nb2 > 0) != (b2 != nullptr)) return fail(NCAHIP_EINVAL, "gram_rows: null pointer");
     if (ma <= 0 || nb1 <= 0 || nb2 < 0 || B <= 0 || HW <= 0) return fail(NCAHIP_EINVAL, "gram_rows: bad size");
     const int nb = nb1 + nb2;
     if (!((ma <= 32 && nb <= 128) || (ma <= 128 && nb <= 80)))
         return fail(NCAHIP_ERANGE, "gram_rows: ma=%d nb=%d outside (<=32 x <=128) / (<=128 x <=80)", ma, nb);
     if (workspace_bytes < ncahip_gram_rows_workspace(ma, nb, B, HW)) return fail(NCAHIP_EINVAL, "gram_rows: workspace too small");
-    return hip_result(nca_launch_gram_rows(a, ma, b1, nb1, b2, nb2, B, HW, out, (float*)workspace, (hipStream_t)stream),
-                      "gram_rows");
+    return hip_result(nca_launch_gram_rows(a, ma, b1, nb1, b2, nb2, B, HW, out, (float*)workspace, (hipStream_t)stream,
+                                           accumulate != 0), "gram_rows");
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }

@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCon
 // dst[j] = sum_i src[i*m + j] (fixed order -> deterministic)
 // dst[j] = sum_i src[i][j]: a block owns 16 columns, its 16 row groups take every sixteenth row each, partial sums combined
 // in a fixed order (deterministic)
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int m) {
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int m, int accumulate) {
     __shared__ float part[16][17];
     const int c = threadIdx.x & 15, rg = threadIdx.x >> 4, j = blockIdx.x * 16 + c;
     float acc0 = 0.0f, acc1 = 0.0f;
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
         float v = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) v += part[k][c];
-        dst[j] = v;
+        dst[j] = accumulate ? dst[j] + v : v;
     }
 }
 // perception-weight partials [B*C*bpp][27] -> grad [C][27]
@@ -883,8 +883,8 @@ hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
     return hipErrorInvalidValue;
 }
 
-hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((m + 15) / 16), dim3(256), 0, st, src, dst, n, m);
+hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st, bool accumulate) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((m + 15) / 16), dim3(256), 0, st, src, dst, n, m, accumulate ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t nca_launch_reduce_wp(const float* part, float* dst, int B, int C, int H, int W, hipStream_t st) {

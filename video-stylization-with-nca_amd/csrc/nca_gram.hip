@@ -159,10 +159,10 @@ int nca_gram_grid(int B, int HW) {
     return (int)(total < 2L * cus ? total : 2L * cus);
 }
 
-// out[ma*nb + ma] = [products | row sums of A]; ws holds nca_gram_grid(B, HW) partials of that size.
+// out[ma*nb + ma] (+)= [products | row sums of A]; ws holds nca_gram_grid(B, HW) partials of that size.
 // Shapes: ma <= 128 with nb <= 80 (dW1-like: rows split over the waves), or ma <= 32 with nb <= 128 (dW2-like).
 hipError_t nca_launch_gram_rows(const float* a, int ma, const float* b1, int nb1, const float* b2, int nb2, int B, int HW,
-                                float* out, float* ws, hipStream_t st) {
+                                float* out, float* ws, hipStream_t st, bool accumulate) {
     const int nb = nb1 + nb2, grid = nca_gram_grid(B, HW);
     const GramArgs ga{a, b1, b2, ws, ma, nb1, nb2, B, HW};
     hipError_t e = hipErrorInvalidValue;
@@ -171,5 +171,5 @@ hipError_t nca_launch_gram_rows(const float* a, int ma, const float* b1, int nb1
     if (ma <= 32 && nb <= 128) e = ma <= 16 ? launch_gram<1, 2, false>(ga, grid, st) : launch_gram<2, 2, false>(ga, grid, st);
     else if (ma <= 128 && nb <= 80) e = ma <= 64 ? launch_gram<1, 5, true>(ga, grid, st) : launch_gram<2, 5, true>(ga, grid, st);
     if (e != hipSuccess) return e;
-    return nca_launch_reduce_rows(ws, out, grid, ma * nb + ma, st);
+    return nca_launch_reduce_rows(ws, out, grid, ma * nb + ma, st, accumulate);
 }

@@ -58,12 +58,12 @@ int nca_cond_bwd_slab_floats(int C, int hidden);
 int nca_cond_bwd_nslab();
 int nca_cond_bwd_nblk(int B, int C, int H, int W);
 hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& a, hipStream_t st);
-hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st);
+hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st, bool accumulate = false);   // dst (+)= column sums
 // nca_gram.hip: out[ma*nb + ma] = [sum_n a[i][n] * b[j][n] | sum_n a[i][n]] over all B*HW cells; b rows from two tensors
 int nca_dynca_bwd_grid(int B, int H, int W);   // workgroups of the DyNCA backward kernel (= partial slabs of its fused dW2)
 int nca_gram_grid(int B, int HW);
 hipError_t nca_launch_gram_rows(const float* a, int ma, const float* b1, int nb1, const float* b2, int nb2, int B, int HW,
-                                float* out, float* ws, hipStream_t st);
+                                float* out, float* ws, hipStream_t st, bool accumulate = false);
 hipError_t nca_launch_reduce_wp(const float* part, float* dst, int B, int C, int H, int W, hipStream_t st);
 
 // fused steps (nca_step_fwd.hip); hipErrorInvalidValue when no instantiation covers the shape

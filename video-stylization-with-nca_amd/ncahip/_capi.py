@@ -40,10 +40,10 @@ SIGNATURES = {
                                   _F, _F, _F, _U64, _U64, _P],
     "ncahip_philox_uniform_f32": [_P, _I, _I, _I, _U64, _U64, _P],
     "ncahip_dynca_step_bwd_w2_workspace": [_I, _I, _I, _I, _I],
-    "ncahip_dynca_step_bwd_w2_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P, _P, _P, _P, _P, _P,
+    "ncahip_dynca_step_bwd_w2_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P, _P, _P, _P, _P, _I, _P,
                                      ctypes.c_size_t, _P],
     "ncahip_gram_rows_workspace": [_I, _I, _I, _I],
-    "ncahip_gram_rows_f32": [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P, ctypes.c_size_t, _P],
+    "ncahip_gram_rows_f32": [_P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, ctypes.c_size_t, _P],
     "ncahip_cond_grow_bwd_workspace": [_I, _I, _I, _I, _I],
     "ncahip_cond_grow_bwd_f32": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F,
                                  _U64, _U64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P],

@@ -260,9 +260,10 @@ def cond_grow_backward(states: torch.Tensor, pre: torch.Tensor, goal: Optional[t
     return g
 
 
-def gram_rows(a: torch.Tensor, b1: torch.Tensor, b2: Optional[torch.Tensor] = None):
+def gram_rows(a: torch.Tensor, b1: torch.Tensor, b2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
     """(sum_cells a_i * b_j  [ma, nb],  sum_cells a_i  [ma]) over all B*H*W cells, for a [B,ma,H,W] and b = [b1 | b2] rows
-    [B,nb1,H,W] / [B,nb2,H,W]: the weight and bias gradient of a 1x1 conv layer (ncahip_gram_rows_f32)."""
+    [B,nb1,H,W] / [B,nb2,H,W]: the weight and bias gradient of a 1x1 conv layer (ncahip_gram_rows_f32).  `out` (a float32
+    device vector of ma*nb + ma elements) is ADDED to instead of a fresh result being returned."""
     a, b1 = _dev(a, "a"), _dev(b1, "b1")
     B, ma, H, W = a.shape
     nb1, nb2 = b1.shape[1], 0
@@ -270,11 +271,15 @@ def gram_rows(a: torch.Tensor, b1: torch.Tensor, b2: Optional[torch.Tensor] = No
         b2 = _dev(b2, "b2")
         nb2 = b2.shape[1]
     nb = nb1 + nb2
-    out = torch.empty(ma * nb + ma, device=a.device, dtype=torch.float32)
+    acc = out is not None
+    if acc:
+        assert out.is_cuda and out.dtype == torch.float32 and out.numel() == ma * nb + ma and out.is_contiguous()
+    else:
+        out = torch.empty(ma * nb + ma, device=a.device, dtype=torch.float32)
     nbytes = lib().ncahip_gram_rows_workspace(ma, nb, B, H * W)
     ws = torch.empty(nbytes, device=a.device, dtype=torch.uint8)
-    check(lib().ncahip_gram_rows_f32(_p(a), ma, _p(b1), nb1, _p(b2), nb2, B, H * W, _p(out), _p(ws), nbytes, _stream()),
-          "gram_rows")
+    check(lib().ncahip_gram_rows_f32(_p(a), ma, _p(b1), nb1, _p(b2), nb2, B, H * W, _p(out), int(acc), _p(ws), nbytes,
+                                     _stream()), "gram_rows")
     return out[:ma * nb].view(ma, nb), out[ma * nb:]
 
 
@@ -301,8 +306,9 @@ def dynca_nsteps_backward(states: torch.Tensor, cond: Optional[torch.Tensor], us
     fused = _gram_fits(fc, k1)      # layer-2 gradient fused into the step kernel, layer-1 gradient through gram_rows
     hbuf = None if fused else torch.empty(B, fc, H, W, device=dev)
     dhbuf = torch.empty(B, fc, H, W, device=dev)
-    if fused:
-        w2g = torch.empty(C * fc + C, device=dev)
+    if fused:      # [dW | db] accumulators of both layers: the entry points add each step's products in place
+        acc2 = torch.zeros(C * fc + C, device=dev)
+        acc1 = torch.zeros(fc * k1 + fc, device=dev)
         nws = lib().ncahip_dynca_step_bwd_w2_workspace(B, C, H, W, fc)
         ws2 = torch.empty(nws, device=dev, dtype=torch.uint8)
     dy = torch.empty(B, 4 * C, H, W, device=dev)
@@ -316,10 +322,9 @@ def dynca_nsteps_backward(states: torch.Tensor, cond: Optional[torch.Tensor], us
         if fused:
             check(lib().ncahip_dynca_step_bwd_w2_f32(_p(x_t), _p(cond), _p(u_t), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C, H,
                                                      W, fc, c_cond, PAD_MODES[pad_mode], update_rate, seed, step0 + t, _p(g),
-                                                     _p(gx), _p(dhbuf), _p(dy), _p(w2g), _p(ws2), nws, _stream()),
+                                                     _p(gx), _p(dhbuf), _p(dy), _p(acc2), 1, _p(ws2), nws, _stream()),
                   "dynca_step_bwd_w2")
-            w1g, b1g = gram_rows(dhbuf, y, cond)         # HIP product with the cell axis as K (csrc/nca_gram.hip)
-            gw2 += w2g[:C * fc].view(C, fc); gb2 += w2g[C * fc:]; gw1 += w1g; gb1 += b1g
+            gram_rows(dhbuf, y, cond, out=acc1)          # HIP product with the cell axis as K (csrc/nca_gram.hip)
             g = gx
             if g_states is not None:
                 g = g + g_states[t]
@@ -338,4 +343,7 @@ def dynca_nsteps_backward(states: torch.Tensor, cond: Optional[torch.Tensor], us
         g = gx
         if g_states is not None:
             g = g + g_states[t]
+    if fused:
+        gw1, gb1 = acc1[:fc * k1].view(fc, k1), acc1[fc * k1:]
+        gw2, gb2 = acc2[:C * fc].view(C, fc), acc2[C * fc:]
     return {"x0": g, "w1": gw1, "b1": gb1, "w2": gw2, "b2": gb2}
