@@ -587,6 +587,78 @@ def test_cond_step_shape_fuzz(ops):
         assert rel_err(xp2.cpu(), d2["x1"]) < REL_TOL, tag
 
 
+def test_cond_backward_shape_fuzz(ops):
+    """Seeded random shapes / channel counts (C below the kernels' padded widths included) / goal widths / alive settings for
+    ONE backward step against the oracle's autograd (conditioned_trainer.py:125-132).  Cases with a cell on the life
+    threshold are skipped (the mask's derivative is zero almost everywhere; on the threshold the two sides disagree)."""
+    rng = np.random.RandomState(int(os.environ.get("NCAHIP_FUZZ_SEED", "777")))
+    done = 0
+    for case in range(int(os.environ.get("NCAHIP_FUZZ_CASES", "8"))):
+        C = int(rng.choice([5, 8, 12, 13, 16]))
+        B = int(rng.randint(1, 3)); H = int(rng.randint(1, 25)); W = 4 * int(rng.randint(1, 11))
+        alive = int(rng.choice([-1, 3]))
+        gch = int(rng.choice([1, max(1, C - 4), C]))
+        gen = torch.Generator().manual_seed(3000 + case)
+        prm = rand_cond_prm(C, seed=case, out_scale=2.0)
+        x0 = torch.rand(B, C, H, W, generator=gen) * 1.4 - 0.2
+        if alive >= 0:
+            x0[:, alive] = torch.rand(B, H, W, generator=gen) * 0.4
+        goal = torch.randn(B, gch, H, W, generator=gen)
+        us = torch.rand(1, B, 1, H, W, generator=gen)
+        cot = torch.randn(B, C, H, W, generator=gen)
+        gpad = O.cond_pad_goal(goal, C)
+        if alive >= 0:
+            d = O.cond_step(x0, gpad, us[0], prm, alive, 0.1, 0.5, use_living_channel=True, return_all=True)
+            pools = [torch.nn.functional.max_pool2d(t[:, alive:alive + 1], 3, 1, 1) for t in (x0, d["x1"])]
+            if any(bool(_near_threshold(pl, 0.1, 1e-5).any()) for pl in pools):
+                continue
+            xT, dx0, dg, grads = O.cond_grow_loss_grads(x0, gpad, list(us), prm, alive, 0.1, 0.5, cot)
+        else:
+            xT, dx0, dg, grads = _oracle_noalive_grads(x0, goal, us, prm, cot, C)
+        w = cond_w(ops, prm, x0.to(DEV))
+        _, states, pre = ops.cond_grow(x0.to(DEV), 1, goal.to(DEV), us.to(DEV), w, alive, keep_history=True)
+        gr = ops.cond_grow_backward(states, pre, goal.to(DEV), us.to(DEV), w, cot.to(DEV), 1, alive)
+        tag = (case, C, B, H, W, alive, gch)
+        assert _grad_close(gr["x0"], dx0), tag
+        assert _grad_close(gr["goal"], dg[:, C - gch:]), tag
+        assert _grad_close(gr["wp"].view(3 * C, 1, 3, 3), grads["perception_net.weight"]), tag
+        for k, n in (("w1", "update_net.out.0.weight"), ("w2", "update_net.out.2.weight"), ("w3", "update_net.out.4.weight")):
+            assert _grad_close(gr[k], grads[n][:, :, 0, 0]), (k,) + tag
+        assert _grad_close(gr["b1"], grads["update_net.out.0.bias"]) and _grad_close(gr["b2"], grads["update_net.out.2.bias"]), tag
+        done += 1
+    assert done > 0
+
+
+def test_dynca_backward_shape_fuzz(ops):
+    """Seeded random shapes / pad modes / conditioning widths / layer widths for the DyNCA backward (two steps) against the
+    oracle's autograd: the fused layer-2 product, the cell-axis-as-K layer-1 product, the vectorised and the border-band
+    stencil adjoint all see odd sizes here."""
+    rng = np.random.RandomState(int(os.environ.get("NCAHIP_FUZZ_SEED", "888")))
+    pads = ["replicate", "circular", "reflect", "constant"]
+    for case in range(int(os.environ.get("NCAHIP_FUZZ_CASES", "8"))):
+        C, fc = [(12, 96), (16, 128), (8, 64), (16, 96), (5, 40)][int(rng.randint(0, 5))]
+        cc = int(rng.choice([0, 2, 3]))
+        B = int(rng.randint(1, 3)); H = int(rng.randint(2, 30)); W = int(rng.randint(2, 45))
+        if rng.rand() < 0.5:
+            W = max(4, (W // 4) * 4)
+        pad = pads[int(rng.randint(0, 4))]
+        gen = torch.Generator().manual_seed(4000 + case)
+        prm = rand_dynca_prm(C, fc, cc, seed=case, scale=3.0)
+        x0 = torch.rand(B, C, H, W, generator=gen) - 0.5
+        cond = torch.rand(B, cc, H, W, generator=gen) if cc else None
+        us = torch.rand(2, B, 1, H, W, generator=gen)
+        cot = torch.randn(B, C, H, W, generator=gen)
+        xT, dx0, grads = O.dynca_nsteps_loss_grads(x0, cond, list(us), prm, pad, 0.5, cot)
+        w = dyn_w(ops, prm, x0.to(DEV))
+        cd = None if cond is None else cond.to(DEV)
+        _, states = ops.dynca_nsteps(x0.to(DEV), 2, cd, us.to(DEV), w, pad, 0.5, keep_history=True)
+        gr = ops.dynca_nsteps_backward(states, cd, us.to(DEV), w, cot.to(DEV), None, 2, pad, 0.5)
+        tag = (case, C, fc, cc, B, H, W, pad)
+        assert _grad_close(gr["x0"], dx0), tag
+        assert _grad_close(gr["w1"], grads["w1.weight"][:, :, 0, 0]) and _grad_close(gr["b1"], grads["w1.bias"]), tag
+        assert _grad_close(gr["w2"], grads["w2.weight"][:, :, 0, 0]) and _grad_close(gr["b2"], grads["w2.bias"]), tag
+
+
 def test_dynca_step_shape_fuzz(ops):
     """Seeded random shapes / pad modes / conditioning widths for the DyNCA step (dynca.py:117-138)."""
     rng = np.random.RandomState(int(os.environ.get("NCAHIP_FUZZ_SEED", "4321")))
