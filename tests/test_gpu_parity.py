@@ -21,7 +21,8 @@ def ops(request):
     assert torch.cuda.is_available(), "gpu tests need the MI355X"
     from ncahip import ops as _ops
     _ops.selftest()
-    _ops.force_generic({"fast": 0, "generic": 1, "wave": 2}[request.param])
+    _ops._test_mode = {"fast": 0, "generic": 1, "wave": 2}[request.param]
+    _ops.force_generic(_ops._test_mode)
     yield _ops
     _ops.force_generic(False)
 
@@ -585,6 +586,29 @@ def test_cond_step_shape_fuzz(ops):
         d2 = O.cond_step(x2ref, gpad, u2, prm, max(alive, 0), 0.1, rate, use_living_channel=alive >= 0, return_all=True)
         xp2, _ = ops.cond_step(xp, pre, None if goal is None else goal.to(DEV), u2.to(DEV), w, alive, 0.1, rate)
         assert rel_err(xp2.cpu(), d2["x1"]) < REL_TOL, tag
+
+
+def test_cond_large_plane_tile_vs_generic(ops):
+    """Planes of 2^22 cells and more (plane bytes >= 2^24): the tile kernels' in-plane byte offsets must not go through 24-bit
+    multiplies.  The CPU oracle is out of reach at this size; the any-shape kernels (oracle-checked at every small shape)
+    are the reference here.  1 x 12 x 1024 x 4096, two steps, in-kernel Philox mask."""
+    if ops._test_mode != 0:
+        pytest.skip("compares the two kernel families itself; run once")
+    B, C, H, W = 1, 12, 1024, 4096
+    gen = torch.Generator().manual_seed(9)
+    prm = rand_cond_prm(C, seed=9, out_scale=2.0)
+    x = torch.rand(B, C, H, W, generator=gen).to(DEV)
+    goal = (torch.randn(B, 8, H, W, generator=gen) * 0.5).to(DEV)
+    w = cond_w(ops, prm, x)
+    outs = []
+    try:
+        for force in (0, 1):
+            ops.force_generic(force)
+            o, _, _ = ops.cond_grow(x, 2, goal, None, w, 3, seed=7)
+            outs.append(o)
+    finally:
+        ops.force_generic(ops._test_mode)
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-6 * max(1.0, float(outs[1].abs().max()))
 
 
 def test_cond_backward_shape_fuzz(ops):

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""One-off sanity at sizes far above the parity tests: the tile kernels (32-bit in-plane offsets, XCD-chunked tile walks)
+against the generic any-shape kernels on the same inputs, forward steps of both models, 1 x 16 x 2048 x 2048."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "video-stylization-with-nca_amd")]
+import torch
+import bench
+from ncahip import ops
+
+dev = "cuda"
+B, C, H, W = 1, 16, 2048, 2048
+gen = torch.Generator().manual_seed(0)
+prm = bench.make_weights(gen)
+x = torch.rand(B, C, H, W, generator=gen).to(dev)
+goal = (torch.randn(B, 12, H, W, generator=gen) * 0.5).to(dev)
+w = ops.CondWeights(prm["perception_net.weight"], prm["update_net.out.0.weight"], prm["update_net.out.0.bias"],
+                    prm["update_net.out.2.weight"], prm["update_net.out.2.bias"], prm["update_net.out.4.weight"], x)
+L = ops.lib()
+outs = []
+for force in (0, 1):
+    L.ncahip_debug_force_generic(force)
+    o, _, _ = ops.cond_grow(x, 3, goal, None, w, 3, seed=7)
+    outs.append(o)
+L.ncahip_debug_force_generic(0)
+err = float((outs[0] - outs[1]).abs().max())
+print("cond 1x16x2048^2, 3 steps: tile kernels vs generic kernels max abs diff %.3e" % err)
+assert err < 1e-5
+# a 5 x 5 window around each corner and the centre against the CPU oracle would need the whole grid; the generic kernel is
+# itself checked against the oracle at every parity-test shape
+k1 = 4 * C + 3
+dw = ops.DyncaWeights(torch.randn(128, k1, generator=gen) * (0.5 / k1 ** 0.5), torch.randn(128, generator=gen) * 0.1,
+                      torch.randn(C, 128, generator=gen) * (0.02 / 128 ** 0.5), torch.zeros(C), torch.zeros(1, device=dev))
+xd = (torch.rand(B, C, H, W, generator=gen) - 0.5).to(dev)
+cond = (torch.rand(B, 3, H, W, generator=gen) * 2 - 1).to(dev)
+a, _ = ops.dynca_nsteps(xd, 2, cond, None, dw, "circular", 0.5, seed=3)
+# unaligned view of the same problem: one column less -> per-element path of the same kernel family
+b_, _ = ops.dynca_nsteps(xd[..., :-1].contiguous(), 2, cond[..., :-1].contiguous(), None, dw, "replicate", 0.5, seed=3)
+print("dynca 1x16x2048^2 ok:", bool(torch.isfinite(a).all()), bool(torch.isfinite(b_).all()))
+print("large shapes ok")
+
+# ---- backward at 2048^2: a live patch near the bottom-right corner, everything else dead.  The alive mask zeroes dead cells
+# in both directions, so every gradient must equal the one of the 192 x 192 crop that contains the patch and the same two
+# image borders (the crop's other two borders see zero padding where the full image has dead cells).
+Tn, S, c0 = 2, 2048, 2048 - 192
+g2 = torch.Generator().manual_seed(5)
+xc = torch.zeros(1, C, 192, 192)
+xc[:, :, 60:150, 70:160] = torch.rand(1, C, 90, 90, generator=g2)
+gc = torch.randn(1, 12, 192, 192, generator=g2) * 0.5
+uc = torch.rand(Tn, 1, 1, 192, 192, generator=g2)
+cc_ = torch.randn(1, C, 192, 192, generator=g2)
+def embed(t, fill=0.0):
+    full = torch.full(t.shape[:-2] + (S, S), fill)
+    full[..., c0:, c0:] = t
+    return full
+res = []
+for name, xx, gg, uu, ct in (("crop", xc, gc, uc, cc_), ("full", embed(xc), embed(gc), embed(uc, 0.5), embed(cc_))):
+    xx, gg, uu, ct = xx.to(dev), gg.to(dev), uu.to(dev), ct.to(dev)
+    w2 = ops.CondWeights(prm["perception_net.weight"], prm["update_net.out.0.weight"], prm["update_net.out.0.bias"],
+                         prm["update_net.out.2.weight"], prm["update_net.out.2.bias"], prm["update_net.out.4.weight"], xx)
+    out, states, pre = ops.cond_grow(xx, Tn, gg, uu, w2, 3, keep_history=True)
+    gr = ops.cond_grow_backward(states, pre, gg, uu, w2, ct, Tn, 3)
+    res.append((out, gr))
+(oc, gcr), (of, gfr) = res
+def rel(a, b):
+    return float((a - b).abs().max()) / max(1e-6, float(b.abs().max()))
+print("forward  crop vs full window: %.2e" % rel(of[..., c0:, c0:], oc))
+print("dL/dx0   crop vs full window: %.2e   outside the window: %.2e" % (rel(gfr["x0"][..., c0:, c0:], gcr["x0"]),
+      float(gfr["x0"][..., :c0, :].abs().max())))
+for k in ("w1", "w2", "w3", "b1", "b2", "wp", "goal"):
+    a = gfr[k][..., c0:, c0:] if k == "goal" else gfr[k]
+    print("  d%-4s %.2e" % (k, rel(a, gcr[k])))
+    assert rel(a, gcr[k]) < 2e-4, k
+assert rel(of[..., c0:, c0:], oc) < 1e-5 and rel(gfr["x0"][..., c0:, c0:], gcr["x0"]) < 2e-4
+print("large-shape backward ok")

@@ -218,6 +218,9 @@ struct StBF16 {
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk2(v[0], v[1]), pk2(v[2], v[3])}, r, (int)voff, (int)soff, AUX);
     }
 };
+// channel index * plane bytes: a full 32-bit multiply -- plane bytes reach 2^24 at 2048 x 2048 fp32 cells, beyond v_mul_u32_u24
+// (a handful per tile; the dispatch guards keep C * H * W * 4 below 2^32)
+__device__ __forceinline__ unsigned nca_mul_u32(unsigned a, unsigned b) { return a * b; }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t nca_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
 }
@@ -315,7 +318,7 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
 #pragma unroll
             for (int k = 0; k < CP / 2; ++k) {
                 if (EXACT) R.xf[k] = ST::template ld4<kAuxCoherent>(rx, vox, 2u * k * plane4);
-                else R.xf[k] = ST::template ld4<kAuxCoherent>(rx, pix4 + __umul24((unsigned)min(2 * k + hl, C - 1), plane4), 0u);
+                else R.xf[k] = ST::template ld4<kAuxCoherent>(rx, pix4 + nca_mul_u32((unsigned)min(2 * k + hl, C - 1), plane4), 0u);
             }
         }
         if (GOAL && has_goal) {
@@ -325,7 +328,7 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
                 const int d = 2 * k - gch0;   // uniform
                 if (EXACT) R.gf[k] = ST::template ld4<0>(rg, d >= 0 ? vox : pix4, d >= 0 ? (unsigned)d * plane4 : 0u);
                 else   // C < CP: the padded channels 2k + hl >= C must not index past the goal tensor's last plane
-                    R.gf[k] = ST::template ld4<0>(rg, pix4 + __umul24((unsigned)min(max(d + hl, 0), a.goal_ch - 1), plane4), 0u);
+                    R.gf[k] = ST::template ld4<0>(rg, pix4 + nca_mul_u32((unsigned)min(max(d + hl, 0), a.goal_ch - 1), plane4), 0u);
             }
         }
     }
@@ -333,12 +336,12 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
         const int hr = ci >> 1, hgy = t.ty0 - 1 + hr, hgx = (ci & 1) ? t.tx0 + WTW : t.tx0 - 1;
         const bool hok = ci < 12 && (!chk || (hgy >= 0 && hgy < H && hgx >= 0 && hgx < W));
         const unsigned pix4 = hok ? (unsigned)(__mul24(hgy, W) + hgx) * SB : 0u;
-        const unsigned voh = pix4 + __umul24((unsigned)q4, plane4);   // channel 4k + q4
+        const unsigned voh = pix4 + nca_mul_u32((unsigned)q4, plane4);   // channel 4k + q4
         if (STATE) {
 #pragma unroll
             for (int k = 0; k < CP / 4; ++k) {
                 if (EXACT) R.xh[k] = ST::template ld1<kAuxCoherent>(rx, voh, 4u * k * plane4);
-                else R.xh[k] = ST::template ld1<kAuxCoherent>(rx, pix4 + __umul24((unsigned)min(4 * k + q4, C - 1), plane4), 0u);
+                else R.xh[k] = ST::template ld1<kAuxCoherent>(rx, pix4 + nca_mul_u32((unsigned)min(4 * k + q4, C - 1), plane4), 0u);
             }
         }
         if (GOAL && has_goal) {
@@ -347,7 +350,7 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
                 const int d = 4 * k - gch0;   // uniform
                 if (EXACT && d >= 0) R.gh[k] = ST::template ld1<0>(rg, voh, (unsigned)d * plane4);
                 else   // (C < CP: clamp to the goal tensor's last plane, as above)
-                    R.gh[k] = ST::template ld1<0>(rg, pix4 + __umul24((unsigned)min(max(4 * k + q4 - gch0, 0), a.goal_ch - 1), plane4), 0u);
+                    R.gh[k] = ST::template ld1<0>(rg, pix4 + nca_mul_u32((unsigned)min(max(4 * k + q4 - gch0, 0), a.goal_ch - 1), plane4), 0u);
             }
         }
     }
@@ -1057,7 +1060,7 @@ __device__ __forceinline__ void store_tile(const NcaCondArgs& a, const WTile& t,
     const int gy = t.ty0 + row, gx = t.tx0 + 4 * ff;
     const bool ok = !CHECK || (gy < H && gx + 3 < W);
     const __amdgpu_buffer_rsrc_t ro = nca_rsrc(reinterpret_cast<char*>(a.x_out) + (size_t)t.b * C * plane * SB);
-    const unsigned vo = (ok ? (unsigned)(__mul24(gy, W) + gx) * SB : 0u) + __umul24((unsigned)q4, plane4);
+    const unsigned vo = (ok ? (unsigned)(__mul24(gy, W) + gx) * SB : 0u) + nca_mul_u32((unsigned)q4, plane4);
     wave_sync();
 #pragma unroll
     for (int k = 0; k < CP / 4; ++k) {
