@@ -73,3 +73,39 @@ for k in ("w1", "w2", "w3", "b1", "b2", "wp", "goal"):
     assert rel(a, gcr[k]) < 2e-4, k
 assert rel(of[..., c0:, c0:], oc) < 1e-5 and rel(gfr["x0"][..., c0:, c0:], gcr["x0"]) < 2e-4
 print("large-shape backward ok")
+
+# ---- DyNCA at 2048^2 by periodicity: with circular padding an 8 x 8 tiling of a 256^2 problem (state, conditioning, uniforms)
+# evolves into the tiling of the 256^2 result; dL/dx0 tiles likewise, and the weight gradients are 64 x the small ones when the
+# cotangent is tiled too.
+g3 = torch.Generator().manual_seed(11)
+xs = (torch.rand(1, C, 256, 256, generator=g3) - 0.5)
+cs = torch.rand(1, 3, 256, 256, generator=g3) * 2 - 1
+us_ = torch.rand(2, 1, 1, 256, 256, generator=g3)
+cts = torch.randn(1, C, 256, 256, generator=g3)
+tile = lambda t: t.repeat(*([1] * (t.dim() - 2)), 8, 8)
+rs = []
+for name, f in (("small", lambda t: t), ("tiled", tile)):
+    xx, cn, uu, ct = f(xs).to(dev), f(cs).to(dev), f(us_).to(dev), f(cts).to(dev)
+    out, states = ops.dynca_nsteps(xx, 2, cn, uu, dw, "circular", 0.5, keep_history=True)
+    gr = ops.dynca_nsteps_backward(states, cn, uu, dw, ct, None, 2, "circular", 0.5)
+    rs.append((out.cpu(), {k: v.cpu() for k, v in gr.items()}))
+(os_, gs), (ot, gt) = rs
+print("dynca forward  tiled vs tile(small): %.2e" % rel(ot, tile(os_)))
+print("dynca dL/dx0   tiled vs tile(small): %.2e" % rel(gt["x0"], tile(gs["x0"])))
+assert rel(ot, tile(os_)) < 1e-5 and rel(gt["x0"], tile(gs["x0"])) < 2e-4
+for k in ("w1", "b1", "w2", "b2"):
+    print("  d%-3s tiled vs 64 x small: %.2e" % (k, rel(gt[k], 64.0 * gs[k])))
+    assert rel(gt[k], 64.0 * gs[k]) < 2e-4, k
+print("large-shape dynca ok")
+
+# ---- bf16-storage ConditionedNCA at 2048^2: live patch / dead elsewhere, against the 192^2 crop (bit-exact: same arithmetic)
+ob = []
+for xx, gg, uu in ((xc, gc, uc), (embed(xc), embed(gc), embed(uc, 0.5))):
+    xx, gg, uu = xx.bfloat16().to(dev), gg.bfloat16().to(dev), uu.to(dev)
+    w2 = ops.CondWeights(prm["perception_net.weight"], prm["update_net.out.0.weight"], prm["update_net.out.0.bias"],
+                         prm["update_net.out.2.weight"], prm["update_net.out.2.bias"], prm["update_net.out.4.weight"], xx)
+    o, _, _ = ops.cond_grow(xx, 3, gg, uu[:1].repeat(3, 1, 1, 1, 1), w2, 3)
+    ob.append(o.float())
+print("bf16 forward crop vs full window: %.2e   outside: %.2e" % (rel(ob[1][..., c0:, c0:], ob[0]), float(ob[1][..., :c0, :].abs().max())))
+assert rel(ob[1][..., c0:, c0:], ob[0]) == 0.0
+print("large-shape bf16 ok")
