@@ -588,6 +588,55 @@ def test_cond_step_shape_fuzz(ops):
         assert rel_err(xp2.cpu(), d2["x1"]) < REL_TOL, tag
 
 
+def test_many_small_items_and_side_stream(ops):
+    """B = 67 grids of 20 x 20 (more super-tiles than workgroup slots per XCD chunk, ragged tile edges, batch offsets) for the
+    forward and backward of both models against the oracle, launched on a non-default stream."""
+    B, H, W = 67, 20, 20
+    gen = torch.Generator().manual_seed(67)
+    side = torch.cuda.Stream()
+    # ConditionedNCA, C = 16, two steps
+    C = 16
+    prm = rand_cond_prm(C, seed=4, out_scale=2.0)
+    x0 = torch.rand(B, C, H, W, generator=gen) * 1.4 - 0.2
+    x0[:, 3] = torch.rand(B, H, W, generator=gen) * 0.4
+    goal = torch.randn(B, 12, H, W, generator=gen)
+    us = torch.rand(2, B, 1, H, W, generator=gen)
+    cot = torch.randn(B, C, H, W, generator=gen)
+    gpad = O.cond_pad_goal(goal, C)
+    ref = O.cond_grow(x0, gpad, list(us), prm, 3)
+    w = cond_w(ops, prm, x0.to(DEV))
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out, states, pre = ops.cond_grow(x0.to(DEV), 2, goal.to(DEV), us.to(DEV), w, 3, keep_history=True)
+        gr = ops.cond_grow_backward(states, pre, goal.to(DEV), us.to(DEV), w, cot.to(DEV), 2, 3)
+    side.synchronize()
+    assert rel_err(out.cpu(), ref) < REL_TOL
+    d1 = O.cond_step(x0, gpad, us[0], prm, 3, 0.1, 0.5, use_living_channel=True, return_all=True)
+    pools = [torch.nn.functional.max_pool2d(t[:, 3:4], 3, 1, 1) for t in (x0, d1["x1"], d1["x2"], ref)]
+    if not any(bool(_near_threshold(pl, 0.1, 1e-5).any()) for pl in pools):
+        _, dx0, dg, grads = O.cond_grow_loss_grads(x0, gpad, list(us), prm, 3, 0.1, 0.5, cot)
+        assert _grad_close(gr["x0"], dx0) and _grad_close(gr["goal"], dg[:, C - 12:])
+        assert _grad_close(gr["w1"], grads["update_net.out.0.weight"][:, :, 0, 0])
+        assert _grad_close(gr["wp"].view(3 * C, 1, 3, 3), grads["perception_net.weight"])
+    # DyNCA, C = 12, fc = 96, reflect padding, two steps
+    C, fc, cc = 12, 96, 3
+    dp = rand_dynca_prm(C, fc, cc, seed=6, scale=3.0)
+    xd = torch.rand(B, C, H, W, generator=gen) - 0.5
+    cond = torch.rand(B, cc, H, W, generator=gen)
+    ud = torch.rand(2, B, 1, H, W, generator=gen)
+    cd_ = torch.randn(B, C, H, W, generator=gen)
+    xT, dx0, grads = O.dynca_nsteps_loss_grads(xd, cond, list(ud), dp, "reflect", 0.5, cd_)
+    dwt = dyn_w(ops, dp, xd.to(DEV))
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        outd, st = ops.dynca_nsteps(xd.to(DEV), 2, cond.to(DEV), ud.to(DEV), dwt, "reflect", 0.5, keep_history=True)
+        gd = ops.dynca_nsteps_backward(st, cond.to(DEV), ud.to(DEV), dwt, cd_.to(DEV), None, 2, "reflect", 0.5)
+    side.synchronize()
+    assert rel_err(outd.cpu(), xT) < REL_TOL
+    assert _grad_close(gd["x0"], dx0) and _grad_close(gd["w1"], grads["w1.weight"][:, :, 0, 0]) and _grad_close(gd["w2"], grads["w2.weight"][:, :, 0, 0])
+    assert _grad_close(gd["b1"], grads["w1.bias"]) and _grad_close(gd["b2"], grads["w2.bias"])
+
+
 def test_cond_large_plane_tile_vs_generic(ops):
     """Planes of 2^22 cells and more (plane bytes >= 2^24): the tile kernels' in-plane byte offsets must not go through 24-bit
     multiplies.  The CPU oracle is out of reach at this size; the any-shape kernels (oracle-checked at every small shape)
