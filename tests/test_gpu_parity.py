@@ -387,13 +387,13 @@ def test_cond_grow_backward_vs_oracle_autograd(ops, C, shape, gch, alive, Tn):
     assert _grad_close(gr["b1"], grads["update_net.out.0.bias"]) and _grad_close(gr["b2"], grads["update_net.out.2.bias"])
 
 
-def _oracle_noalive_grads(x0, goal, us, prm, cot, C):
+def _oracle_noalive_grads(x0, goal, us, prm, cot, C, rate=0.5):
     x0 = x0.clone().requires_grad_(True)
-    g = O.cond_pad_goal(goal, C).clone().requires_grad_(True)
+    g = (O.cond_pad_goal(goal, C) if goal is not None else torch.zeros_like(x0)).clone().requires_grad_(True)
     p = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
     x = x0
     for u in us:
-        x = O.cond_step(x, g, u, p, 0, 0.1, 0.5, use_living_channel=False)
+        x = O.cond_step(x, g, u, p, 0, 0.1, rate, use_living_channel=False)
     (x * cot).sum().backward()
     return x.detach(), x0.grad, g.grad, {k: v.grad for k, v in p.items()}
 
@@ -669,31 +669,37 @@ def test_cond_backward_shape_fuzz(ops):
     for case in range(int(os.environ.get("NCAHIP_FUZZ_CASES", "8"))):
         C = int(rng.choice([5, 8, 12, 13, 16]))
         B = int(rng.randint(1, 3)); H = int(rng.randint(1, 25)); W = 4 * int(rng.randint(1, 11))
-        alive = int(rng.choice([-1, 3]))
-        gch = int(rng.choice([1, max(1, C - 4), C]))
+        alive = int(rng.choice([-1, 3, min(4, C - 1)]))
+        gch = int(rng.choice([0, 1, max(1, C - 4), C]))
+        rate = float(rng.choice([0.5, 0.5, 0.0, 1.0]))
+        philox = bool(rng.rand() < 0.4)            # in-kernel mask: the oracle gets the same uniforms from ncahip_philox_uniform
         gen = torch.Generator().manual_seed(3000 + case)
         prm = rand_cond_prm(C, seed=case, out_scale=2.0)
         x0 = torch.rand(B, C, H, W, generator=gen) * 1.4 - 0.2
         if alive >= 0:
             x0[:, alive] = torch.rand(B, H, W, generator=gen) * 0.4
-        goal = torch.randn(B, gch, H, W, generator=gen)
+        goal = torch.randn(B, gch, H, W, generator=gen) if gch else None
         us = torch.rand(1, B, 1, H, W, generator=gen)
+        if philox:
+            us = ops.philox_uniform(B, H, W, 17 + case, 5, DEV).cpu()[None]
         cot = torch.randn(B, C, H, W, generator=gen)
-        gpad = O.cond_pad_goal(goal, C)
+        gpad = O.cond_pad_goal(goal, C) if gch else torch.zeros_like(x0)
         if alive >= 0:
-            d = O.cond_step(x0, gpad, us[0], prm, alive, 0.1, 0.5, use_living_channel=True, return_all=True)
+            d = O.cond_step(x0, gpad, us[0], prm, alive, 0.1, rate, use_living_channel=True, return_all=True)
             pools = [torch.nn.functional.max_pool2d(t[:, alive:alive + 1], 3, 1, 1) for t in (x0, d["x1"])]
             if any(bool(_near_threshold(pl, 0.1, 1e-5).any()) for pl in pools):
                 continue
-            xT, dx0, dg, grads = O.cond_grow_loss_grads(x0, gpad, list(us), prm, alive, 0.1, 0.5, cot)
+            xT, dx0, dg, grads = O.cond_grow_loss_grads(x0, gpad, list(us), prm, alive, 0.1, rate, cot)
         else:
-            xT, dx0, dg, grads = _oracle_noalive_grads(x0, goal, us, prm, cot, C)
+            xT, dx0, dg, grads = _oracle_noalive_grads(x0, gpad[:, C - gch:] if gch else None, us, prm, cot, C, rate)
         w = cond_w(ops, prm, x0.to(DEV))
-        _, states, pre = ops.cond_grow(x0.to(DEV), 1, goal.to(DEV), us.to(DEV), w, alive, keep_history=True)
-        gr = ops.cond_grow_backward(states, pre, goal.to(DEV), us.to(DEV), w, cot.to(DEV), 1, alive)
-        tag = (case, C, B, H, W, alive, gch)
+        gd, ud = (None if goal is None else goal.to(DEV)), (None if philox else us.to(DEV))
+        _, states, pre = ops.cond_grow(x0.to(DEV), 1, gd, ud, w, alive, fire_rate=rate, seed=17 + case, step0=5, keep_history=True)
+        gr = ops.cond_grow_backward(states, pre, gd, ud, w, cot.to(DEV), 1, alive, fire_rate=rate, seed=17 + case, step0=5)
+        tag = (case, C, B, H, W, alive, gch, rate, philox)
         assert _grad_close(gr["x0"], dx0), tag
-        assert _grad_close(gr["goal"], dg[:, C - gch:]), tag
+        if gch:
+            assert _grad_close(gr["goal"], dg[:, C - gch:]), tag
         assert _grad_close(gr["wp"].view(3 * C, 1, 3, 3), grads["perception_net.weight"]), tag
         for k, n in (("w1", "update_net.out.0.weight"), ("w2", "update_net.out.2.weight"), ("w3", "update_net.out.4.weight")):
             assert _grad_close(gr[k], grads[n][:, :, 0, 0]), (k,) + tag
