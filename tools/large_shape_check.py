@@ -109,3 +109,28 @@ for xx, gg, uu in ((xc, gc, uc), (embed(xc), embed(gc), embed(uc, 0.5))):
 print("bf16 forward crop vs full window: %.2e   outside: %.2e" % (rel(ob[1][..., c0:, c0:], ob[0]), float(ob[1][..., :c0, :].abs().max())))
 assert rel(ob[1][..., c0:, c0:], ob[0]) == 0.0
 print("large-shape bf16 ok")
+
+# ---- DyNCA C = 32 (configs[4]) with fc = 256 (two launches per step) and fc = 128 at 512^2, again by periodicity (4 x 4 tiling
+# of 128^2), f32 and bf16 storage
+C3 = 32
+for fc3 in (128, 256):
+    k3 = 4 * C3 + 3
+    g4 = torch.Generator().manual_seed(fc3)
+    dw3 = ops.DyncaWeights(torch.randn(fc3, k3, generator=g4) * (0.5 / k3 ** 0.5), torch.randn(fc3, generator=g4) * 0.1,
+                           torch.randn(C3, fc3, generator=g4) * (0.3 / fc3 ** 0.5), torch.randn(C3, generator=g4) * 0.02,
+                           torch.zeros(1, device=dev))
+    x3 = torch.rand(1, C3, 128, 128, generator=g4) - 0.5
+    c3 = torch.rand(1, 3, 128, 128, generator=g4) * 2 - 1
+    u3 = torch.rand(3, 1, 1, 128, 128, generator=g4)
+    t4 = lambda t: t.repeat(*([1] * (t.dim() - 2)), 4, 4)
+    o_s, _ = ops.dynca_nsteps(x3.to(dev), 3, c3.to(dev), u3.to(dev), dw3, "circular", 0.5)
+    o_t, _ = ops.dynca_nsteps(t4(x3).to(dev), 3, t4(c3).to(dev), t4(u3).to(dev), dw3, "circular", 0.5)
+    e = rel(o_t.cpu(), t4(o_s.cpu()))
+    print("dynca C=32 fc=%d 512^2 tiled vs tile(128^2): %.2e" % (fc3, e))
+    assert e < 1e-5
+    if fc3 == 128:
+        ob_s, _ = ops.dynca_nsteps(x3.bfloat16().to(dev), 3, c3.to(dev), u3.to(dev), dw3, "circular", 0.5)
+        ob_t, _ = ops.dynca_nsteps(t4(x3).bfloat16().to(dev), 3, t4(c3).to(dev), t4(u3).to(dev), dw3, "circular", 0.5)
+        assert torch.equal(ob_t.float().cpu(), t4(ob_s.float().cpu()))
+        print("dynca C=32 bf16 storage tiled == tile(small)")
+print("large-shape C=32 ok")
