@@ -24,6 +24,12 @@ with open("$out/${tag}_kernel_stats.txt", "w") as o:
         line = "%-120s calls %6s avg_ns %12s pct %6s" % (r["Name"][:120], r["Calls"], r["AverageNs"], r["Percentage"])
         print(line); o.write(line + "\n")
 PY
+# MFMA-pipe occupancy (PMC pass of its own: counters only)
+MC="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
+timeout -k 10 300 rocprofv3 --pmc $MC -d $out/${tag}_pmc_mfma_fwd -o m --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/${tag}_pmcm.log 2>&1 || { tail -20 $out/${tag}_pmcm.log; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc $MC -d $out/${tag}_pmc_mfma_bwd -o m --output-format csv -- python tools/bench_train.py > $out/${tag}_pmcm2.log 2>&1 || { tail -20 $out/${tag}_pmcm2.log; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc $MC -d $out/${tag}_pmc_mfma_dy -o m --output-format csv -- python tools/bench_dynca_train.py > $out/${tag}_pmcm3.log 2>&1 || { tail -20 $out/${tag}_pmcm3.log; exit 1; }
+python tools/pmc_mfma.py $out/${tag}_pmc_mfma_fwd $out/${tag}_pmc_mfma_bwd $out/${tag}_pmc_mfma_dy > $out/${tag}_pmc_mfma.txt
 # training-shaped pass (forward with history + backward), bf16 / bf16x3 forward, backward phase accounting
 timeout -k 10 200 python tools/bench_train.py > $out/${tag}_train.json 2> $out/${tag}_train.err || { tail -20 $out/${tag}_train.err; exit 1; }
 timeout -k 10 200 python tools/bench_train.py cfg3 >> $out/${tag}_train.json 2>> $out/${tag}_train.err || { tail -20 $out/${tag}_train.err; exit 1; }
