@@ -166,3 +166,73 @@ def test_ot_loss_arithmetic():
         ref += max(d.min(1).mean(), d.min(0).mean())
         ref += np.abs(X.mean(0) - Y.mean(0)).mean() + np.abs(np.cov(X.T) - np.cov(Y.T)).mean()
     assert abs(got - ref) < 1e-5 * max(1.0, abs(ref)), (got, ref)
+
+
+def test_loss_accepts_the_reference_image_inputs_and_default_trainer_objective():
+    """train.py hands the trainer a PIL RGB image (utils.py:28-31 -> transforms.ToTensor): PIL, H x W x C uint8 and C x H x W
+    float inputs must all build the default objective, and give the same style tensor."""
+    import warnings
+    from PIL import Image
+    from ncahip.conditioned_trainer import ConditionedNCATrainer
+    from ncahip.loss import Loss, _to_nchw
+    rgb = (np.random.RandomState(0).rand(36, 40, 3) * 255).astype(np.uint8)
+    pil = Image.fromarray(rgb, "RGB")
+    a, b = _to_nchw(pil), _to_nchw(rgb)
+    c = _to_nchw(torch.from_numpy(rgb).permute(2, 0, 1).float() / 255.0)
+    assert a.shape == (1, 3, 36, 40) and torch.equal(a, b) and torch.equal(a, c) and float(a.max()) <= 1.0
+    assert _to_nchw(rgb[:, :, 0]).shape == (1, 1, 36, 40)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        nca, ds = StubNCA(), Targets()
+        tr = ConditionedNCATrainer(nca, ds, pil, nca_steps=[3, 6], pool_size=8, log_base_path="/tmp/ncahip_test",
+                                   device=torch.device("cpu"))          # loss=None: the reference's default objective
+        assert isinstance(tr.loss, Loss) and set(tr.loss.loss_weights) == {"overflow", "appearance", "content"}
+        gen = torch.rand(2, 3, 40, 40, requires_grad=True)
+        np.random.seed(0)
+        val, log = tr.loss({"generated_images": gen, "nca_state": torch.rand(2, 8, 40, 40) * 3 - 1.5,
+                            "target_images": torch.rand(2, 3, 24, 24)})      # content target of another size: resized
+        val.backward()
+        assert torch.isfinite(val) and set(log) == {"overflow", "appearance", "content"} and float(gen.grad.abs().max()) > 0
+
+
+def test_ot_batched_equals_the_per_sample_loop():
+    from ncahip.loss import ot_loss_batched, ot_loss_single
+    g = torch.Generator().manual_seed(3)
+    tgt = [torch.randn(1, 6, 40, 40, generator=g), torch.randn(1, 10, 16, 16, generator=g)]
+    gen = [torch.randn(3, 6, 40, 40, generator=g), torch.randn(3, 10, 16, 16, generator=g)]
+    np.random.seed(11)
+    loop = sum(ot_loss_single(tgt, [f[b:b + 1] for f in gen]) for b in range(3)) / 3
+    a = np.random.rand()
+    np.random.seed(11)
+    bat = ot_loss_batched(tgt, gen)
+    b = np.random.rand()
+    assert abs(float(loop) - float(bat)) < 1e-5 * max(1.0, abs(float(loop)))
+    assert a == b                                                        # same consumption of numpy's global stream
+
+
+def test_slw_and_gram_follow_the_reference_reductions():
+    """'SlW' (appearance_loss.py:109-140): image + 5 levels, squared differences SUMMED; 'Gram' (:98-106): mean of squares."""
+    import warnings
+    from ncahip.loss import Loss, STYLE_LAYERS, _gram
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        style = torch.rand(3, 32, 32, generator=torch.Generator().manual_seed(1))
+        gen = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(2))
+        L = Loss(torch.device("cpu"), content_loss_weight=0.0, overflow_loss_weight=0.0, appearance_loss_type="SlW",
+                 target_style_image=style)
+        torch.manual_seed(5)
+        got = float(L({"generated_images": gen, "nca_state": gen})[0])
+        torch.manual_seed(5)            # independent evaluation with the same projection draws
+        feats = lambda im: [((im - L.vgg.mean) / L.vgg.std).flatten(2)] + [L.vgg(im, STYLE_LAYERS)[l].flatten(2) for l in STYLE_LAYERS]
+        ref = 0.0
+        for x, y in zip(feats(gen), feats(style[None])):
+            pr = torch.nn.functional.normalize(torch.randn(x.shape[1], 32), dim=0)
+            xs = torch.einsum("bcn,cp->bpn", x, pr).sort()[0]
+            ys = torch.nn.functional.interpolate(torch.einsum("bcn,cp->bpn", y, pr).sort()[0], x.shape[2], mode="nearest")
+            ref += float((xs - ys).square().sum())
+        assert abs(got - ref) < 1e-4 * abs(ref)
+        G = Loss(torch.device("cpu"), content_loss_weight=0.0, overflow_loss_weight=0.0, appearance_loss_type="Gram",
+                 target_style_image=style)
+        gg = float(G({"generated_images": gen, "nca_state": gen})[0])
+        fr = sum(float((_gram(G.style_feats[l]) - _gram(G.vgg(gen, STYLE_LAYERS)[l])).square().mean()) for l in STYLE_LAYERS)
+        assert abs(gg - fr) < 1e-5 * abs(fr)

@@ -14,8 +14,9 @@ does is the reference's recipe, stated here once (line numbers are the reference
 How it is carried out differs: the pool is one device tensor (index_select / index_copy_ instead of a Python list and
 `torch.stack`), dead samples are found by ONE alive-mask launch over the batch instead of a host round trip per sample,
 the per-parameter gradient sums the reference logs are fetched with a single transfer, and with `torch.distributed`
-initialised every rank owns pool_size/world slots and the gradients travel in one flat all-reduce before they are normalised
-(ncahip.dist).  `loss=` accepts any module mapping the reference's loss-input dict to `(loss, summary)`.
+initialised every rank owns pool_size/world slots and samples batch_size/world of them with a rank-offset generator, rank 0's
+draw of T is broadcast so all ranks run the same number of steps, the 2 fresh seeds of an iteration are dealt over the ranks
+(per GLOBAL batch), and the gradients travel in one flat all-reduce before they are normalised (ncahip.dist).  `loss=` accepts any module mapping the reference's loss-input dict to `(loss, summary)`.
 """
 import math
 import random
@@ -36,7 +37,8 @@ class ConditionedNCATrainer(NCATrainer):
     def __init__(self, nca, target_dataset, target_style_image, nca_steps=[48, 96], lr: float = 2e-3,
                  pool_size: int = 512, num_damaged: int = 0, log_base_path: str = "test", damage_radius: int = 3,
                  appearance_loss_type: str = "OT", appearance_loss_weight: float = 1.0, content_loss_weight: float = 1.0,
-                 overflow_loss_weight: float = 1.0, device: Optional[torch.device] = None, visualiser=None, loss=None):
+                 overflow_loss_weight: float = 1.0, device: Optional[torch.device] = None, visualiser=None, loss=None,
+                 sample_seed: int = 0):
         super().__init__(pool_size, num_damaged, log_base_path, device)
         self.nca, self.visualiser = nca, visualiser
         # data
@@ -59,10 +61,20 @@ class ConditionedNCATrainer(NCATrainer):
         # this rank's shard of the pool
         self.pool_size = ncadist.shard_size(pool_size)
         self.pool = SamplePool(self.pool_size)
+        # sampling generators: the reference's global `random` / `np.random` streams in a single process; with data
+        # parallelism rank-offset generators, so the shards put different samples into the global batch (T stays shared)
+        self._py_rng, self._np_rng = random, np.random
+        if ncadist.world_size() > 1:
+            base = int(sample_seed)
+            self._py_rng = random.Random(ncadist.rank_seed(base))
+            self._np_rng = np.random.RandomState(ncadist.rank_seed(base) % (2 ** 32))
+            torch.manual_seed(ncadist.rank_seed(base + 1))              # fire masks drawn with torch.rand_like (nca.py:172)
+            if hasattr(nca, "mask_seed"):
+                nca.mask_seed = ncadist.rank_seed(int(nca.mask_seed) + 1)   # ... or in-kernel Philox
 
     # ------------------------------------------------------------------------------------------------ sampling
     def sample_targets(self, sampled_indices):
-        picks = np.random.choice(len(self.target_dataset), size=len(sampled_indices), replace=True)
+        picks = self._np_rng.choice(len(self.target_dataset), size=len(sampled_indices), replace=True)
         return self.target_dataset[picks]
 
     def sample_batch(self, sampled_indices, sample_pool) -> torch.Tensor:
@@ -105,7 +117,7 @@ class ConditionedNCATrainer(NCATrainer):
         return report
 
     def train_batch(self, batch, targets):
-        steps = random.randint(self.min_steps, self.max_steps)
+        steps = ncadist.shared_int(random.randint(self.min_steps, self.max_steps))   # every rank: rank 0's draw
         grown = self.nca.grow(batch, num_steps=steps, goal=targets)
         loss, parts = self.loss({"generated_images": grown[:, :self.num_target_channels], "nca_state": grown,
                                  "target_images": targets})
@@ -124,11 +136,14 @@ class ConditionedNCATrainer(NCATrainer):
         w.scalars(i, **metrics)
 
     def _iteration(self, i: int, batch_size: int):
-        idxs: Sequence[int] = random.sample(range(len(self.pool)), batch_size)
+        # `batch_size` is the GLOBAL batch: each rank takes its share from its own pool shard
+        idxs: Sequence[int] = self._py_rng.sample(range(len(self.pool)), ncadist.local_batch(batch_size))
         with torch.no_grad():
             targets = self.sample_targets(idxs).to(self.device)
             batch = self.sample_batch(idxs, self.pool).to(self.device)
-            batch[:2] = self.nca.generate_seed(2).to(self.device)
+            fresh = ncadist.global_slots(2)               # 2 fresh seeds per global batch (conditioned_trainer.py:167)
+            if fresh:
+                batch[:fresh] = self.nca.generate_seed(fresh).to(self.device)
         outputs = batch
         for _ in range(2):                                # the reference trains twice on every sampled batch
             outputs, loss, metrics = self.train_batch(outputs, targets)

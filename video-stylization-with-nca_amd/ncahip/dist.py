@@ -8,7 +8,11 @@ one strategy BASELINE.json's north_star asks for:
     gradient (~10.7k floats = 43 KB: latency-bound, so one bucket / one call), issued BEFORE the per-parameter
     gradient normalisation (conditioned_trainer.py:134-136) so the normalised direction equals the
     single-process large-batch one;
-  * every rank draws the same number of NCA steps (shared `random` seed) so no rank idles at the collective.
+  * every rank runs the same number of NCA steps: rank 0 draws T with the reference's own call and broadcasts it
+    (`shared_int`), so no rank idles at the collective; everything else that is sampled (pool slots, targets, fire
+    masks) comes from rank-offset generators (`rank_seed`) so the shards contribute DIFFERENT samples to the global batch;
+  * the reference's per-iteration seed injections are per GLOBAL batch (`global_slots`): 2 fresh seeds per batch in
+    ConditionedNCATrainer (conditioned_trainer.py:167), slot 0 every 8th iteration in the DyNCA loop (experiments.py:213-216).
 """
 import os
 from typing import Iterable, Optional
@@ -70,11 +74,35 @@ def allreduce_mean_grads(params: Iterable[torch.nn.Parameter], group=None) -> in
     return flat.numel()
 
 
-def shared_randint_seed(base: int = 0) -> int:
-    """A seed every rank agrees on (rank 0's choice), for the per-iteration step-count draw."""
-    t = torch.tensor([base], dtype=torch.int64)
-    if world_size() > 1:
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-        t = t.to(dev)
-        dist.broadcast(t, src=0)
+def shared_int(value: int = 0) -> int:
+    """Rank 0's `value` on every rank (one 8-byte broadcast): the per-iteration step count T, drawn by rank 0 with the
+    reference's own RNG call, so that every rank runs the same number of NCA steps and none idles at the all-reduce."""
+    if world_size() == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = t.to(dev)
+    dist.broadcast(t, src=0)
     return int(t.item())
+
+
+shared_randint_seed = shared_int      # earlier name
+
+
+def rank_seed(base: int) -> int:
+    """A seed that differs per rank and per `base` (base * world + rank): the sampling generators of the trainers."""
+    return int(base) * world_size() + rank()
+
+
+def local_batch(global_batch: int) -> int:
+    """Per-rank share of a global batch (must divide evenly: the all-reduce averages equal shards)."""
+    w = world_size()
+    if global_batch % w != 0:
+        raise ValueError(f"ncahip.dist: global batch {global_batch} is not divisible by the world size {w}")
+    return global_batch // w
+
+
+def global_slots(n: int) -> int:
+    """How many of `n` per-global-batch items (fresh seeds) fall to this rank: item k goes to rank k % world."""
+    w, r = world_size(), rank()
+    return sum(1 for k in range(n) if k % w == r)

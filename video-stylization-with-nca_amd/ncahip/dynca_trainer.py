@@ -13,8 +13,9 @@ scripts; this class carries exactly the part SURVEY.md section 8 row a15 puts on
         pool[batch_idx] = states                              (:269 writes back states[:, :12]; generalised to c_in)
 
 The loss is supplied by the caller (the reference's appearance / motion losses need VGG / MSOE weights that are not
-obtainable offline).  With torch.distributed initialised each rank owns pool_size/world slots and gradients are
-all-reduced through one flat bucket before the normalisation (ncahip.dist).
+obtainable offline).  With torch.distributed initialised each rank owns pool_size/world slots, takes batch_size/world of
+them per iteration under a rank-offset reseed ((i+424)*world + rank), adopts rank 0's T, and the gradients are all-reduced
+through one flat bucket before the normalisation (ncahip.dist); `batch_size` is the GLOBAL batch.
 """
 from typing import Callable, Optional, Sequence
 
@@ -43,17 +44,23 @@ class DyNCATrainer:
     def step(self, cond_img: Optional[torch.Tensor] = None, extra: Optional[dict] = None):
         """One training iteration; returns (loss value as a 0-d tensor, T)."""
         i = self.iteration
-        np.random.seed(i + self.reseed_offset)
-        torch.manual_seed(i + self.reseed_offset)
+        # single process: the reference's reseed (experiments.py:196-198).  Data parallel: a rank-offset seed, so the shards
+        # draw different slots and fire masks; T is rank 0's draw, broadcast; the seed injection into slot 0 is per GLOBAL batch
+        seed = ncadist.rank_seed(i + self.reseed_offset)
+        np.random.seed(seed % (2 ** 32))
+        torch.manual_seed(seed)
         if torch.cuda.is_available():
-            torch.cuda.manual_seed_all(i + self.reseed_offset)
+            torch.cuda.manual_seed_all(seed)
+        if hasattr(self.model, "mask_seed") and ncadist.world_size() > 1:
+            self.model.mask_seed = seed
+        local = ncadist.local_batch(self.batch_size)
         with torch.no_grad():
-            batch_idx = np.random.choice(self.pool_size, self.batch_size, replace=False)
+            batch_idx = np.random.choice(self.pool_size, local, replace=False)
             idx = torch.as_tensor(batch_idx, device=self.pool.device)
             states = self.pool.index_select(0, idx)
-            if i % self.inject_seed_step == 0:
+            if i % self.inject_seed_step == 0 and ncadist.global_slots(1):
                 states[:1] = self.model.seed(1, size=self.size).to(states.device)[:1]
-        step_n = int(np.random.randint(self.min_steps, self.max_steps))
+        step_n = ncadist.shared_int(int(np.random.randint(self.min_steps, self.max_steps)))
         kw = {} if cond_img is None else {"cond_img": cond_img}
         states_after, rgb = self.model.forward_nsteps(states, step_n, **kw)
         input_dict = {"generated_image_list": [rgb], "nca_state": states_after, "step_n": step_n}

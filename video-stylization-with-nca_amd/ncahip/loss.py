@@ -6,8 +6,11 @@ feature extractor below is a pure-torch VGG16-features definition that loads a l
 when NCAHIP_VGG16_WEIGHTS points at one and otherwise runs with seeded random weights (timing stand-in;
 loss values vs the reference are then "parity unpinned").  Appearance types: 'OT' (the reference's default: relaxed
 EMD over cosine distances + first/second moment matching, appearance_loss.py:149-220), 'Gram' and 'SlW' (sliced
-Wasserstein, project-sort).  The OT arithmetic itself is pinned by tests/test_trainer_logic.py against an independent
-float64 evaluation of the same formulas.
+Wasserstein, project-sort over the image + the five style levels, appearance_loss.py:109-140).  The OT arithmetic itself is
+pinned by tests/test_trainer_logic.py against an independent float64 evaluation of the same formulas; the batch is evaluated
+with batched matrix products (`ot_loss_batched`) instead of the reference's per-sample Python loop (:212-220) -- same index
+draws from numpy's global stream in the same order, same value up to summation order.  `feature_dtype=torch.bfloat16` runs the
+VGG convolutions in bf16 on the device (BASELINE configs[2]); the loss arithmetic on the features stays fp32.
 """
 import os
 import warnings
@@ -55,11 +58,13 @@ class VGG16Features(nn.Module):
 
     def forward(self, x, layers):
         x = (x - self.mean) / self.std
+        dt = self.features[0].weight.dtype          # bf16 when the module was cast (.to(torch.bfloat16)): convs on bf16 MFMA
+        x = x.to(dt)
         out, last = {}, max(layers)
         for i, m in enumerate(self.features):
             x = m(x)
             if i in layers:
-                out[i] = x
+                out[i] = x.float()
             if i >= last:
                 break
         return out
@@ -71,15 +76,30 @@ def _gram(f):
     return f @ f.transpose(1, 2) / (h * w)
 
 
-def _sliced_wasserstein(a, b, n_proj=32):
-    bsz, c = a.shape[0], a.shape[1]
-    a, b = a.reshape(bsz, c, -1), b.reshape(b.shape[0], c, -1)
-    proj = F.normalize(torch.randn(c, n_proj, device=a.device), dim=0)
-    pa = torch.sort(torch.einsum("bcn,cp->bpn", a, proj), dim=-1)[0]
-    pb = torch.sort(torch.einsum("bcn,cp->bpn", b, proj), dim=-1)[0]
-    if pa.shape[-1] != pb.shape[-1]:
-        pb = F.interpolate(pb, size=pa.shape[-1], mode="nearest")
-    return ((pa - pb) ** 2).mean()
+def _sliced_wasserstein(source, target, n_proj=32):
+    """appearance_loss.py:121-136: source [b,c,n], target [1,c,m] flattened features; random unit projections drawn on the
+    CPU generator (torch.randn(ch, 32)), project + sort, nearest-resample the target to n, SUM of squared differences."""
+    ch, n = source.shape[-2:]
+    proj = F.normalize(torch.randn(ch, n_proj), dim=0).to(source.device)
+    ps = torch.einsum("bcn,cp->bpn", source, proj).sort()[0]
+    pt = torch.einsum("bcn,cp->bpn", target, proj).sort()[0]
+    return (ps - F.interpolate(pt, n, mode="nearest")).square().sum()
+
+
+def _to_nchw(img) -> torch.Tensor:
+    """appearance_loss.py:41-43 (torchvision ToTensor + unsqueeze): a PIL image or an H x W x C uint8 array becomes a
+    [1,C,H,W] float tensor in [0,1]; float arrays are only transposed; a float tensor is taken as C x H x W (or N x C x H x W)
+    already in network range."""
+    if isinstance(img, torch.Tensor):
+        t = img.float()
+        return t[None] if t.dim() == 3 else t
+    if not isinstance(img, np.ndarray):          # PIL.Image (or anything exposing the array interface)
+        img = np.asarray(img)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    t = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1)))
+    t = t.float().div(255.0) if img.dtype == np.uint8 else t.float()
+    return t[None]
 
 
 def _pairwise_cos(x, y):
@@ -120,9 +140,45 @@ def ot_loss_single(target_feats, gen_feats, n_samples=1000):
     return loss
 
 
+def ot_loss_batched(target_feats, gen_feats, n_samples=1000):
+    """The batch mean of ot_loss_single (appearance_loss.py:212-220) without the per-sample Python loop: the sub-sampling
+    indices are drawn sample by sample, layer by layer, exactly as the loop would draw them from numpy's global stream; the
+    cosine-distance, nearest-neighbour and covariance products then run as batched GEMMs over all samples of a layer."""
+    B = gen_feats[0].shape[0]
+    idx = [[None] * len(gen_feats) for _ in range(B)]
+    for b in range(B):                                     # the reference's draw order: sample-major, layer-minor
+        for li, t in enumerate(target_feats):
+            h, w = t.shape[2], t.shape[3]
+            if h > 32:
+                idx[b][li] = np.sort(np.random.choice(np.arange(h * w), size=n_samples, replace=False))
+    total = 0
+    for li, (t, g) in enumerate(zip(target_feats, gen_feats)):
+        c = t.shape[1]
+        tv, gv = t.reshape(1, c, -1), g.reshape(B, c, -1)
+        if idx[0][li] is not None:
+            ix = torch.as_tensor(np.stack([idx[b][li] for b in range(B)]), device=t.device)          # [B, N]
+            gv = torch.gather(gv, 2, ix[:, None, :].expand(B, c, -1))
+            tv = tv.expand(B, c, -1).gather(2, ix[:, None, :].expand(B, c, -1))
+        else:
+            tv = tv.expand(B, c, -1)
+        x, y = tv.transpose(1, 2), gv.transpose(1, 2)                                               # [B, N, d]
+        xn = torch.sqrt((x ** 2).sum(2))[:, :, None]
+        yn = torch.sqrt((y ** 2).sum(2))[:, None, :]
+        d = 1.0 - torch.bmm(x, y.transpose(1, 2)) / (xn + 1e-10) / (yn + 1e-10)
+        remd = torch.maximum(d.min(2)[0].mean(1), d.min(1)[0].mean(1))                              # [B]
+        mx, my = x.mean(1, keepdim=True), y.mean(1, keepdim=True)
+        xc, yc = x - mx, y - my
+        n = x.shape[1]
+        cx = torch.bmm(xc.transpose(1, 2), xc) / (n - 1)
+        cy = torch.bmm(yc.transpose(1, 2), yc) / (n - 1)
+        mom = (mx - my).abs().mean(dim=(1, 2)) + (cx - cy).abs().mean(dim=(1, 2))
+        total = total + (remd + mom).sum()
+    return total / B
+
+
 class Loss(nn.Module):
     def __init__(self, device, content_loss_weight=1.0, overflow_loss_weight=1.0, appearance_loss_weight=1.0,
-                 appearance_loss_type="OT", target_style_image=None):
+                 appearance_loss_type="OT", target_style_image=None, feature_dtype=torch.float32):
         super().__init__()
         self.device = device
         self.appearance_loss_type = appearance_loss_type
@@ -140,12 +196,12 @@ class Loss(nn.Module):
         if content_loss_weight != 0:
             self.loss_weights["content"] = content_loss_weight
         self.vgg = VGG16Features().to(device) if (appearance_loss_weight != 0 or content_loss_weight != 0) else None
+        if self.vgg is not None and feature_dtype != torch.float32:
+            self.vgg.features.to(feature_dtype)
         if appearance_loss_weight != 0:
-            style = torch.as_tensor(target_style_image, dtype=torch.float32, device=device)
-            if style.dim() == 3:
-                style = style[None]
+            self.target_style_tensor = _to_nchw(target_style_image).to(device)
             with torch.no_grad():
-                self.style_feats = self.vgg(style, STYLE_LAYERS)
+                self.style_feats = self.vgg(self.target_style_tensor, STYLE_LAYERS)
 
     def get_overflow_loss(self, input_dict):  # loss.py:37-40
         s = input_dict["nca_state"]
@@ -167,19 +223,23 @@ class Loss(nn.Module):
             if "appearance" in self.loss_weights:
                 acc = 0
                 if self.appearance_loss_type == "OT":    # appearance_loss.py:212-220: mean over the batch
-                    tgt = [self.style_feats[l] for l in STYLE_LAYERS]
-                    for b in range(gen.shape[0]):
-                        acc = acc + ot_loss_single(tgt, [gf[l][b:b + 1] for l in STYLE_LAYERS])
-                    acc = acc / gen.shape[0]
-                for l in (STYLE_LAYERS if self.appearance_loss_type != "OT" else ()):
-                    if self.appearance_loss_type == "Gram":
-                        acc = acc + F.mse_loss(_gram(gf[l]), _gram(self.style_feats[l]).expand(gf[l].shape[0], -1, -1))
-                    else:
-                        acc = acc + _sliced_wasserstein(gf[l], self.style_feats[l].expand(gf[l].shape[0], -1, -1, -1))
+                    acc = ot_loss_batched([self.style_feats[l] for l in STYLE_LAYERS], [gf[l] for l in STYLE_LAYERS])
+                elif self.appearance_loss_type == "Gram":   # :98-106
+                    for l in STYLE_LAYERS:
+                        acc = acc + (_gram(self.style_feats[l]) - _gram(gf[l])).square().mean()
+                else:                                       # 'SlW', :138-140: the normalised image is the first "feature" level
+                    flat = lambda f: f.reshape(f.shape[0], f.shape[1], -1)
+                    norm = lambda im: (im - self.vgg.mean) / self.vgg.std
+                    src = [flat(norm(gen))] + [flat(gf[l]) for l in STYLE_LAYERS]
+                    tgt = [flat(norm(self.target_style_tensor))] + [flat(self.style_feats[l]) for l in STYLE_LAYERS]
+                    acc = sum(_sliced_wasserstein(x, y) for x, y in zip(src, tgt))
                 terms["appearance"] = acc
             if "content" in self.loss_weights:
+                tgt_img = input_dict["target_images"]
+                if tgt_img.shape[-2:] != gen.shape[-2:]:      # content_loss.py:31-32 (torchvision resize: antialiased bilinear)
+                    tgt_img = F.interpolate(tgt_img, size=gen.shape[-2:], mode="bilinear", align_corners=False, antialias=True)
                 with torch.no_grad():
-                    tf = self.vgg(input_dict["target_images"], (CONTENT_LAYER,))[CONTENT_LAYER]
+                    tf = self.vgg(tgt_img, (CONTENT_LAYER,))[CONTENT_LAYER]
                 terms["content"] = F.mse_loss(gf[CONTENT_LAYER], tf)
         for k, v in terms.items():
             v = v * self.loss_weights[k]
