@@ -260,6 +260,22 @@ int ncahip_cond_grow_bwd_f32(const float *states, const uint8_t *pre, int T,
                              float *g_wp, float *g_w1, float *g_b1, float *g_w2, float *g_b2, float *g_w3,
                              void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
 
+/* The same backward over a bf16 history: states [T+1 slots] and goal as stored by ncahip_cond_grow_fwd_bf16 with ring = T+1
+ * (BASELINE configs[2]: a bf16 pool halves the saved-for-backward set).  The stored values are widened exactly, the step is
+ * recomputed in fp32 from them and EVERY gradient (inputs g_final, outputs, scratch) is fp32: the gradient of the fp32 step
+ * function evaluated along the bf16 trajectory (straight-through with respect to the storage rounding and the bf16 matrix
+ * operands of the forward; bound against the fp32 gradients in tests/).  W % 4 == 0, states / goal 8-byte aligned.           */
+int ncahip_cond_grow_bwd_bf16(const uint16_t *states, const uint8_t *pre, int T,
+                              const uint16_t *goal, int goal_ch, const float *u,
+                              const float *wp, const float *w1, const float *b1,
+                              const float *w2, const float *b2, const float *w3,
+                              int B, int C, int H, int W, int hidden,
+                              int alive_ch, float alive_thr, float fire_rate,
+                              float clamp_lo, float clamp_hi, uint64_t seed, uint64_t step0,
+                              const float *g_final, float *g_x0, float *g_goal,
+                              float *g_wp, float *g_w1, float *g_b1, float *g_w2, float *g_b2, float *g_w3,
+                              void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
+
 /* The [B,1,H,W] uniforms the kernels draw for (seed, step) when u == NULL (for tests/tools). */
 int ncahip_philox_uniform_f32(float *u, int B, int H, int W, uint64_t seed, uint64_t step,
                               ncahip_stream_t stream);

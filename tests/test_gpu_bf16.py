@@ -150,8 +150,56 @@ def test_module_grow_bf16(ops):
     assert yb.dtype == torch.bfloat16 and yb.shape == yf.shape
     d = (yb.float() - yf).abs()
     assert float(d.mean()) < 2e-2, float(d.mean())
-    with pytest.raises(NotImplementedError):
-        m.grow(x, 2, goal)                      # autograd through the bf16 path is not provided
+    # autograd through the bf16 path: bf16 history ring, fp32 gradients for every parameter (encoder included)
+    m._mask_step = 0
+    out = m.grow(x.clone().requires_grad_(True), 3, goal)
+    assert out.dtype == torch.bfloat16
+    out.float().square().mean().backward()
+    for n_, p_ in m.named_parameters():
+        if p_.requires_grad:
+            assert p_.grad is not None and p_.grad.dtype == torch.float32 and bool(torch.isfinite(p_.grad).all()), n_
+
+
+@pytest.mark.parametrize("C,shape,gch,Tn", [(16, (2, 32, 48), 12, 4), (12, (2, 24, 32), 8, 3), (16, (1, 16, 16), 16, 2)])
+def test_cond_grow_backward_bf16_history(ops, C, shape, gch, Tn):
+    """ncahip_cond_grow_bwd_bf16: the gradient of the fp32 step function along the bf16 trajectory.  Checked two ways:
+    (i) exactly that definition -- the fp32 backward kernel fed the widened bf16 history must agree bit for bit;
+    (ii) against oracle autograd through the fp32 steps started from the same bf16-representable inputs (different
+    trajectory: bf16 storage + bf16 matrix operands in the forward), within the bf16 budget.  The alpha channel is held
+    fixed (zero output row) so no life mask sits near its threshold and the comparison is smooth."""
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(C + Tn)
+    from test_gpu_parity import rand_cond_prm
+    prm = rand_cond_prm(C, seed=C + 1, out_scale=1.0)
+    prm["update_net.out.4.weight"][3] = 0.0                         # alpha never changes
+    x0 = bfr(torch.rand(B, C, H, W, generator=gen))
+    x0[:, 3] = bfr(0.5 + 0.5 * torch.rand(B, H, W, generator=gen))
+    x0[0, :, : H // 3] = 0.0                                        # a dead band with a live frontier
+    goal = bfr(torch.randn(B, gch, H, W, generator=gen) * 0.5)
+    us = torch.rand(Tn, B, 1, H, W, generator=gen)
+    cot = torch.randn(B, C, H, W, generator=gen)
+    xd, gd, ud, cd = x0.to(DEV).bfloat16(), goal.to(DEV).bfloat16(), us.to(DEV), cot.to(DEV)
+    w = weights(ops, prm, xd)
+    out, states, pre = ops.cond_grow(xd, Tn, gd, ud, w, 3, keep_history=True)
+    assert states.dtype == torch.bfloat16
+    g16 = ops.cond_grow_backward(states, pre, gd, ud, w, cd, Tn, 3)
+    g32 = ops.cond_grow_backward(states.float(), pre, gd.float(), ud, w, cd, Tn, 3)
+    for k in g16:
+        assert g16[k].dtype == torch.float32 and torch.equal(g16[k], g32[k]), k
+    _, gx, gg, gw = O.cond_grow_loss_grads(x0, O.cond_pad_goal(goal, C), list(us), prm, 3, 0.1, 0.5, cot)
+    # a ReLU whose pre-activation changes sign between the two trajectories moves ONE cell's gradient by O(1), so the bound is
+    # on the relative L2 error (2 %), with a loose cap on the largest single-element deviation
+    def rel2(a, b):
+        a, b = a.cpu().double().reshape(-1), b.double().reshape(-1)
+        return float((a - b).norm() / b.norm().clamp_min(1e-12)), float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    for got, ref in ((g16["x0"], gx), (g16["goal"], gg[:, C - gch:])):
+        l2, mx = rel2(got, ref)
+        assert l2 < 2e-2 and mx < 0.25, (l2, mx)
+    names = {"wp": "perception_net.weight", "w1": "update_net.out.0.weight", "b1": "update_net.out.0.bias",
+             "w2": "update_net.out.2.weight", "b2": "update_net.out.2.bias", "w3": "update_net.out.4.weight"}
+    for k, n in names.items():
+        l2, mx = rel2(g16[k], gw[n])
+        assert l2 < 2e-2 and mx < 5e-2, (k, l2, mx)
 
 
 # ------------------------------------------------------------------------------------------------ DyNCA, bf16 storage

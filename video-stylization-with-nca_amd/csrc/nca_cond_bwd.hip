@@ -90,7 +90,9 @@ __device__ __forceinline__ void piped(LD&& ld, MM&& mm) {
 #define NCA_BPHASE(i) do { } while (0)
 #endif
 
-template <int CP>
+// ST = storage type of the history (states / pending states) and of the goal encoding: StF32, or StBF16 for a bf16 pool
+// (BASELINE configs[2]): the values are widened exactly on load and the whole recomputation and every gradient stay f32.
+template <int CP, typename ST = StF32>
 __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const NcaCondBwdArgs ba) {
     using K = BCfg<CP>;
     using FK = WCfg<CP>;
@@ -205,35 +207,36 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
         NCA_BPHASE(0);   // loop overhead / previous tile's tail
         // ---- all global loads of the tile are requested up front (one HBM round trip per tile instead of two: with one
         //      wave per SIMD nothing else hides it): forward operands, pending x'_t (alpha halo 1 + interior), incoming gradient
-        TileRegs<CP> R;
-        issue_loads<CP, true, true>(a, t, lane, R);
-        const float* const xn = ba.x_next + (size_t)t.b * C * plane;
+        TileRegs<CP, ST> R;
+        issue_loads<CP, true, true, -1, false, ST>(a, t, lane, R);
+        const char* const xn = reinterpret_cast<const char*>(ba.x_next) + (size_t)t.b * C * plane * ST::BYTES;
         const float* const gn = ba.g_next + (size_t)t.b * C * plane;
         const int hl = (lane >> 5) & 1, l5 = lane & 31;
         const int row = (lane >> 2) & 3, ff = lane & 3;
         const bool ok = ty0 + row < H && tx0 + 4 * ff + 3 < W;
         const unsigned off = ok ? (unsigned)((ty0 + row) * W + tx0 + 4 * ff) : 0u;
-        float av[3];
+        typename ST::raw1 av[3];
         bool aok[3];
         if (use_alive) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int gy = ty0 - 1 + 2 * k + hl, gx = tx0 - 1 + l5;
                 aok[k] = l5 < 18 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-                av[k] = xn[(unsigned)a.alive_ch * plane + (aok[k] ? (unsigned)(gy * W + gx) : 0u)];
+                av[k] = ST::gld1(xn, (unsigned)a.alive_ch * plane + (aok[k] ? (unsigned)(gy * W + gx) : 0u));
             }
         }
-        f32x4 xv[CP / 4], gv[CP / 4];
+        typename ST::raw4 xv[CP / 4];
+        f32x4 gv[CP / 4];
 #pragma unroll
         for (int k = 0; k < CP / 4; ++k) {
             const unsigned ch = (unsigned)min(4 * k + g, C - 1);
-            xv[k] = ld4(xn + ch * plane + off);
+            xv[k] = ST::gld4(xn, ch * plane + off);
             gv[k] = ld4(gn + ch * plane + off);
         }
         // ---- forward staging: s_t (XR), pre_t (PN), z_t (Z), fire mask (MK) -------------------------------
         const TileLds L = wave_private_lds<CP>(PWR);
-        if (t.inner) stage_tile<CP, false>(a, t, L, lane, R, 0);
-        else stage_tile<CP, true>(a, t, L, lane, R, 0);
+        if (t.inner) stage_tile<CP, false, false, ST>(a, t, L, lane, R, 0);
+        else stage_tile<CP, true, false, ST>(a, t, L, lane, R, 0);
         NCA_BPHASE(1);   // forward staging
 
         // ---- pending x'_t: alpha halo 1 -> A1 (post mask), interior -> XR; incoming gradient -> TB --------
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             if (use_alive) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
-                    if (l5 < 18) A1[(2 * k + hl) * RS + l5 + 3] = aok[k] ? av[k] : NCA_NEG_INF;
+                    if (l5 < 18) A1[(2 * k + hl) * RS + l5 + 3] = aok[k] ? ST::cv1(av[k]) : NCA_NEG_INF;
             }
             // z_t interior out (kernel B needs it for the perception-weight gradient)
             float* const zo = ba.zbuf + (size_t)t.b * C * plane + off;
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             for (int k = 0; k < CP / 4; ++k) {
                 const int ch = 4 * k + g;
                 const bool live = ok && ch < C;
-                st4(XR + ch * XRS + row * WTW + 4 * ff, live ? xv[k] : f32x4{0.f, 0.f, 0.f, 0.f});
+                st4(XR + ch * XRS + row * WTW + 4 * ff, live ? ST::cv4(xv[k]) : f32x4{0.f, 0.f, 0.f, 0.f});
                 st4(TB + ch * XRS + row * WTW + 4 * ff, live ? gv[k] : f32x4{0.f, 0.f, 0.f, 0.f});
             }
             wave_sync();
@@ -269,23 +272,26 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
         if (tw.t + tw.stride < tw.end) {
             const int tnx = tw.t + tw.stride, gch = a.goal_ch;
             const int nb = tnx / (st_x * st_y), ny0 = ((tnx / st_x) % st_y) * BSTH + wave * WTH, nx0 = (tnx % st_x) * BSTW;
-            const float* const bx = a.x_in + (size_t)nb * C * plane;
-            const float* const bg = gch ? a.goal + (size_t)nb * gch * plane : bx;
-            const float* const bn = ba.x_next + (size_t)nb * C * plane;
+            constexpr unsigned SB = ST::BYTES;      // state-type tensors are addressed in bytes; the 4-byte warm-up read may
+            // straddle into the next element of a bf16 row, which is fine: the value is never consumed
+            const char* const bx = reinterpret_cast<const char*>(a.x_in) + (size_t)nb * C * plane * SB;
+            const char* const bg = gch ? reinterpret_cast<const char*>(a.goal) + (size_t)nb * gch * plane * SB : bx;
+            const char* const bn = reinterpret_cast<const char*>(ba.x_next) + (size_t)nb * C * plane * SB;
             const float* const bq = ba.g_next + (size_t)nb * C * plane;
             const unsigned col = (unsigned)min(nx0, W - 1);
             // state + goal planes: 8 rows each (ty0-1 ..; two more than needed keeps the index arithmetic to shifts)
             for (int base = 0; base < 8 * (C + gch); base += 64) {
                 const int i = min(base + lane, 8 * (C + gch) - 1), pl = i >> 3;
-                const unsigned rowo = (unsigned)min(max(ny0 + (i & 7) - 1, 0), H - 1) * (unsigned)W + col;
-                const float* const p = (pl < C ? bx + (unsigned)pl * plane : bg + (unsigned)(pl - C) * plane) + rowo;
+                const unsigned rowo = (unsigned)min(max(ny0 + (i & 7) - 1, 0), H - 1) * (unsigned)W + (col & ~1u);
+                const char* const p = (pl < C ? bx + (size_t)((unsigned)pl * plane + rowo) * SB : bg + (size_t)((unsigned)(pl - C) * plane + rowo) * SB);
                 asm volatile("global_load_dword %0, %1, off" : "+v"(l2warm) : "v"(p) : "memory");
             }
             // pending state + incoming gradient: 4 rows each
             for (int base = 0; base < 8 * C; base += 64) {
                 const int i = min(base + lane, 8 * C - 1), pl = i >> 2;
-                const unsigned rowo = (unsigned)min(ny0 + (i & 3), H - 1) * (unsigned)W + col;
-                const float* const p = (pl < C ? bn + (unsigned)pl * plane : bq + (unsigned)(pl - C) * plane) + rowo;
+                const unsigned rowo = (unsigned)min(ny0 + (i & 3), H - 1) * (unsigned)W + (col & ~1u);
+                const void* const p = pl < C ? (const void*)(bn + (size_t)((unsigned)pl * plane + rowo) * SB)
+                                             : (const void*)(bq + (unsigned)(pl - C) * plane + rowo);
                 asm volatile("global_load_dword %0, %1, off" : "+v"(l2warm) : "v"(p) : "memory");
             }
         }
@@ -836,10 +842,10 @@ __global__ __launch_bounds__(64) void reduce_wp_kernel(const float* __restrict__
     dst[c * 27 + i] = acc;
 }
 
-template <int CP>
+template <int CP, typename ST>
 hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
     using K = BCfg<CP>;
-    auto kern = cond_step_bwd_kernel<CP>;
+    auto kern = cond_step_bwd_kernel<CP, ST>;
     const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
     static thread_local bool attr_done = false;
     if (!attr_done) {
@@ -877,9 +883,14 @@ int nca_cond_bwd_nslab() {
 int nca_cond_bwd_nblk(int B, int C, int H, int W) { return B * C * ((((H + SROWS - 1) / SROWS) * (W / 4) + 255) / 256); }
 
 // W % 4 == 0 and 16-byte aligned tensors required (checked by the C ABI).
-hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
-    if (ba.f.C <= 12) return launch_bwd<12>(ba, st);
-    if (ba.f.C <= 16) return launch_bwd<16>(ba, st);
+hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st, bool bf16) {
+    if (bf16) {   // history (f.x_in, x_next) and goal hold bf16; gradients and scratch stay f32
+        if (ba.f.C <= 12) return launch_bwd<12, StBF16>(ba, st);
+        if (ba.f.C <= 16) return launch_bwd<16, StBF16>(ba, st);
+        return hipErrorInvalidValue;
+    }
+    if (ba.f.C <= 12) return launch_bwd<12, StF32>(ba, st);
+    if (ba.f.C <= 16) return launch_bwd<16, StF32>(ba, st);
     return hipErrorInvalidValue;
 }
 

@@ -190,6 +190,11 @@ struct StF32 {
     static __device__ __forceinline__ void st4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)soff, AUX);
     }
+    // plain global loads at an ELEMENT offset from a typeless base (backward kernel: pending state x'_t)
+    static __device__ __forceinline__ raw1 gld1(const void* base, unsigned elem) { return static_cast<const float*>(base)[elem]; }
+    static __device__ __forceinline__ raw4 gld4(const void* base, unsigned elem) {
+        return *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + elem);
+    }
 };
 // bf16 storage (round-to-nearest-even on store: v_cvt_pk_bf16_f32; widening on load is exact)
 struct StBF16 {
@@ -216,6 +221,10 @@ struct StBF16 {
     template <int AUX>
     static __device__ __forceinline__ void st4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk2(v[0], v[1]), pk2(v[2], v[3])}, r, (int)voff, (int)soff, AUX);
+    }
+    static __device__ __forceinline__ raw1 gld1(const void* base, unsigned elem) { return (unsigned)static_cast<const uint16_t*>(base)[elem]; }
+    static __device__ __forceinline__ raw4 gld4(const void* base, unsigned elem) {
+        return *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(base) + elem);
     }
 };
 // channel index * plane bytes: a full 32-bit multiply -- plane bytes reach 2^24 at 2048 x 2048 fp32 cells, beyond v_mul_u32_u24

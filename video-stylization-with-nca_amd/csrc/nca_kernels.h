@@ -57,7 +57,7 @@ struct NcaCondBwdArgs {
 int nca_cond_bwd_slab_floats(int C, int hidden);
 int nca_cond_bwd_nslab();
 int nca_cond_bwd_nblk(int B, int C, int H, int W);
-hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& a, hipStream_t st);
+hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& a, hipStream_t st, bool bf16 = false);   // bf16: f.x_in / x_next / f.goal hold bf16
 hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st, bool accumulate = false);   // dst (+)= column sums
 // nca_gram.hip: out[ma*nb + ma] = [sum_n a[i][n] * b[j][n] | sum_n a[i][n]] over all B*HW cells; b rows from two tensors
 int nca_dynca_bwd_grid(int B, int H, int W);   // workgroups of the DyNCA backward kernel (= partial slabs of its fused dW2)

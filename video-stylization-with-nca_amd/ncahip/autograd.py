@@ -14,31 +14,38 @@ def _needs_grad(*tensors) -> bool:
 
 # ------------------------------------------------------------------------------------ ConditionedNCA
 class _CondGrow(torch.autograd.Function):
+    """x float32 or bfloat16 (a bf16 pool, BASELINE configs[2]: the history ring -- the saved-for-backward set -- is then
+    bf16 too, half the bytes).  goal is the encoder's float32 output; for a bf16 state it is rounded to bf16 for the kernels
+    and its gradient comes back float32.  Gradients are float32 except dL/dx0, which takes x's dtype."""
+
     @staticmethod
     def forward(ctx, x, goal, wp, w1, b1, w2, b2, w3, cfg):
         T, us = cfg["T"], cfg["us"]
         w = ops.CondWeights(wp, w1, b1, w2, b2, w3, x)
-        out, states, pre = ops.cond_grow(x, T, goal, us, w, cfg["alive_ch"], cfg["thr"], cfg["fire_rate"], cfg["lo"],
+        gk = goal if (goal is None or goal.dtype == x.dtype) else goal.to(x.dtype)
+        out, states, pre = ops.cond_grow(x, T, gk, us, w, cfg["alive_ch"], cfg["thr"], cfg["fire_rate"], cfg["lo"],
                                          cfg["hi"], cfg["seed"], cfg["step0"], keep_history=True)
         ctx.cfg, ctx.w = cfg, w
-        ctx.save_for_backward(states, pre, goal if goal is not None else x.new_empty(0))
+        ctx.goal_dtype = None if goal is None else goal.dtype
+        ctx.save_for_backward(states, pre, gk if gk is not None else x.new_empty(0))
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         states, pre, goal = ctx.saved_tensors
         cfg, w = ctx.cfg, ctx.w
-        g = ops.cond_grow_backward(states, pre, goal if goal.numel() else None, cfg["us"], w, g_out.contiguous(),
+        g = ops.cond_grow_backward(states, pre, goal if goal.numel() else None, cfg["us"], w, g_out.float().contiguous(),
                                    cfg["T"], cfg["alive_ch"], cfg["thr"], cfg["fire_rate"], cfg["lo"], cfg["hi"],
                                    cfg["seed"], cfg["step0"])
-        return (g["x0"], g["goal"], g["wp"].view_as(ctx.w.wp).reshape(-1, 1, 3, 3), g["w1"][:, :, None, None],
+        ggoal = g["goal"] if g["goal"] is None else g["goal"].to(ctx.goal_dtype)
+        return (g["x0"].to(states.dtype), ggoal, g["wp"].view_as(ctx.w.wp).reshape(-1, 1, 3, 3), g["w1"][:, :, None, None],
                 g["b1"], g["w2"][:, :, None, None], g["b2"], g["w3"][:, :, None, None], None)
 
 
 def cond_grow_autograd(model, x: torch.Tensor, goal: Optional[torch.Tensor], T: int) -> torch.Tensor:
     if T == 0:
         return x
-    bf16 = x.dtype == torch.bfloat16      # bf16 pool (BASELINE configs[2]): bf16-storage kernels, inference only
+    bf16 = x.dtype == torch.bfloat16      # bf16 pool (BASELINE configs[2]): bf16-storage kernels, forward and backward
     x = x.contiguous() if bf16 else x.float().contiguous()
     u = model.update_net.out
     params = (model.perception_net.weight, u[0].weight, u[0].bias, u[2].weight, u[2].bias, u[4].weight)
@@ -46,13 +53,10 @@ def cond_grow_autograd(model, x: torch.Tensor, goal: Optional[torch.Tensor], T: 
     cfg = dict(T=T, us=us, alive_ch=model._alive_ch(), thr=model.alpha_living_threshold, fire_rate=model.cell_fire_rate,
                lo=-10.0, hi=10.0, seed=model.mask_seed, step0=model._mask_step)
     model._mask_step += T
-    if bf16:
-        if torch.is_grad_enabled() and _needs_grad(x, goal, *params):
-            raise NotImplementedError("ncahip: the bf16-storage grow loop is forward-only; train with float32 states "
-                                      "or call it under torch.no_grad()")
-        goal = None if goal is None else goal.detach().to(torch.bfloat16)
-    elif _needs_grad(x, goal, *params):
+    if _needs_grad(x, goal, *params):
         return _CondGrow.apply(x, goal, *params, cfg)
+    if bf16:
+        goal = None if goal is None else goal.detach().to(torch.bfloat16)
     w = ops.CondWeights(*params, x)
     out, _, _ = ops.cond_grow(x, T, goal, us, w, cfg["alive_ch"], cfg["thr"], cfg["fire_rate"], cfg["lo"], cfg["hi"],
                               cfg["seed"], cfg["step0"])

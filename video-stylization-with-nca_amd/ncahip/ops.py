@@ -236,11 +236,13 @@ def cond_grow_backward(states: torch.Tensor, pre: torch.Tensor, goal: Optional[t
                        w: CondWeights, g_final: torch.Tensor, T: int, alive_ch: int = 3, thr: float = 0.1,
                        fire_rate: float = 0.5, lo: float = -10.0, hi: float = 10.0, seed: int = 0, step0: int = 0):
     """Backward of cond_grow (states/pre = the keep_history=True buffers).  Returns a dict of gradients in the
-    reference parameter layouts: x0, goal, wp [3C,9], w1 [hid,3C], b1, w2 [hid,hid], b2, w3 [C,hid]."""
-    states, pre, g_final = _dev(states, "states"), _dev(pre, "pre", torch.uint8), _dev(g_final, "g_final")
+    reference parameter layouts: x0, goal, wp [3C,9], w1 [hid,3C], b1, w2 [hid,hid], b2, w3 [C,hid].  A bfloat16 history
+    (and goal) selects ncahip_cond_grow_bwd_bf16; g_final and every returned gradient are float32 either way."""
+    dt, sfx = _state_dtype(states)
+    states, pre, g_final = _dev(states, "states", dt), _dev(pre, "pre", torch.uint8), _dev(g_final.float(), "g_final")
     assert states.shape[0] == T + 1 and pre.shape[0] == T + 1
     _, B, C, H, W = states.shape
-    goal, gch = _goal_args(goal, B, C, H, W)
+    goal, gch = _goal_args(goal, B, C, H, W, dt)
     if us is not None:
         us = _dev(us, "us")
     dev, f32 = states.device, torch.float32
@@ -252,11 +254,10 @@ def cond_grow_backward(states: torch.Tensor, pre: torch.Tensor, goal: Optional[t
          "b2": torch.empty(hid, device=dev, dtype=f32), "w3": torch.empty(C, hid, device=dev, dtype=f32)}
     nbytes = lib().ncahip_cond_grow_bwd_workspace(B, C, H, W, hid)
     ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-    check(lib().ncahip_cond_grow_bwd_f32(_p(states), _p(pre), T, _p(goal), gch, _p(us), _p(w.wp), _p(w.w1), _p(w.b1),
-                                         _p(w.w2), _p(w.b2), _p(w.w3), B, C, H, W, hid, alive_ch, thr, fire_rate, lo, hi,
-                                         seed, step0, _p(g_final), _p(g["x0"]), _p(g["goal"]), _p(g["wp"]), _p(g["w1"]),
-                                         _p(g["b1"]), _p(g["w2"]), _p(g["b2"]), _p(g["w3"]), _p(ws), nbytes, _stream()),
-          "cond_grow_bwd")
+    check(getattr(lib(), "ncahip_cond_grow_bwd_" + sfx)(
+        _p(states), _p(pre), T, _p(goal), gch, _p(us), _p(w.wp), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), _p(w.w3), B, C, H, W,
+        hid, alive_ch, thr, fire_rate, lo, hi, seed, step0, _p(g_final), _p(g["x0"]), _p(g["goal"]), _p(g["wp"]), _p(g["w1"]),
+        _p(g["b1"]), _p(g["w2"]), _p(g["b2"]), _p(g["w3"]), _p(ws), nbytes, _stream()), "cond_grow_bwd_" + sfx)
     return g
 
 
