@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NCAHIP_VERSION 100 /* major*10000 + minor*100 + patch : 0.1.0 */
+#define NCAHIP_VERSION 200 /* major*10000 + minor*100 + patch : 0.2.0 */
 
 /* argument errors */
 #define NCAHIP_EINVAL (-1)   /* null pointer / non-positive size / bad enum            */
@@ -43,9 +43,9 @@ int ncahip_version(void);
 const char *ncahip_last_error(void);
 
 /* Largest shapes the fused step kernels accept (C <= max_c, fc <= max_fc, hidden <= 64).  The fp32 DyNCA *forward* entry
- * points additionally take 16 < C <= 32 (BASELINE configs[4]) and fc up to 1024 (one launch per 128-wide slice of the
- * hidden layer, the later ones accumulating into x_out); the bf16-storage and backward kernels cover fc <= max_fc, the
- * backward kernels C <= max_c.                                                                                          */
+ * points and ncahip_dynca_nsteps_bwd_f32 additionally take 16 < C <= 32 (BASELINE configs[4]) and fc up to 1024 (one launch
+ * per 128-wide slice of the hidden layer, the later ones accumulating); the single-step DyNCA backward entry points take
+ * C <= 32 with fc <= max_fc; the ConditionedNCA tile kernels (forward fast paths, bf16, backward) cover C <= max_c.        */
 int ncahip_limits(int *max_c, int *max_fc, int *max_hidden);
 
 /* Arithmetic of the UpdateNet products in ncahip_cond_step_fwd_f32 / ncahip_cond_grow_fwd_f32 (process-wide; C in {12,16},
@@ -133,6 +133,25 @@ int ncahip_dynca_step_bwd_w2_f32(const float *x_t, const float *cond, const floa
                                  float *gw2_out, int accumulate, void *workspace, size_t workspace_bytes,
                                  ncahip_stream_t stream);
 
+/* Backward of ncahip_dynca_nsteps_fwd_f32      autograd through dynca.py:168-178 (experiments.py:226,254)
+ *   The whole T-step loop is enqueued on the stream with caller-owned scratch (no allocation, no host round trip).  states:
+ *   the T+1 slots the forward kept with ring = T+1; cond / u (or seed, step0) / weights as in the forward.  g_final = dL/dx_T
+ *   (INCLUDING any cotangent of x_T itself); g_states (nullable): [T+1 slots] cotangents of the intermediate states x_t, slots
+ *   0..T-1 are added where x_t's gradient is formed (forward_nsteps' return_middle_feature).  Writes dL/dx_0 and the weight
+ *   gradients in the reference layouts g_w1 [fc, 4C+c_cond], g_b1 [fc], g_w2 [C, fc], g_b2 [C] (overwritten).  C <= 32,
+ *   fc <= 1024: hidden layers wider than 128 run as 128-wide slices (w2 relu(w1 y + b1) is a sum over hidden units; dL/dy is
+ *   accumulated over the slices, the weight gradients of different slices are independent).  Per step: perception of x_t,
+ *   per slice {fused MLP-backward kernel (dh, dL/dy, dW2|db2 on MFMA), dW1|db1 = ncahip_gram_rows_f32(dh, perception, cond)},
+ *   stencil adjoint.  Deterministic (fixed-order partial sums, no float atomics).                                          */
+size_t ncahip_dynca_nsteps_bwd_workspace(int B, int C, int H, int W, int fc, int c_cond);
+int ncahip_dynca_nsteps_bwd_f32(const float *states, int T, const float *cond, const float *u,
+                                const float *w1, const float *b1, const float *w2, const float *b2,
+                                int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                                float update_rate, uint64_t seed, uint64_t step0,
+                                const float *g_final, const float *g_states,
+                                float *g_x0, float *g_w1, float *g_b1, float *g_w2, float *g_b2,
+                                void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
+
 /* Weight-gradient products of the DyNCA backward with the cell axis as K (replaces the library GEMMs over transposed
  * copies that autograd through dynca.py:127-128 amounts to):
  *     out[i*nb + j] = sum over all B*HW cells of a[., i, .] * b[., j, .]     i < ma, j < nb = nb1 + nb2
@@ -140,6 +159,7 @@ int ncahip_dynca_step_bwd_w2_f32(const float *x_t, const float *cond, const floa
  * a [B, ma, HW]; the b rows come from two tensors, b1 [B, nb1, HW] then b2 [B, nb2, HW] (b2 may be NULL with nb2 = 0):
  * dW1 | db1 = gram(dh_out, perception, cond), dW2 | db2 = gram(g_next * mask, h_out).  Exact fp32 MFMA, per-workgroup
  * partials summed in a fixed order (deterministic).  Shapes: ma <= 128 with nb <= 80, or ma <= 32 with nb <= 128
+ * -- since 0.2.0: ma <= 128 with nb <= 144 --
  * (NCAHIP_ERANGE otherwise).  out holds ma*nb + ma floats; accumulate = 0 overwrites it, 1 adds to it (the sum over the
  * steps of a backward pass without a separate add per step).                                                          */
 size_t ncahip_gram_rows_workspace(int ma, int nb, int B, int HW);

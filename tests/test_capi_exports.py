@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol():
         assert name in _capi.SIGNATURES, f"{name} missing from the ctypes table"
         assert len(_capi.SIGNATURES[name]) == nargs, (name, len(_capi.SIGNATURES[name]), nargs)
     assert set(_capi.SIGNATURES) == set(protos)
-    assert _capi.version() == 100
+    assert _capi.version() == 200
     assert _capi.limits()[0] >= 16
 
 
@@ -72,12 +72,18 @@ def test_argument_validation_without_gpu():
     rc = L.ncahip_cond_step_fwd_bf16(ctypes.c_void_p(0x1002), None, two, one, None, 0, None, one, one, one, one, one, one,
                                      1, 16, 8, 8, 64, 3, 0.1, 0.5, -10.0, 10.0, 0, 0, None)
     assert rc == -2
-    # DyNCA forward accepts 16 < C <= 32, the backward does not
+    # DyNCA forward and backward accept C <= 32 (BASELINE configs[4]), nothing beyond
     rc = L.ncahip_dynca_step_fwd_f32(one, two, None, None, one, one, one, one, 1, 33, 8, 8, 96, 0, 1, 0.5, 0, 0, None)
     assert rc == -2
-    rc = L.ncahip_dynca_step_bwd_f32(one, None, None, one, one, one, one, 1, 32, 8, 8, 96, 0, 1, 0.5, 0, 0,
+    rc = L.ncahip_dynca_step_bwd_f32(one, None, None, one, one, one, one, 1, 33, 8, 8, 96, 0, 1, 0.5, 0, 0,
                                      one, two, one, one, one, None)
-    assert rc == -2 and b"backward" in L.ncahip_last_error()
+    assert rc == -2 and b"exceeds" in L.ncahip_last_error()
+    # the T-step backward driver: workspace size is a pure function of the shape; a short workspace is refused
+    need = L.ncahip_dynca_nsteps_bwd_workspace(2, 32, 64, 64, 256, 3)
+    assert need > 2 * 32 * 64 * 64 * 4 * (2 + 4 + 4) and L.ncahip_dynca_nsteps_bwd_workspace(0, 32, 64, 64, 256, 3) == 0
+    rc = L.ncahip_dynca_nsteps_bwd_f32(one, 2, two, None, one, one, one, one, 2, 32, 64, 64, 256, 3, 1, 0.5, 0, 0, one, None,
+                                       two, one, one, one, one, ctypes.c_void_p(0x4000), need - 1, None)
+    assert rc == -1 and b"workspace" in L.ncahip_last_error()
     # wide hidden layers (fc > 128) are an fp32-forward feature (one launch per 128-wide slice): bf16 storage and the
     # backward refuse them, and so does the forward beyond 1024
     rc = L.ncahip_dynca_step_fwd_bf16(one, two, None, None, one, one, one, one, 1, 16, 8, 8, 256, 0, 1, 0.5, 0, 0, None)

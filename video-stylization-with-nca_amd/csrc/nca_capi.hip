@@ -287,7 +287,6 @@ int ncahip_dynca_step_bwd_f32(const float* x_t, const float* cond, const float* 
     if (!g_next || !g_x || !h_out || !dh_out || !dy_scratch) return fail(NCAHIP_EINVAL, "dynca step bwd: null pointer");
     if (int rc = check_dynca(x_t, g_x, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
     if (g_next == g_x) return fail(NCAHIP_EINVAL, "dynca step bwd: g_next and g_x must not alias");
-    if (C > kMaxC) return fail(NCAHIP_ERANGE, "dynca step bwd: C=%d exceeds %d (the backward kernels cover C <= 16)", C, kMaxC);
     if ((size_t)(fc > 4 * C ? fc : 4 * C) * H * W * sizeof(float) >= ((size_t)1 << 32))
         return fail(NCAHIP_ERANGE, "dynca step bwd: fc*H*W*4 must stay below 4 GiB (32-bit store offsets inside a batch item)");
     NcaDyncaArgs a{x_t, nullptr, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step,
@@ -309,7 +308,6 @@ int ncahip_dynca_step_bwd_w2_f32(const float* x_t, const float* cond, const floa
     if (!g_next || !g_x || !dh_out || !dy_scratch || !gw2_out || !workspace) return fail(NCAHIP_EINVAL, "dynca step bwd_w2: null pointer");
     if (int rc = check_dynca(x_t, g_x, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
     if (g_next == g_x) return fail(NCAHIP_EINVAL, "dynca step bwd_w2: g_next and g_x must not alias");
-    if (C > kMaxC) return fail(NCAHIP_ERANGE, "dynca step bwd_w2: C=%d exceeds %d (the backward kernels cover C <= 16)", C, kMaxC);
     if ((size_t)(fc > 4 * C ? fc : 4 * C) * H * W * sizeof(float) >= ((size_t)1 << 32))
         return fail(NCAHIP_ERANGE, "dynca step bwd_w2: fc*H*W*4 must stay below 4 GiB (32-bit store offsets inside a batch item)");
     if (workspace_bytes < ncahip_dynca_step_bwd_w2_workspace(B, C, H, W, fc)) return fail(NCAHIP_EINVAL, "dynca step bwd_w2: workspace too small");
@@ -319,6 +317,108 @@ int ncahip_dynca_step_bwd_w2_f32(const float* x_t, const float* cond, const floa
     if (int rc = hip_result(nca_launch_dynca_step_bwd(a, (hipStream_t)stream), "dynca_step_bwd_w2")) return rc;
     return hip_result(nca_launch_reduce_rows((const float*)workspace, gw2_out, nca_dynca_bwd_grid(B, H, W), C * fc + C,
                                              (hipStream_t)stream, accumulate != 0), "dynca_step_bwd_w2 reduce");
+}
+
+// ---- backward of ncahip_dynca_nsteps_fwd_f32: the whole T-step loop on the stream, caller-owned workspace ----------------
+namespace {
+struct DyncaBwdPlan {
+    int nsl, fs;                 // hidden-layer slices of at most 128 units (fs = width of the full slices)
+    size_t n, off_g[2], off_y, off_dy, off_dh, off_ws2, off_wsg, off_acc1, off_acc2, total;
+    int grid2, gridg, K1;
+};
+DyncaBwdPlan dynca_bwd_plan(int B, int C, int H, int W, int fc, int c_cond) {
+    DyncaBwdPlan p{};
+    p.nsl = (fc + 127) / 128;
+    p.fs = fc < 128 ? fc : 128;
+    p.K1 = 4 * C + c_cond;
+    p.n = (size_t)B * C * H * W;
+    p.grid2 = nca_dynca_bwd_grid(B, H, W);
+    p.gridg = nca_gram_grid(B, H * W);
+    size_t o = 0;
+    auto take = [&](size_t floats) { size_t at = o; o += (floats * sizeof(float) + 255) & ~(size_t)255; return at; };
+    p.off_g[0] = take(p.n);
+    p.off_g[1] = take(p.n);
+    p.off_y = take(4 * p.n);
+    p.off_dy = take(4 * p.n);
+    p.off_dh = take((size_t)B * p.fs * H * W);
+    p.off_ws2 = take((size_t)p.grid2 * ((size_t)C * p.fs + C));
+    p.off_wsg = take((size_t)p.gridg * ((size_t)p.fs * p.K1 + p.fs));
+    p.off_acc1 = take((size_t)p.nsl * ((size_t)p.fs * p.K1 + p.fs));
+    p.off_acc2 = take((size_t)p.nsl * ((size_t)C * p.fs + C));
+    p.total = o;
+    return p;
+}
+}  // namespace
+
+size_t ncahip_dynca_nsteps_bwd_workspace(int B, int C, int H, int W, int fc, int c_cond) {
+    if (!dims_ok(B, C, H, W) || fc <= 0 || c_cond < 0) return 0;
+    return dynca_bwd_plan(B, C, H, W, fc, c_cond).total;
+}
+
+int ncahip_dynca_nsteps_bwd_f32(const float* states, int T, const float* cond, const float* u, const float* w1, const float* b1,
+                                const float* w2, const float* b2, int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                                float update_rate, uint64_t seed, uint64_t step0, const float* g_final, const float* g_states,
+                                float* g_x0, float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* workspace,
+                                size_t workspace_bytes, ncahip_stream_t stream) {
+    if (T < 1 || !states || !g_final || !g_x0 || !g_w1 || !g_b1 || !g_w2 || !g_b2 || !workspace)
+        return fail(NCAHIP_EINVAL, "dynca nsteps bwd: null pointer or T < 1");
+    if (int rc = check_dynca(states, g_x0, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, kMaxFcFwd)) return rc;
+    if ((size_t)(128 > 4 * C ? 128 : 4 * C) * H * W * sizeof(float) >= ((size_t)1 << 32))
+        return fail(NCAHIP_ERANGE, "dynca nsteps bwd: 4C*H*W*4 must stay below 4 GiB (32-bit store offsets inside a batch item)");
+    const DyncaBwdPlan p = dynca_bwd_plan(B, C, H, W, fc, c_cond);
+    if (workspace_bytes < p.total) return fail(NCAHIP_EINVAL, "dynca nsteps bwd: workspace too small");
+    if (((uintptr_t)workspace & 15) != 0) return fail(NCAHIP_ERANGE, "dynca nsteps bwd: workspace must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* const ws = (char*)workspace;
+    float* const gbuf[2] = {(float*)(ws + p.off_g[0]), (float*)(ws + p.off_g[1])};
+    float* const y = (float*)(ws + p.off_y);
+    float* const dy = (float*)(ws + p.off_dy);
+    float* const dh = (float*)(ws + p.off_dh);
+    float* const ws2 = (float*)(ws + p.off_ws2);
+    float* const wsg = (float*)(ws + p.off_wsg);
+    float* const acc1 = (float*)(ws + p.off_acc1);
+    float* const acc2 = (float*)(ws + p.off_acc2);
+    const size_t a1n = (size_t)p.fs * p.K1 + p.fs, a2n = (size_t)C * p.fs + C;
+    hipError_t e = hipMemsetAsync(acc1, 0, (size_t)p.nsl * a1n * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(acc2, 0, (size_t)p.nsl * a2n * sizeof(float), st);
+    if (e != hipSuccess) return hip_result(e, "dynca nsteps bwd memset");
+    const size_t slot = p.n, uslot = (size_t)B * H * W;
+    const float* gcur = g_final;
+    for (int t = T - 1; t >= 0; --t) {
+        const float* const x_t = states + (size_t)t * slot;
+        float* const g_out = t == 0 ? g_x0 : gbuf[t & 1];
+        if (int rc = hip_result(nca_launch_dynca_perceive(x_t, y, B, C, H, W, pad_mode, st), "dynca nsteps bwd perceive")) return rc;
+        for (int sl = 0; sl < p.nsl; ++sl) {
+            const int h0 = sl * 128, fs = fc - h0 < 128 ? fc - h0 : 128;
+            NcaDyncaArgs a{x_t, nullptr, cond, u ? u + (size_t)t * uslot : nullptr, w1 + (size_t)h0 * p.K1, b1 + h0, w2 + h0, b2, B, C, H, W,
+                           fs, c_cond, pad_mode, update_rate, seed, step0 + (uint64_t)t, gcur, nullptr, dh, dy, g_out};
+            a.w2_ld = fc;
+            a.gw2_ws = ws2;
+            if (int rc = hip_result(nca_launch_dynca_step_bwd_mlp(a, st, sl > 0), "dynca nsteps bwd step")) return rc;
+            // slabs hold [C x fs | C] of THIS slice (compact); slices narrower than p.fs use the front of their accumulator
+            if (int rc = hip_result(nca_launch_reduce_rows(ws2, acc2 + (size_t)sl * a2n, p.grid2, C * fs + C, st, true), "dynca nsteps bwd reduce")) return rc;
+            if (int rc = hip_result(nca_launch_gram_rows(dh, fs, y, 4 * C, cond, c_cond, B, H * W, acc1 + (size_t)sl * a1n, wsg, st, true),
+                                    "dynca nsteps bwd gram")) return rc;
+        }
+        NcaDyncaArgs s{x_t, nullptr, cond, nullptr, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step0 + (uint64_t)t,
+                       gcur, nullptr, dh, dy, g_out};
+        s.g_extra = g_states ? g_states + (size_t)t * slot : nullptr;
+        if (int rc = hip_result(nca_launch_dynca_step_bwd_stencil(s, st), "dynca nsteps bwd stencil")) return rc;
+        gcur = g_out;
+    }
+    // accumulators -> gradients in the reference layouts: w1 [fc, K1] rows of a slice are contiguous, w2 [C, fc] columns are not
+    for (int sl = 0; sl < p.nsl && e == hipSuccess; ++sl) {
+        const int h0 = sl * 128, fs = fc - h0 < 128 ? fc - h0 : 128;
+        const float* const s1 = acc1 + (size_t)sl * a1n;
+        const float* const s2 = acc2 + (size_t)sl * a2n;
+        e = hipMemcpyAsync(g_w1 + (size_t)h0 * p.K1, s1, (size_t)fs * p.K1 * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(g_b1 + h0, s1 + (size_t)fs * p.K1, fs * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync(g_w2 + h0, (size_t)fc * sizeof(float), s2, (size_t)fs * sizeof(float), (size_t)fs * sizeof(float), C,
+                                 hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess && sl == 0) e = hipMemcpyAsync(g_b2, s2 + (size_t)C * fs, C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    }
+    return hip_result(e, "dynca nsteps bwd copy");
 }
 
 // ---- weight-gradient products of the DyNCA backward (cell axis as K) -------------------------------------------------
@@ -332,8 +432,8 @@ int ncahip_gram_rows_f32(const float* a, int ma, const float* b1, int nb1, const
     if (!a || !b1 || !out || !workspace || (nb2 > 0) != (b2 != nullptr)) return fail(NCAHIP_EINVAL, "gram_rows: null pointer");
     if (ma <= 0 || nb1 <= 0 || nb2 < 0 || B <= 0 || HW <= 0) return fail(NCAHIP_EINVAL, "gram_rows: bad size");
     const int nb = nb1 + nb2;
-    if (!((ma <= 32 && nb <= 128) || (ma <= 128 && nb <= 80)))
-        return fail(NCAHIP_ERANGE, "gram_rows: ma=%d nb=%d outside (<=32 x <=128) / (<=128 x <=80)", ma, nb);
+    if (!((ma <= 32 && nb <= 128) || (ma <= 128 && nb <= 144)))
+        return fail(NCAHIP_ERANGE, "gram_rows: ma=%d nb=%d outside (<=32 x <=128) / (<=128 x <=144)", ma, nb);
     if (workspace_bytes < ncahip_gram_rows_workspace(ma, nb, B, HW)) return fail(NCAHIP_EINVAL, "gram_rows: workspace too small");
     return hip_result(nca_launch_gram_rows(a, ma, b1, nb1, b2, nb2, B, HW, out, (float*)workspace, (hipStream_t)stream,
                                            accumulate != 0), "gram_rows");

@@ -29,7 +29,7 @@ template <int RT, int CT, bool ROWSPLIT>
 __global__ __launch_bounds__(kGramThreads, 2) void gram_rows_kernel(const GramArgs a) {
     constexpr int MA_T = ROWSPLIT ? 4 * RT : RT, NB_T = ROWSPLIT ? CT : 4 * CT;
     constexpr int ROWS = 16 * (MA_T + NB_T), PER = ROWS / 4;   // rows staged per chunk; rows per wave
-    __shared__ float lds[ROWS * kGramLS];
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // ROWS * kGramLS floats (74 KB at CT = 9: dynamic)
     const int tid = threadIdx.x, lane = tid & 63, g = (lane >> 4) & 3, ci = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = a.nb1 + a.nb2, HW = a.HW;
@@ -144,7 +144,14 @@ __global__ __launch_bounds__(kGramThreads, 2) void gram_rows_kernel(const GramAr
 
 template <int RT, int CT, bool ROWSPLIT>
 hipError_t launch_gram(const GramArgs& a, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((gram_rows_kernel<RT, CT, ROWSPLIT>), dim3(grid), dim3(kGramThreads), 0, st, a);
+    constexpr int MA_T = ROWSPLIT ? 4 * RT : RT, NB_T = ROWSPLIT ? CT : 4 * CT;
+    constexpr size_t lds = (size_t)16 * (MA_T + NB_T) * kGramLS * sizeof(float);
+    auto kern = gram_rows_kernel<RT, CT, ROWSPLIT>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kGramThreads), lds, st, a);
     return hipGetLastError();
 }
 
@@ -160,7 +167,7 @@ int nca_gram_grid(int B, int HW) {
 }
 
 // out[ma*nb + ma] (+)= [products | row sums of A]; ws holds nca_gram_grid(B, HW) partials of that size.
-// Shapes: ma <= 128 with nb <= 80 (dW1-like: rows split over the waves), or ma <= 32 with nb <= 128 (dW2-like).
+// Shapes: ma <= 128 with nb <= 144 (dW1-like: rows split over the waves), or ma <= 32 with nb <= 128 (dW2-like).
 hipError_t nca_launch_gram_rows(const float* a, int ma, const float* b1, int nb1, const float* b2, int nb2, int B, int HW,
                                 float* out, float* ws, hipStream_t st, bool accumulate) {
     const int nb = nb1 + nb2, grid = nca_gram_grid(B, HW);
@@ -170,6 +177,7 @@ hipError_t nca_launch_gram_rows(const float* a, int ma, const float* b1, int nb1
     if ((size_t)ma * HW * 4 >= lim || (size_t)nb1 * HW * 4 >= lim || (size_t)nb2 * HW * 4 >= lim) return hipErrorInvalidValue;
     if (ma <= 32 && nb <= 128) e = ma <= 16 ? launch_gram<1, 2, false>(ga, grid, st) : launch_gram<2, 2, false>(ga, grid, st);
     else if (ma <= 128 && nb <= 80) e = ma <= 64 ? launch_gram<1, 5, true>(ga, grid, st) : launch_gram<2, 5, true>(ga, grid, st);
+    else if (ma <= 128 && nb <= 144) e = ma <= 64 ? launch_gram<1, 9, true>(ga, grid, st) : launch_gram<2, 9, true>(ga, grid, st);   // C = 32: 4C + c_cond = 131
     if (e != hipSuccess) return e;
     return nca_launch_reduce_rows(ws, out, grid, ma * nb + ma, st, accumulate);
 }

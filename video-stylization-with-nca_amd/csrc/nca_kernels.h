@@ -22,6 +22,7 @@ struct NcaDyncaArgs {
     // fc > 128 runs as several launches over 128-wide slices of the hidden layer (nca_launch_dynca_step_fwd):
     int w2_ld;             // row stride of w2 (0: = fc); later slices run the accumulating instantiation (x_out += mask * slice)
     float* gw2_ws;         // backward, fused dW2: per-workgroup partials [grid][C*fc + C] (dW2 | db2); hbuf is then not written
+    const float* g_extra;  // backward stencil: optional cotangent of x_t itself, added to g_out (forward_nsteps' middle features)
 };
 
 struct NcaCondArgs {
@@ -70,6 +71,8 @@ hipError_t nca_launch_reduce_wp(const float* part, float* dst, int B, int C, int
 hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st);
 hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st);
 hipError_t nca_launch_dynca_step_bwd(const NcaDyncaArgs& a, hipStream_t st);
+hipError_t nca_launch_dynca_step_bwd_mlp(const NcaDyncaArgs& a, hipStream_t st, bool acc);      // MLP part only (hidden-layer slices)
+hipError_t nca_launch_dynca_step_bwd_stencil(const NcaDyncaArgs& a, hipStream_t st);            // stencil adjoint + residual
 hipError_t nca_launch_dynca_step_fwd_bf16(const NcaDyncaArgs& a, hipStream_t st);   // x_in / x_out hold bf16
 // wave-private-tile variant (nca_cond_wave.hip); needs W % 4 == 0 and 16-byte aligned x_in / goal
 hipError_t nca_launch_cond_step_fwd_wave(const NcaCondArgs& a, hipStream_t st);

@@ -187,12 +187,12 @@ struct DyncaCfg {
     static constexpr int OFF_MK = OFF_Z + CP * CS;
     static constexpr int OFF_CN = OFF_MK + TH * TW;
     static constexpr int LDS_FLOATS = OFF_CN + (HAS_COND ? 4 * TH * TW : 0);
-    // backward variant: transposed A-operand images
-    static constexpr int MJ = (4 * CP + (HAS_COND ? 4 : 0) + 15) / 16;  // 16-row tiles of the perception index j
-    static constexpr int OFF_W2T = LDS_FLOATS;                        // [M1T][4][64]:  W2[ch=4gg+s][h=16m+i]
-    static constexpr int OFF_W1T = OFF_W2T + M1T * 4 * 64;            // [MJ][K2S][64]: W1[h=k(s,gg)][j=16mj+i]
-    static constexpr int LDS_FLOATS_BWD = OFF_W1T + MJ * K2S * 64;
-    static constexpr int TBS = 20;                                    // transposition tiles [16 cells][TBS] (16-byte rows)
+    // backward variant: the transposed operands (W2^T for dh, W1^T for dL/dy) are 16-byte reads of the FORWARD images (see the
+    // kernel), so the backward needs no weight images of its own.  dL/dy is produced in tiles of 16 rows = 4 channels x 4
+    // filters (row i <-> channel 4mj + (i & 3), filter i >> 2): MJ = CP / 4 tiles, no conditioning rows (dynca.py:123).
+    static constexpr int MJ = CP / 4;
+    static constexpr int LDS_FLOATS_BWD = LDS_FLOATS;
+    static constexpr int TBS = M2T == 1 ? 20 : 36;                    // transposition tiles [16 cells][TBS] (16-byte rows)
     static constexpr int OFF_TB = LDS_FLOATS_BWD;                     // fused dW2: per wave NT tiles
     static constexpr int LDS_FLOATS_BWD_W2 = OFF_TB + 4 * NT * 16 * TBS;
     static_assert(FC % 16 == 0 && CP % 4 == 0 && TW % 16 == 0, "shape");
@@ -208,9 +208,8 @@ struct DyncaCfg {
 // (dW2 = (G*mask) h^T, dW1 = dh y^T, K = all cells) are plain library GEMMs on those buffers.
 template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT, bool VEC, bool BWD = false, bool B16 = false, bool ACC = false, bool W2F = false>
 __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(const NcaDyncaArgs a) {
-    static_assert(!W2F || (BWD && CP <= 16), "fused dW2 is an option of the backward kernel (one 16-row channel tile)");
-    static_assert(!(BWD && B16), "the bf16-storage step is forward only");
-    static_assert(!ACC || (!BWD && !B16), "accumulating passes (fc slices beyond the first) exist for the fp32 forward only");
+    static_assert(!W2F || BWD, "fused dW2 is an option of the backward kernel");
+    static_assert(!ACC || !B16, "accumulating passes (fc slices beyond the first) read fp32 partial results");
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
     using Pos = TilePos<TH, TW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -245,30 +244,28 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
     });
     fill_image<FC>(B1L, a.b1, tid, [&](int idx) -> long { return idx < fc ? idx : -1; });
     fill_image<K::M2T * 16>(B2L, a.b2, tid, [&](int idx) -> long { return (idx < C && !ACC) ? idx : -1; });
-    const float* const W2T = smem + K::OFF_W2T;
-    const float* const W1T = smem + K::OFF_W1T;
-    if (BWD) {
-        fill_image<K::M1T * 4 * 64>(smem + K::OFF_W2T, a.w2, tid, [&](int idx) -> long {
-            const int l = idx & 63, s = (idx >> 6) % 4, m = (idx >> 6) / 4;
-            const int ch = 4 * (l >> 4) + s, h = 16 * m + (l & 15);
-            return (ch < C && h < fc) ? (long)ch * fc + h : -1;
-        });
-        fill_image<K::MJ * K::K2S * 64>(smem + K::OFF_W1T, a.w1, tid, [&](int idx) -> long {
-            const int l = idx & 63, s = (idx >> 6) % K::K2S, mj = (idx >> 6) / K::K2S;
-            const int h = 16 * (s >> 2) + 4 * (l >> 4) + (s & 3), j = 16 * mj + (l & 15);
-            return (h < fc && j < K1) ? (long)h * K1 + j : -1;
-        });
-    }
+    // Transposed operands of the backward, read from the forward images with ONE 16-byte LDS read each (the 64 lanes of a read
+    // cover 1 KiB contiguously: conflict-free):
+    //   W2^T, k-steps s = 0..3 of (m, m2):  W2[ch = 16 m2 + 4g + s][h = 16 m + ci]  = W2L[(m2*K2S + 4m + (ci&3))*64 + (ci>>2)*16 + 4g + s]
+    //   W1^T, k-steps r = 0..3 of (m, mj):  W1[h = 16 m + 4g + r][row ci of tile mj] = W1L[(m*K1S + 4mj + (ci>>2))*64 + (ci&3)*16 + 4g + r]
+    // with row ci of dL/dy tile mj standing for channel 4mj + (ci & 3), filter ci >> 2.
+    const int w2t_lane = (ci & 3) * 64 + (ci >> 2) * 16 + 4 * g;
+    const int w1t_lane = (ci >> 2) * 64 + (ci & 3) * 16 + 4 * g;
 
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int ntiles = a.B * tiles_x * tiles_y;
     const size_t plane = (size_t)H * W;
     // fused dW2 (W2F): dW2[ch][hid] = sum_cells dO[ch][cell] * h[hid][cell] accumulated over the whole launch, one 16x16
     // tile per hidden tile m (rows = channels 4g+r, column = hidden 16m+ci), and db2 = sum_cells dO
-    f32x4 w2acc[W2F ? K::M1T : 1];
-    float b2acc[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 w2acc[W2F ? K::M1T : 1][K::M2T];
+    float b2acc[K::M2T][4];
 #pragma unroll
-    for (int m = 0; m < (W2F ? K::M1T : 1); ++m) w2acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m2 = 0; m2 < K::M2T; ++m2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b2acc[m2][r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < (W2F ? K::M1T : 1); ++m) w2acc[m][m2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     float* const TBW = smem + K::OFF_TB + wave * (NT * 16 * K::TBS);
 
     for (NcaTileWalk tw = nca_tile_walk(ntiles); tw.t < tw.end; tw.t += tw.stride) {
@@ -358,7 +355,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
             }
             if constexpr (BWD) {
                 // ---- backward data path -----------------------------------------------------------------
-                float dO[NT][4];   // dL/d(out) = G * mask, accumulator layout (channel 4g+r, cell ci)
+                float dO[NT][K::M2T][4];   // dL/d(out) = G * mask, accumulator layout (channel 16 m2 + 4g + r, cell ci)
                 bool live[NT];
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
@@ -367,39 +364,49 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                     const float mk = MK[r0[n] * TW + q0[n]];
                     const float* const gb = a.g_next + (size_t)b * C * plane + (live[n] ? (size_t)gy * W + gx : 0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ch = 4 * g + r;
-                        const float gv = gb[(size_t)min(ch, C - 1) * plane];
-                        dO[n][r] = (live[n] && ch < C) ? gv * mk : 0.0f;
-                    }
+                    for (int m2 = 0; m2 < K::M2T; ++m2)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ch = 16 * m2 + 4 * g + r;
+                            const float gv = gb[(size_t)min(ch, C - 1) * plane];
+                            dO[n][m2][r] = (live[n] && ch < C) ? gv * mk : 0.0f;
+                        }
                 }
-                // Output addressing: the lane's part (cell, 4g rows) is ONE vector offset per n, the (16m + r) row of each store a
-                // scalar offset -- per-store 64-bit vector address arithmetic was ~1300 VALU instructions per pass, in the same
-                // issue slots as the exact-f32 MFMAs.  (Launcher: fc*H*W*4 and 4C*H*W*4 below 4 GiB.)
+                // Output addressing: the lane's part (cell, lane-dependent row group) is ONE vector offset per n, the remaining row
+                // index of each store a scalar offset -- per-store 64-bit vector address arithmetic was ~1300 VALU instructions per
+                // pass, in the same issue slots as the exact-f32 MFMAs.  (Launcher: fc*H*W*4 and 4C*H*W*4 below 4 GiB.)
                 const unsigned plane4 = (unsigned)plane * 4u;
                 const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(a.hbuf + (size_t)b * fc * plane, 0, -1, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rdh = __builtin_amdgcn_make_buffer_rsrc(a.dhbuf + (size_t)b * fc * plane, 0, -1, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(a.dybuf + (size_t)b * 4 * C * plane, 0, -1, 0x00020000);
-                unsigned vo[NT];
+                unsigned vo[NT], voy[NT];
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    vo[n] = (live[n] ? (unsigned)((ty0 + r0[n]) * W + tx0 + q0[n]) * 4u : 0u) + (unsigned)(4 * g) * plane4;
-                const int lim_h = fc - 4 * g, lim_y = 4 * C - 4 * g;   // row 16m + 4g + r exists <=> 16m + r < lim
+                for (int n = 0; n < NT; ++n) {
+                    const unsigned cellb = live[n] ? (unsigned)((ty0 + r0[n]) * W + tx0 + q0[n]) * 4u : 0u;
+                    vo[n] = cellb + (unsigned)(4 * g) * plane4;             // h / dh rows 16m + 4g + r
+                    voy[n] = cellb + (unsigned)(g * C) * plane4;            // dL/dy rows g*C + (4mj + r): filter g, channel 4mj + r
+                }
+                const int lim_h = fc - 4 * g;   // row 16m + 4g + r exists <=> 16m + r < lim_h
                 // fused dW2: the A operands dO[ch = ci][cell 4s+g] of every n, transposed once per pass through the wave's
-                // LDS tiles (lane (g,ci) writes its four channel rows of cell ci with one 16-byte store)
-                float doT[W2F ? NT : 1][4];
+                // LDS tiles (lane (g,ci) writes its four channel rows of cell ci with one 16-byte store per channel tile)
+                float doT[W2F ? NT : 1][K::M2T][4];
                 if constexpr (W2F) {
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        *reinterpret_cast<f32x4*>(TBW + n * 16 * K::TBS + ci * K::TBS + 4 * g) = f32x4{dO[n][0], dO[n][1], dO[n][2], dO[n][3]};
+                    for (int n = 0; n < NT; ++n)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) b2acc[r] += dO[n][r];
-                    }
+                        for (int m2 = 0; m2 < K::M2T; ++m2) {
+                            *reinterpret_cast<f32x4*>(TBW + n * 16 * K::TBS + ci * K::TBS + 16 * m2 + 4 * g) =
+                                f32x4{dO[n][m2][0], dO[n][m2][1], dO[n][m2][2], dO[n][m2][3]};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) b2acc[m2][r] += dO[n][m2][r];
+                        }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
 #pragma unroll
-                        for (int s_ = 0; s_ < 4; ++s_) doT[n][s_] = TBW[n * 16 * K::TBS + (4 * s_ + g) * K::TBS + ci];
+                        for (int m2 = 0; m2 < K::M2T; ++m2)
+#pragma unroll
+                            for (int s_ = 0; s_ < 4; ++s_) doT[n][m2][s_] = TBW[n * 16 * K::TBS + (4 * s_ + g) * K::TBS + 16 * m2 + ci];
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 }
                 f32x4 dY[K::MJ][NT];
@@ -411,7 +418,8 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                 // before its use costs the full LDS round trip each time): layer-1 operands of hidden tile m+1 during the
                 // dL/dy products of tile m, the transposed operands of tile m during its layer-1 chain.  The fences keep the
                 // compiler from sinking the reads back to their uses.
-                float wa1[K::K1S], wt2[4], wt1[4][K::MJ];
+                float wa1[K::K1S];
+                f32x4 wt2[K::M2T], wt1[K::MJ];
                 f32x4 bias1;
                 auto fetch1 = [&](int m) {
                     const float* const w1m = W1L + m * K::K1S * 64 + lane;
@@ -421,11 +429,9 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                 };
                 auto fetch_t = [&](int m) {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) wt2[s] = W2T[(m * 4 + s) * 64 + lane];
+                    for (int m2 = 0; m2 < K::M2T; ++m2) wt2[m2] = *reinterpret_cast<const f32x4*>(W2L + (m2 * K::K2S + 4 * m) * 64 + w2t_lane);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int mj = 0; mj < K::MJ; ++mj) wt1[r][mj] = W1T[(mj * K::K2S + 4 * m + r) * 64 + lane];
+                    for (int mj = 0; mj < K::MJ; ++mj) wt1[mj] = *reinterpret_cast<const f32x4*>(W1L + (m * K::K1S + 4 * mj) * 64 + w1t_lane);
                 };
                 fetch1(0);
                 float hT[W2F ? NT : 1][4];
@@ -442,10 +448,12 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                         for (int n = 0; n < NT; ++n) acc1[n] = nca_mfma(wa1[s], P[n][s], acc1[n]);
                     }
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
+                    for (int m2 = 0; m2 < K::M2T; ++m2)
 #pragma unroll
-                        for (int n = 0; n < NT; ++n) dacc[n] = nca_mfma(wt2[s], dO[n][s], dacc[n]);
-                    }
+                        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) dacc[n] = nca_mfma(wt2[m2][s], dO[n][m2][s], dacc[n]);
+                        }
                     __builtin_amdgcn_sched_barrier(0);
                     if (m + 1 < K::M1T) fetch1(m + 1);
                     __builtin_amdgcn_sched_barrier(0);
@@ -478,27 +486,44 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
 #pragma unroll
                         for (int mj = 0; mj < K::MJ; ++mj) {
 #pragma unroll
-                            for (int n = 0; n < NT; ++n) dY[mj][n] = nca_mfma(wt1[r][mj], dacc[n][r], dY[mj][n]);
+                            for (int n = 0; n < NT; ++n) dY[mj][n] = nca_mfma(wt1[mj][r], dacc[n][r], dY[mj][n]);
                         }
                     if constexpr (W2F) {
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int n = 0; n < NT; ++n)
 #pragma unroll
-                            for (int s_ = 0; s_ < 4; ++s_) w2acc[m] = nca_mfma(doT[n][s_], hT[n][s_], w2acc[m]);
+                            for (int m2 = 0; m2 < K::M2T; ++m2)
+#pragma unroll
+                                for (int s_ = 0; s_ < 4; ++s_) w2acc[m][m2] = nca_mfma(doT[n][m2][s_], hT[n][s_], w2acc[m][m2]);
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the tiles are rewritten by the next hidden tile
                     }
                 }
+                // dL/dy out: tile mj, register r of lane (g, cell) = channel 4mj + r, filter g -> plane g*C + 4mj + r.  Later
+                // slices of a wide hidden layer (ACC) add to what the earlier launches wrote.
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     if (!live[n]) continue;
+                    float prev[K::MJ][4];
+                    if constexpr (ACC) {
+#pragma unroll
+                        for (int mj = 0; mj < K::MJ; ++mj)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                prev[mj][r] = (4 * mj + r < C) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                                                     rdy, (int)voy[n], (int)((unsigned)(4 * mj + r) * plane4), 0))
+                                                               : 0.0f;
+                    }
 #pragma unroll
                     for (int mj = 0; mj < K::MJ; ++mj)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            if (16 * mj + r < lim_y)
-                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dY[mj][n][r]), rdy, (int)vo[n],
-                                                                      (int)((unsigned)(16 * mj + r) * plane4), 0);
+                            if (4 * mj + r < C) {
+                                float v = dY[mj][n][r];
+                                if constexpr (ACC) v += prev[mj][r];
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rdy, (int)voy[n],
+                                                                      (int)((unsigned)(4 * mj + r) * plane4), 0);
+                            }
                         }
                 }
             } else {
@@ -591,20 +616,24 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
     }
     if constexpr (W2F) {
         // the four waves' dW2 / db2 partials are summed through LDS (weight images and tiles are dead) into the workgroup's slab
-        constexpr int SW = 16 * FC + 16;
+        constexpr int CH = 16 * K::M2T, SW = CH * FC + CH;
         __syncthreads();
         float* const sw = smem + wave * SW;
 #pragma unroll
         for (int m = 0; m < K::M1T; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sw[(4 * g + r) * FC + 16 * m + ci] = w2acc[m][r];
+            for (int m2 = 0; m2 < K::M2T; ++m2)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = b2acc[r];
+                for (int r = 0; r < 4; ++r) sw[(16 * m2 + 4 * g + r) * FC + 16 * m + ci] = w2acc[m][m2][r];
 #pragma unroll
-            for (int d = 1; d < 16; d <<= 1) v += __shfl_xor(v, d);
-            if (ci == 0) sw[16 * FC + 4 * g + r] = v;
-        }
+        for (int m2 = 0; m2 < K::M2T; ++m2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = b2acc[m2][r];
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) v += __shfl_xor(v, d);
+                if (ci == 0) sw[CH * FC + 16 * m2 + 4 * g + r] = v;
+            }
         __syncthreads();
         float* const slab = a.gw2_ws + (size_t)blockIdx.x * ((size_t)C * fc + C);
         for (int i = tid; i < C * fc; i += kThreads) {
@@ -612,7 +641,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
             slab[i] = (smem[o] + smem[SW + o]) + (smem[2 * SW + o] + smem[3 * SW + o]);
         }
         if (tid < C) {
-            const int o = 16 * FC + tid;
+            const int o = CH * FC + tid;
             slab[(size_t)C * fc + tid] = (smem[o] + smem[SW + o]) + (smem[2 * SW + o] + smem[3 * SW + o]);
         }
     }
@@ -1017,35 +1046,31 @@ hipError_t launch_dynca(const NcaDyncaArgs& a, hipStream_t st) {
     return vec ? launch_dynca_v<CP, FC, HAS_COND, true, false, ACC>(a, st) : launch_dynca_v<CP, FC, HAS_COND, false, false, ACC>(a, st);
 }
 
-template <int CP, int FC, bool HAS_COND>
+template <int CP, int FC, bool HAS_COND, bool ACC>
 hipError_t launch_dynca_bwd(const NcaDyncaArgs& a, hipStream_t st) {
-    constexpr int TH = 8, TW = 32, NT = 4;
+    constexpr int TH = 8, TW = 32, NT = CP > 16 ? 2 : 4;
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
-    static_assert(K::kBwdFits, "LDS budget (backward)");
+    static_assert(K::LDS_FLOATS_BWD_W2 * 4 <= 160 * 1024 && 4 * (16 * K::M2T * FC + 16 * K::M2T) <= K::LDS_FLOATS_BWD_W2, "LDS budget (backward)");
     const bool vec = (a.W % 4 == 0) && aligned16(a.x_in);
-    const size_t lds = (size_t)K::LDS_FLOATS_BWD * sizeof(float);
     const int ntiles = a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
     const int grid = grid_for(ntiles, 1);
-    auto go = [&](auto kern) -> hipError_t {
+    auto go = [&](auto kern, size_t lds) -> hipError_t {
         hipError_t e = set_lds(kern, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, a);
         return hipGetLastError();
     };
     if (a.gw2_ws) {   // fused dW2 | db2: per-workgroup partials, h is not written
-        static_assert(K::LDS_FLOATS_BWD_W2 * 4 <= 160 * 1024 && 4 * (16 * FC + 16) <= K::LDS_FLOATS_BWD_W2, "LDS budget (fused dW2)");
         const size_t lds2 = (size_t)K::LDS_FLOATS_BWD_W2 * sizeof(float);
-        auto go2 = [&](auto kern) -> hipError_t {
-            hipError_t e = set_lds(kern, lds2);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds2, st, a);
-            return hipGetLastError();
-        };
-        return vec ? go2(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, true, true, false, false, true>)
-                   : go2(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, false, true, false, false, true>);
+        return vec ? go(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, true, true, false, ACC, true>, lds2)
+                   : go(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, false, true, false, ACC, true>, lds2);
     }
-    return vec ? go(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, true, true>)
-               : go(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, false, true>);
+    if constexpr (ACC) return hipErrorInvalidValue;   // hidden-layer slices exist for the fused-dW2 form only
+    else {
+        const size_t lds = (size_t)K::LDS_FLOATS_BWD * sizeof(float);
+        return vec ? go(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, true, true>, lds)
+                   : go(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, false, true>, lds);
+    }
 }
 
 // dL/dx_t = G + dy[0:C] + adj(Sx)(dy[C:2C]) + adj(Sy)(dy[2C:3C]) + adj(L)(dy[3C:4C]), where adj is the adjoint of
@@ -1057,6 +1082,7 @@ __device__ float dynca_bwd_cell(const NcaDyncaArgs& a, int b, int c, int py, int
     const float* const dy = a.dybuf + (size_t)b * 4 * C * plane;
     const size_t off = (size_t)py * W + px;
     float acc = a.g_next[((size_t)b * C + c) * plane + off] + dy[(size_t)c * plane + off];
+    if (a.g_extra) acc += a.g_extra[((size_t)b * C + c) * plane + off];   // cotangent of the intermediate state itself
     // per axis: for candidate offset iq in {-1,0,1} and tap t in {-1,0,1}: does pad(q + t) land on p ?
     int qy[3], qx[3];
     bool hy[3][3], hx[3][3];
@@ -1127,6 +1153,10 @@ __global__ __launch_bounds__(256) void dynca_step_bwd_stencil_vec_kernel(const N
     const float4 gv = *reinterpret_cast<const float4*>(a.g_next + ((size_t)b * C + c) * plane + (size_t)py * W + x0);
     const float4 d0 = *reinterpret_cast<const float4*>(dy + (size_t)c * plane);
     float acc[4] = {gv.x + d0.x, gv.y + d0.y, gv.z + d0.z, gv.w + d0.w};
+    if (a.g_extra) {
+        const float4 ge = *reinterpret_cast<const float4*>(a.g_extra + ((size_t)b * C + c) * plane + (size_t)py * W + x0);
+        acc[0] += ge.x; acc[1] += ge.y; acc[2] += ge.z; acc[3] += ge.w;
+    }
     float v[3][3][6];   // [filter plane][row y-1..y+1][col x0-1..x0+4]
 #pragma unroll
     for (int f = 0; f < 3; ++f)
@@ -1250,14 +1280,26 @@ int nca_dynca_bwd_grid(int B, int H, int W) {
     return grid_for(ntiles, 1);
 }
 
-hipError_t nca_launch_dynca_step_bwd(const NcaDyncaArgs& a, hipStream_t st) {
+// The MLP part of one backward step (writes dh, dL/dy and, with gw2_ws, the per-workgroup dW2 | db2 partials).  acc: a later
+// 128-wide slice of a wide hidden layer -- dL/dy is added to what the earlier slices wrote.
+hipError_t nca_launch_dynca_step_bwd_mlp(const NcaDyncaArgs& a, hipStream_t st, bool acc) {
     const bool hc = a.c_cond > 0;
-    hipError_t e = hipErrorInvalidValue;
-    if (a.C <= 12 && a.fc <= 96) e = hc ? launch_dynca_bwd<12, 96, true>(a, st) : launch_dynca_bwd<12, 96, false>(a, st);
-    else if (a.C <= 16 && a.fc <= 128) e = hc ? launch_dynca_bwd<16, 128, true>(a, st) : launch_dynca_bwd<16, 128, false>(a, st);
-    if (e != hipSuccess) return e;
+    if (!acc) {
+        if (a.C <= 12 && a.fc <= 96) return hc ? launch_dynca_bwd<12, 96, true, false>(a, st) : launch_dynca_bwd<12, 96, false, false>(a, st);
+        if (a.C <= 16 && a.fc <= 128) return hc ? launch_dynca_bwd<16, 128, true, false>(a, st) : launch_dynca_bwd<16, 128, false, false>(a, st);
+        if (a.C <= 32 && a.fc <= 128) return hc ? launch_dynca_bwd<32, 128, true, false>(a, st) : launch_dynca_bwd<32, 128, false, false>(a, st);
+        return hipErrorInvalidValue;
+    }
+    if (a.C <= 16 && a.fc <= 128) return hc ? launch_dynca_bwd<16, 128, true, true>(a, st) : launch_dynca_bwd<16, 128, false, true>(a, st);
+    if (a.C <= 32 && a.fc <= 128) return hc ? launch_dynca_bwd<32, 128, true, true>(a, st) : launch_dynca_bwd<32, 128, false, true>(a, st);
+    return hipErrorInvalidValue;
+}
+
+// The stencil-adjoint part: g_out = g_next (+ g_extra) + adj(perception)(dybuf).
+hipError_t nca_launch_dynca_step_bwd_stencil(const NcaDyncaArgs& a, hipStream_t st) {
     const size_t n = (size_t)a.B * a.C * a.H * a.W;
-    const bool vec = (a.W % 4 == 0) && a.W >= 12 && a.H >= 3 && aligned16(a.g_next) && aligned16(a.g_out) && aligned16(a.dybuf);
+    const bool vec = (a.W % 4 == 0) && a.W >= 12 && a.H >= 3 && aligned16(a.g_next) && aligned16(a.g_out) && aligned16(a.dybuf) &&
+                     (a.g_extra == nullptr || aligned16(a.g_extra));
     if (vec && a.H >= 5) {
         hipLaunchKernelGGL(dynca_step_bwd_stencil_vec_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, a);
         const size_t nb = (size_t)a.B * a.C * (4 * a.W + 8 * (a.H - 4));
@@ -1266,6 +1308,12 @@ hipError_t nca_launch_dynca_step_bwd(const NcaDyncaArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(dynca_step_bwd_stencil_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     }
     return hipGetLastError();
+}
+
+hipError_t nca_launch_dynca_step_bwd(const NcaDyncaArgs& a, hipStream_t st) {
+    hipError_t e = nca_launch_dynca_step_bwd_mlp(a, st, false);
+    if (e != hipSuccess) return e;
+    return nca_launch_dynca_step_bwd_stencil(a, st);
 }
 
 hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st) {

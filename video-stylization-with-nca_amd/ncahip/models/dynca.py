@@ -118,13 +118,10 @@ class DyNCA(nn.Module):
         return list(self.perception_scales) != [0]
 
     def _composed(self, x) -> bool:
-        """True when the step runs as HIP stencil + library GEMMs instead of the fused kernels: multi-scale perception, or
-        a differentiable pass at 16 < C <= 32 or fc > 128 (the fused backward kernels cover C <= 16, fc <= 128; BASELINE
-        configs[4] trains at C = 32).  The forward alone stays fused: fc > 128 runs as one launch per 128-wide slice."""
-        if self._multiscale():
-            return True
-        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        return (self.c_in > 16 or self.w1.out_channels > 128) and needs_grad
+        """True when the step runs as HIP stencil + library GEMMs instead of the fused kernels: multi-scale perception only.
+        Forward and backward are fused for every C <= 32 and fc <= 1024 (BASELINE configs[4] trains at C = 32, fc = 256:
+        hidden layers wider than 128 run as one launch per 128-wide slice)."""
+        return self._multiscale()
 
     # ------------------------------------------------------------------ reference surface
     def perceive_torch(self, x, scale=0):

@@ -285,66 +285,38 @@ def gram_rows(a: torch.Tensor, b1: torch.Tensor, b2: Optional[torch.Tensor] = No
 
 
 def _gram_fits(ma: int, nb: int) -> bool:
-    return (ma <= 32 and nb <= 128) or (ma <= 128 and nb <= 80)
+    return (ma <= 32 and nb <= 128) or (ma <= 128 and nb <= 144)
 
 
 def dynca_nsteps_backward(states: torch.Tensor, cond: Optional[torch.Tensor], us: Optional[torch.Tensor], w: DyncaWeights,
                           g_final: torch.Tensor, g_states: Optional[torch.Tensor], T: int, pad_mode: str = "replicate",
                           update_rate: float = 0.5, seed: int = 0, step0: int = 0):
-    """Backward of dynca_nsteps (states = the keep_history=True buffer [T+1,B,C,H,W]).  Per step the HIP kernels
-    produce dL/dx_t and the operands of the weight-gradient products (see ncahip_dynca_step_bwd_f32), which
-    ncahip_gram_rows_f32 evaluates with the cell axis as K.  g_states (optional, [T+1,...]) adds dL/dx_t cotangents of
-    intermediate states (forward_nsteps' return_middle_feature).  Returns dict x0, w1 [fc,4C+cc], b1, w2 [C,fc], b2."""
-    states, g = _dev(states, "states"), _dev(g_final, "g_final")
+    """Backward of dynca_nsteps (states = the keep_history=True buffer [T+1,B,C,H,W]): ONE call into the C driver
+    ncahip_dynca_nsteps_bwd_f32, which enqueues the whole T-step loop (perception, fused MLP-backward kernel per 128-wide
+    slice of the hidden layer, weight-gradient products with the cell axis as K, stencil adjoint) on the current stream with
+    one caller-owned workspace.  g_final must already include any cotangent of x_T itself; g_states (optional, [T+1,...])
+    adds dL/dx_t cotangents of the intermediate states t < T (forward_nsteps' return_middle_feature).
+    Returns dict x0, w1 [fc,4C+cc], b1, w2 [C,fc], b2."""
+    states, g = _dev(states, "states"), _dev(g_final.float(), "g_final")
     _, B, C, H, W = states.shape
+    assert states.shape[0] == T + 1
     c_cond = 0 if cond is None else cond.shape[1]
     if cond is not None:
         cond = _dev(cond, "cond")
     if us is not None:
         us = _dev(us, "us")
-    dev = states.device
+    if g_states is not None:
+        g_states = _dev(g_states.float(), "g_states")
+        assert g_states.shape == states.shape
+    dev, f32 = states.device, torch.float32
     fc, k1 = w.fc, 4 * C + c_cond
-    fused = _gram_fits(fc, k1)      # layer-2 gradient fused into the step kernel, layer-1 gradient through gram_rows
-    hbuf = None if fused else torch.empty(B, fc, H, W, device=dev)
-    dhbuf = torch.empty(B, fc, H, W, device=dev)
-    if fused:      # [dW | db] accumulators of both layers: the entry points add each step's products in place
-        acc2 = torch.zeros(C * fc + C, device=dev)
-        acc1 = torch.zeros(fc * k1 + fc, device=dev)
-        nws = lib().ncahip_dynca_step_bwd_w2_workspace(B, C, H, W, fc)
-        ws2 = torch.empty(nws, device=dev, dtype=torch.uint8)
-    dy = torch.empty(B, 4 * C, H, W, device=dev)
-    gw1, gb1 = torch.zeros(fc, k1, device=dev), torch.zeros(fc, device=dev)
-    gw2, gb2 = torch.zeros(C, fc, device=dev), torch.zeros(C, device=dev)
-    for t in range(T - 1, -1, -1):
-        x_t = states[t]
-        u_t = us[t].reshape(B, 1, H, W) if us is not None else philox_uniform(B, H, W, seed, step0 + t, dev)
-        gx = torch.empty_like(g)
-        y = dynca_perceive(x_t, pad_mode)
-        if fused:
-            check(lib().ncahip_dynca_step_bwd_w2_f32(_p(x_t), _p(cond), _p(u_t), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C, H,
-                                                     W, fc, c_cond, PAD_MODES[pad_mode], update_rate, seed, step0 + t, _p(g),
-                                                     _p(gx), _p(dhbuf), _p(dy), _p(acc2), 1, _p(ws2), nws, _stream()),
-                  "dynca_step_bwd_w2")
-            gram_rows(dhbuf, y, cond, out=acc1)          # HIP product with the cell axis as K (csrc/nca_gram.hip)
-            g = gx
-            if g_states is not None:
-                g = g + g_states[t]
-            continue
-        check(lib().ncahip_dynca_step_bwd_f32(_p(x_t), _p(cond), _p(u_t), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C, H, W,
-                                              fc, c_cond, PAD_MODES[pad_mode], update_rate, seed, step0 + t, _p(g), _p(gx),
-                                              _p(hbuf), _p(dhbuf), _p(dy), _stream()), "dynca_step_bwd")
-        # shapes the HIP products do not cover (none the fused backward kernels reach today): library GEMMs on the device
-        do = g * (u_t + update_rate).floor()
-        if cond is not None:
-            y = torch.cat([y, cond], dim=1)
-        gw2 += torch.matmul(do.transpose(0, 1).reshape(C, -1), hbuf.transpose(0, 1).reshape(fc, -1).t())
-        gb2 += do.sum(dim=(0, 2, 3))
-        gw1 += torch.matmul(dhbuf.transpose(0, 1).reshape(fc, -1), y.transpose(0, 1).reshape(k1, -1).t())
-        gb1 += dhbuf.sum(dim=(0, 2, 3))
-        g = gx
-        if g_states is not None:
-            g = g + g_states[t]
-    if fused:
-        gw1, gb1 = acc1[:fc * k1].view(fc, k1), acc1[fc * k1:]
-        gw2, gb2 = acc2[:C * fc].view(C, fc), acc2[C * fc:]
-    return {"x0": g, "w1": gw1, "b1": gb1, "w2": gw2, "b2": gb2}
+    out = {"x0": torch.empty(B, C, H, W, device=dev, dtype=f32), "w1": torch.empty(fc, k1, device=dev, dtype=f32),
+           "b1": torch.empty(fc, device=dev, dtype=f32), "w2": torch.empty(C, fc, device=dev, dtype=f32),
+           "b2": torch.empty(C, device=dev, dtype=f32)}
+    nbytes = lib().ncahip_dynca_nsteps_bwd_workspace(B, C, H, W, fc, c_cond)
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    check(lib().ncahip_dynca_nsteps_bwd_f32(_p(states), T, _p(cond), _p(us), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C, H, W, fc,
+                                            c_cond, PAD_MODES[pad_mode], update_rate, seed, step0, _p(g), _p(g_states), _p(out["x0"]),
+                                            _p(out["w1"]), _p(out["b1"]), _p(out["w2"]), _p(out["b2"]), _p(ws), nbytes, _stream()),
+          "dynca_nsteps_bwd")
+    return out
