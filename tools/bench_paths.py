@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Timings of every path beside bench.py's headline, one JSON line each (median of >= 10 timed iterations after 3 warm-ups;
+HIP events on the launch stream).  `python tools/bench_paths.py [names...]`; without names: all.
+
+  cond_train      ConditionedNCA grow with history + backward, B=8 T=16 (fp32 and bf16 history)
+  cfg3            BASELINE configs[2] shape: B=32 C=16 256^2 T=96, forward with history + backward, fp32 and bf16
+  dynca_fwd       DyNCA forward steps: C=16/fc=128, C=12/fc=96, C=32/fc=128 and C=32/fc=256 at 2x512^2 (configs[4])
+  dynca_train     DyNCA forward with history + backward (the C driver): C=16/fc=128, C=12/fc=96, C=32/fc=256 at 2x512^2
+  big             working sets beyond the 256 MiB Infinity Cache: perception stencil and fused fp32 step at B=64
+"""
+import json
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "video-stylization-with-nca_amd")]
+import torch
+
+import bench
+from ncahip import ops
+
+DEV = "cuda"
+
+
+def timed(fns, iters=10, warm=3):
+    """fns: list of callables run back to back per iteration; returns per-callable median ms (events between them)."""
+    for _ in range(warm):
+        for f in fns:
+            f()
+    torch.cuda.synchronize()
+    res = [[] for _ in fns]
+    for _ in range(iters):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(fns) + 1)]
+        ev[0].record()
+        for i, f in enumerate(fns):
+            f()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        for i in range(len(fns)):
+            res[i].append(ev[i].elapsed_time(ev[i + 1]))
+    return [statistics.median(r) for r in res], [min(r) for r in res]
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def cond_case(B, H=256, W=256, C=16, dtype=torch.float32):
+    gen = torch.Generator().manual_seed(0)
+    prm = bench.make_weights(gen)
+    x = torch.rand(B, C, H, W, generator=gen).to(DEV, dtype)
+    goal = (torch.randn(B, 12, H, W, generator=gen) * 0.5).to(DEV, dtype)
+    cot = torch.randn(B, C, H, W, generator=gen).to(DEV)
+    w = ops.CondWeights(prm["perception_net.weight"], prm["update_net.out.0.weight"], prm["update_net.out.0.bias"],
+                        prm["update_net.out.2.weight"], prm["update_net.out.2.bias"], prm["update_net.out.4.weight"], x)
+    return x, goal, cot, w
+
+
+def cond_train(B, T, dtype, name, iters=10):
+    x, goal, cot, w = cond_case(B, dtype=dtype)
+    box = {}
+
+    def fwd():
+        box["h"] = ops.cond_grow(x, T, goal, None, w, 3, seed=1, step0=0, keep_history=True)
+
+    def bwd():
+        _, states, pre = box.pop("h")
+        ops.cond_grow_backward(states, pre, goal, None, w, cot, T, 3, seed=1, step0=0)
+
+    (tf, tb), (mf, mb) = timed([fwd, bwd], iters=iters)
+    cells = B * 256 * 256 * T
+    emit(path=name, storage=str(dtype).split(".")[-1], B=B, T=T, fwd_ms=tf, bwd_ms=tb, fwd_us_per_step=tf / T * 1e3,
+         bwd_us_per_step=tb / T * 1e3, fwd_bwd_Gcells_s=cells / (tf + tb) / 1e6, bwd_over_fwd=tb / tf,
+         history_GB=(T + 1) * x.numel() * x.element_size() / 1e9, min_fwd_ms=mf, min_bwd_ms=mb)
+
+
+def dyn_weights(C, fc, cc, gen):
+    k1 = 4 * C + cc
+    return ops.DyncaWeights(torch.randn(fc, k1, generator=gen) * (0.5 / k1 ** 0.5), torch.randn(fc, generator=gen) * 0.1,
+                            torch.randn(C, fc, generator=gen) * (0.02 / fc ** 0.5), torch.zeros(C), torch.zeros(1, device=DEV))
+
+
+def dynca(B, C, fc, H, W, T, train, cc=3, pad="circular"):
+    gen = torch.Generator().manual_seed(0)
+    w = dyn_weights(C, fc, cc, gen)
+    x = (torch.rand(B, C, H, W, generator=gen) - 0.5).to(DEV)
+    cond = (torch.rand(B, cc, H, W, generator=gen) * 2 - 1).to(DEV)
+    cot = torch.randn(B, C, H, W, generator=gen).to(DEV)
+    flops = 2 * (27 * C + fc * (5 * C + cc))
+    cells = B * H * W * T
+    if not train:
+        (ms,), (mn,) = timed([lambda: ops.dynca_nsteps(x, T, cond, None, w, pad, 0.5, seed=1)])
+        emit(path="dynca_fwd", B=B, C=C, fc=fc, HW=[H, W], T=T, us_per_step=ms / T * 1e3, Gcells_s=cells / ms / 1e6,
+             TFLOPs=cells * flops / ms / 1e9, frac_f32_mfma=cells * flops / ms / 1e9 / 157.3, min_us_per_step=mn / T * 1e3)
+        return
+    box = {}
+
+    def fwd():
+        box["h"] = ops.dynca_nsteps(x, T, cond, None, w, pad, 0.5, seed=1, keep_history=True)
+
+    def bwd():
+        _, states = box.pop("h")
+        ops.dynca_nsteps_backward(states, cond, None, w, cot, None, T, pad, 0.5, seed=1)
+
+    (tf, tb), (mf, mb) = timed([fwd, bwd])
+    emit(path="dynca_train", B=B, C=C, fc=fc, HW=[H, W], T=T, fwd_us_per_step=tf / T * 1e3, bwd_us_per_step=tb / T * 1e3,
+         fwd_bwd_Gcells_s=cells / (tf + tb) / 1e6, bwd_over_fwd=tb / tf, bwd_TFLOPs=3 * cells * flops / tb / 1e9)
+
+
+def big():
+    # stencil at B=64: 67 MB in + 268 MB out per launch, 3 rotating input/output pairs = 1 GB touched between re-uses
+    B, C, H, W = 64, 16, 256, 256
+    xs = [torch.randn(B, C, H, W, device=DEV) for _ in range(3)]
+    k = [0]
+
+    def st():
+        ops.dynca_perceive(xs[k[0] % 3], "replicate")
+        k[0] += 1
+    (ms,), (mn,) = timed([st], iters=12)
+    emit(path="stencil_B64", us=ms * 1e3, TBps=320.0 * B * H * W / ms / 1e9, frac_hbm=320.0 * B * H * W / ms / 1e9 / 8.0, min_us=mn * 1e3,
+         working_set_MB=3 * (B * C * H * W * 4 * 5) / 1e6)
+    del xs
+    x, goal, cot, w = cond_case(B)
+    T = 8
+    (ms,), (mn,) = timed([lambda: ops.cond_grow(x, T, goal, None, w, 3, seed=1)], iters=10)
+    cells = B * H * W * T
+    emit(path="cond_fwd_B64", us_per_step=ms / T * 1e3, Gcells_s=cells / ms / 1e6, frac_f32_mfma=cells * 17248 / ms / 1e9 / 157.3,
+         state_MB=x.numel() * 4 / 1e6)
+
+
+def main(names):
+    allp = not names
+    if allp or "cond_train" in names:
+        cond_train(8, 16, torch.float32, "cond_train")
+        cond_train(8, 16, torch.bfloat16, "cond_train")
+    if allp or "cfg3" in names:
+        cond_train(32, 96, torch.float32, "cfg3", iters=10)
+        cond_train(32, 96, torch.bfloat16, "cfg3", iters=10)
+    if allp or "dynca_fwd" in names:
+        dynca(8, 16, 128, 256, 256, 32, False)
+        dynca(8, 12, 96, 256, 256, 32, False)
+        dynca(2, 32, 128, 512, 512, 16, False)
+        dynca(2, 32, 256, 512, 512, 16, False)
+    if allp or "dynca_train" in names:
+        dynca(8, 16, 128, 256, 256, 16, True)
+        dynca(8, 12, 96, 256, 256, 16, True)
+        dynca(2, 32, 256, 512, 512, 8, True)
+    if allp or "big" in names:
+        big()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
