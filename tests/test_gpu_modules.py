@@ -293,3 +293,86 @@ def test_dynca_c32_trains_through_composed_path():
     (yo[:, :3] * 2.0).square().mean().backward()
     assert rel_err(xg.grad.cpu(), xo.grad) < 2e-4
     assert rel_err(m.w1.weight.grad.cpu(), prm["w1.weight"].grad) < 2e-4
+
+
+def test_conditioned_nca_default_arguments_c20():
+    """ConditionedNCA() exactly as the reference constructs it by default (target 3x64x64, 16 hidden channels -> C = 20,
+    nca.py:62-94; train.py -N 16): forward on the fused generic kernels (two output tiles), gradients through the composed
+    pass, both against the oracle."""
+    from ncahip.nca import ConditionedNCA
+    torch.manual_seed(2)
+    m = ConditionedNCA()
+    assert m.num_channels == 20 and m.living_channel_dim == 3
+    with torch.no_grad():
+        for n, p in m.update_net.named_parameters():
+            if n.endswith("bias"):
+                p.uniform_(-0.1, 0.1)
+        m.update_net.out[4].weight.mul_(3.0)
+    prm = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    gen = torch.Generator().manual_seed(4)
+    x0, goal = torch.rand(2, 20, 64, 64, generator=gen), torch.rand(2, 3, 64, 64, generator=gen)
+    x0[0, :, :20] = 0.0
+    us = [torch.rand(2, 1, 64, 64, generator=gen) for _ in range(5)]
+    gpad = O.cond_pad_goal(O.image_encoder(goal, prm), 20)
+    md = m.to(DEV)
+    # teacher-forced single steps (strict) + free-running end state
+    prev, ref = x0, x0
+    for t in range(5):
+        d = O.cond_step(prev, gpad, us[t], prm, 3, return_all=True)
+        _inject(md, [us[t]])
+        with torch.no_grad():
+            got = md.grow(prev.to(DEV), 1, goal.to(DEV)).cpu()
+        near = ((torch.nn.functional.max_pool2d(d["x1"][:, 3:4], 3, 1, 1) - 0.1).abs() < 2e-6).expand_as(got)
+        assert rel_err(got[~near], d["x2"][~near]) < REL_TOL, t
+        prev = d["x2"]
+    _inject(md, us)
+    with torch.no_grad():
+        got = md.grow(x0.to(DEV), 5, goal.to(DEV))
+    bad = ((got.cpu() - prev).abs() > REL_TOL * max(1.0, float(prev.abs().max()))).float().mean()
+    assert float(bad) < 0.01
+    # gradients of every parameter and of x0 (4 steps) vs oracle autograd
+    cot = torch.randn(2, 20, 64, 64, generator=gen)
+    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "embed" in k or k.startswith(("perception", "update")))
+         for k, v in prm.items()}
+    xr = x0.clone().requires_grad_(True)
+    (O.cond_grow(xr, O.cond_pad_goal(O.image_encoder(goal, p), 20), us[:4], p, 3) * cot).sum().backward()
+    _inject(md, us[:4])
+    xd = x0.to(DEV).requires_grad_(True)
+    (md.grow(xd, 4, goal.to(DEV)) * cot.to(DEV)).sum().backward()
+    scale = lambda t: max(float(t.abs().max()), 1e-6)
+    assert float((xd.grad.cpu() - xr.grad).abs().max()) / scale(xr.grad) < 2e-4
+    checked = 0
+    for n, w in md.named_parameters():
+        if p[n].grad is None:
+            continue
+        assert float((w.grad.cpu() - p[n].grad).abs().max()) / scale(p[n].grad) < 2e-4, n
+        checked += 1
+    assert checked == 9
+
+
+@pytest.mark.parametrize("C,gch", [(20, 16), (24, 20), (32, 28), (18, 14)])
+def test_cond_forward_wide_channels_vs_oracle(C, gch):
+    """The fused ConditionedNCA forward for 16 < C <= 32 (generic kernel family, M3T = 2): teacher-forced steps vs the oracle,
+    aligned and ragged shapes."""
+    from ncahip import ops
+    from test_gpu_parity import cond_w, rand_cond_prm
+    for (B, H, W) in ((2, 40, 48), (1, 13, 21)):
+        gen = torch.Generator().manual_seed(C + W)
+        prm = rand_cond_prm(C, seed=C, out_scale=1.0)
+        x = torch.rand(B, C, H, W, generator=gen)
+        x[:, 3] = torch.rand(B, H, W, generator=gen) * 0.3
+        goal = torch.randn(B, gch, H, W, generator=gen)
+        gpad = O.cond_pad_goal(goal, C)
+        w = cond_w(ops, prm, x.to(DEV))
+        prev = x
+        for t in range(4):
+            u = torch.rand(B, 1, H, W, generator=gen)
+            d = O.cond_step(prev, gpad, u, prm, 3, return_all=True)
+            xp, pre = ops.cond_step(prev.to(DEV), None, goal.to(DEV), u.to(DEV), w, 3)
+            got = ops.cond_finalize(xp, pre, 3).cpu()
+            assert torch.equal(pre.cpu().bool(), d["pre"][:, 0])
+            near = ((torch.nn.functional.max_pool2d(d["x1"][:, 3:4], 3, 1, 1) - 0.1).abs() < 2e-6).expand_as(got)
+            assert rel_err(got[~near], d["x2"][~near]) < REL_TOL, (C, H, W, t)
+            prev = d["x2"]
+        got, _, _ = ops.cond_grow(x.to(DEV), 3, goal.to(DEV), None, w, 3, seed=3)      # pending protocol + in-kernel Philox
+        assert bool(torch.isfinite(got).all())

@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int kMaxC = 16, kMaxCDynca = 32, kMaxFc = 128, kMaxFcFwd = 1024, kMaxHidden = 64, kMaxCond = 4;   // DyNCA forward: C <= 32 (configs[4]), fc in 128-wide slices
+constexpr int kMaxC = 16, kMaxCCondFwd = 32, kMaxCDynca = 32, kMaxFc = 128, kMaxFcFwd = 1024, kMaxHidden = 64, kMaxCond = 4;   // DyNCA forward: C <= 32 (configs[4]), fc in 128-wide slices
 
 thread_local char g_err[512] = "";
 
@@ -47,14 +47,14 @@ int check_dynca(const void* x_in, const void* x_out, const void* cond, const voi
 
 int check_cond(const void* x_in, const void* x_out, const void* pre_out, const void* goal, const void* wp,
                const void* w1, const void* b1, const void* w2, const void* b2, const void* w3, int B, int C, int H,
-               int W, int hidden, int goal_ch, int alive_ch) {
+               int W, int hidden, int goal_ch, int alive_ch, int max_c = kMaxC) {
     if (!x_in || !x_out || !pre_out || !wp || !w1 || !b1 || !w2 || !b2 || !w3)
         return fail(NCAHIP_EINVAL, "cond step: null pointer");
     if (!dims_ok(B, C, H, W) || hidden <= 0 || goal_ch < 0) return fail(NCAHIP_EINVAL, "cond step: bad size");
     if ((goal_ch > 0) != (goal != nullptr)) return fail(NCAHIP_EINVAL, "cond step: goal pointer / goal_ch mismatch");
     if (goal_ch > C || alive_ch >= C) return fail(NCAHIP_EINVAL, "cond step: goal_ch/alive_ch outside C=%d", C);
-    if (C > kMaxC || hidden > kMaxHidden)
-        return fail(NCAHIP_ERANGE, "cond step: C=%d hidden=%d exceeds (%d,%d)", C, hidden, kMaxC, kMaxHidden);
+    if (C > max_c || hidden > kMaxHidden)
+        return fail(NCAHIP_ERANGE, "cond step: C=%d hidden=%d exceeds (%d,%d)", C, hidden, max_c, kMaxHidden);
     if (x_in == x_out) return fail(NCAHIP_EINVAL, "cond step: x_in and x_out must not alias (halo reads)");
     return 0;
 }
@@ -144,7 +144,7 @@ int ncahip_cond_step_fwd_f32(const float* x_in, const uint8_t* pre_in, float* x_
                              const float* b1, const float* w2, const float* b2, const float* w3, int B, int C, int H,
                              int W, int hidden, int alive_ch, float alive_thr, float fire_rate, float clamp_lo,
                              float clamp_hi, uint64_t seed, uint64_t step, ncahip_stream_t stream) {
-    if (int rc = check_cond(x_in, x_out, pre_out, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch))
+    if (int rc = check_cond(x_in, x_out, pre_out, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch, kMaxCCondFwd))
         return rc;
     if (pre_in && pre_in == pre_out) return fail(NCAHIP_EINVAL, "cond step: pre_in and pre_out must not alias");
     NcaCondArgs a{x_in, pre_in, x_out, pre_out, goal, u, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch,
@@ -233,7 +233,7 @@ int ncahip_cond_grow_fwd_f32(float* states, uint8_t* pre, int ring, int T, float
                              int alive_ch, float alive_thr, float fire_rate, float clamp_lo, float clamp_hi,
                              uint64_t seed, uint64_t step0, ncahip_stream_t stream) {
     if (ring < 2 || T < 1 || !pre || !x_final) return fail(NCAHIP_EINVAL, "cond grow: ring >= 2, T >= 1, buffers required");
-    if (int rc = check_cond(states, states + 1, pre, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch))
+    if (int rc = check_cond(states, states + 1, pre, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch, kMaxCCondFwd))
         return rc;
     const size_t slot = (size_t)B * C * H * W, pslot = (size_t)B * H * W;
     hipStream_t st = (hipStream_t)stream;

@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(256) void dynca_step_bwd_stencil_vec_kernel(const N
 
 template <int CP, bool VEC>
 hipError_t launch_cond_v(const NcaCondArgs& a, hipStream_t st) {
-    constexpr int TH = 8, TW = 32, NT = 4;
+    constexpr int TH = 8, TW = 32, NT = CP > 16 ? 2 : 4;   // C > 16: 3C/4 perception values per cell row -> two rows per pass
     using K = CondCfg<CP, TH, TW, NT>;
     auto kern = cond_step_fwd_kernel<CP, TH, TW, NT, VEC>;
     const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
@@ -1324,5 +1324,9 @@ hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st) {
         return g_cond_variant == 1 ? nca_launch_cond_step_fwd_wave(a, st) : nca_launch_cond_step_fwd_pc(a, st);
     if (a.C <= 12) return launch_cond<12>(a, st);
     if (a.C <= 16) return launch_cond<16>(a, st);
+    // the reference's default model is C = 3 + 1 + 16 = 20 (nca.py:62-94): the generic kernel family with two output tiles
+    if (a.C <= 20) return launch_cond<20>(a, st);
+    if (a.C <= 24) return launch_cond<24>(a, st);
+    if (a.C <= 32) return launch_cond<32>(a, st);
     return hipErrorInvalidValue;
 }

@@ -42,6 +42,46 @@ class _CondGrow(torch.autograd.Function):
                 g["b1"], g["w2"][:, :, None, None], g["b2"], g["w3"][:, :, None, None], None)
 
 
+class _HipCondPerceive(torch.autograd.Function):
+    """perception_net (nca.py:99-107) on the HIP stencil; differentiated through the same map written as a grouped conv."""
+
+    @staticmethod
+    def forward(ctx, z, wp):
+        ctx.save_for_backward(z, wp)
+        return ops.cond_perceive(z, wp)
+
+    @staticmethod
+    def backward(ctx, gp):
+        z, wp = ctx.saved_tensors
+        with torch.enable_grad():
+            zr, wr = z.detach().requires_grad_(True), wp.detach().requires_grad_(True)
+            p = torch.nn.functional.conv2d(zr, wr, None, 1, 1, 1, zr.shape[1])
+            gz, gw = torch.autograd.grad(p, (zr, wr), gp)
+        return gz, gw
+
+
+def _cond_grow_composed(model, x, goal, T, us):
+    """Differentiable grow for shapes the fused backward kernels do not cover (C > 16 -- the reference's DEFAULT model is
+    C = 20, nca.py:62-94 -- or W % 4 != 0): every step is the reference's sequence (nca.py:181-195) with the alive masks and the
+    depthwise perception on the HIP kernels and the three 1x1 convolutions as library GEMMs, under PyTorch autograd."""
+    a, thr, C = model._alive_ch(), model.alpha_living_threshold, model.num_channels
+    gpad = None
+    if goal is not None:
+        gpad = torch.nn.functional.pad(goal.float(), (0, 0, 0, 0, C - goal.shape[1], 0))
+    alive = (lambda t: ops.cond_alive(t.detach().contiguous(), a, thr).float()) if a >= 0 else (lambda t: torch.ones_like(t[:, :1]))
+    for t in range(T):
+        if us is not None:
+            u = us[t]
+        else:
+            u = ops.philox_uniform(x.shape[0], x.shape[2], x.shape[3], model.mask_seed, model._mask_step - T + t, x.device)
+        pre = alive(x)
+        z = x if gpad is None else x + gpad * pre
+        out = model.update_net.out(_HipCondPerceive.apply(z.contiguous(), model.perception_net.weight))
+        x1 = x + (u.clamp(0.0, 1.0) < model.cell_fire_rate).float() * out
+        x = torch.clamp(x1 * (pre * alive(x1)), -10.0, 10.0)
+    return x
+
+
 def cond_grow_autograd(model, x: torch.Tensor, goal: Optional[torch.Tensor], T: int) -> torch.Tensor:
     if T == 0:
         return x
@@ -54,6 +94,8 @@ def cond_grow_autograd(model, x: torch.Tensor, goal: Optional[torch.Tensor], T: 
                lo=-10.0, hi=10.0, seed=model.mask_seed, step0=model._mask_step)
     model._mask_step += T
     if _needs_grad(x, goal, *params):
+        if x.shape[1] > 16 or x.shape[3] % 4 != 0:     # beyond the fused backward kernels (include/ncahip.h): composed pass
+            return _cond_grow_composed(model, x.float(), goal, T, us)
         return _CondGrow.apply(x, goal, *params, cfg)
     if bf16:
         goal = None if goal is None else goal.detach().to(torch.bfloat16)
