@@ -68,19 +68,37 @@ def event_ms(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def pmc_traffic(*kernel_substrs):
-    """HBM bytes/launch of a kernel from the committed PMC passes (profiles/*_traffic.json; collected with
-    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, tools/collect_traffic.py)."""
+def csrc_sha16():
+    """Hash of the kernel sources this run was built from (tools/collect_traffic.py stamps the same hash into its output)."""
     import glob
-    best = None
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "video-stylization-with-nca_amd", "csrc", "*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(*kernel_substrs):
+    """HBM bytes/launch of a kernel from a committed PMC pass (profiles/*_traffic.json: separate `rocprofv3 --pmc FETCH_SIZE` /
+    `--pmc WRITE_SIZE` runs of this same command, tools/collect_traffic.py).  PMC collection cannot run inside the timed
+    bench, so this is a LOOK-UP, and it is only reported when the file carries the hash of the kernel sources this run was
+    built from; otherwise `traffic` is null and the stale file is named.  Returns (bytes or None, provenance dict)."""
+    import glob
+    sha, hit, stale = csrc_sha16(), None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
         try:
-            for k, v in json.load(open(f)).items():
-                if all(sub in k for sub in kernel_substrs):
-                    best = v["hbm_bytes_per_launch"]
+            d = json.load(open(f))
         except Exception:
-            pass
-    return best
+            continue
+        for k, v in d.items():
+            if k != "_meta" and all(sub in k for sub in kernel_substrs):
+                if d.get("_meta", {}).get("csrc_sha16") == sha:
+                    hit = (v["hbm_bytes_per_launch"], os.path.basename(f))
+                else:
+                    stale = os.path.basename(f)
+    if hit:
+        return hit[0], {"source": "profiles/" + hit[1], "csrc_sha16": sha, "measured_in_this_run": False}
+    return None, {"source": None, "stale_file": stale and "profiles/" + stale, "csrc_sha16": sha, "measured_in_this_run": False}
 
 
 def cpu_baseline(prm, x0, goal):
@@ -111,12 +129,73 @@ def cpu_baseline(prm, x0, goal):
                                       f"{dt:.1f}s, torch CPU fp32, {torch.get_num_threads()} threads"}
 
 
+def train_leg(dev, world, iters):
+    """ConditionedNCATrainer iterations at BASELINE configs[3]'s per-GPU shape (32 grids of 16 x 256 x 256 per rank, pool
+    sharded over the ranks): sample -> 2 x {grow 64 steps with history, objective, backward through the fused backward kernels,
+    ONE flat-bucket gradient all-reduce (RCCL when N > 1), per-tensor normalisation, Adam} -> pool write-back.  The objective is
+    a stand-in (MSE to the target + the reference's overflow term): the VGG weights of the style loss cannot be fetched here."""
+    import tempfile
+    from ncahip import dist as nd
+    from ncahip.conditioned_trainer import ConditionedNCATrainer
+    from ncahip.nca import ConditionedNCA
+
+    class Targets:
+        target_size = (3, H, W)
+
+        def __init__(self):
+            self.data = torch.rand(8, 3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+
+        def __len__(self):
+            return self.data.shape[0]
+
+        def __getitem__(self, idx):
+            return self.data[torch.as_tensor(idx, device=dev)]
+
+    class StandIn(torch.nn.Module):
+        def forward(self, d):
+            s = d["nca_state"]
+            l = (d["generated_images"] - d["target_images"]).square().mean() + (s - s.clamp(-1.0, 1.0)).abs().mean()
+            return [l, {}]
+
+    torch.manual_seed(0)                                  # identical initial weights on every rank
+    nca = ConditionedNCA(target_shape=(3, H, W), num_hidden_channels=C - 4, living_channel_dim=ALIVE_CH).to(dev)
+    nca.mask_rng = "philox"
+    TB, TT = 32, 64
+    out = {}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        tr = ConditionedNCATrainer(nca, Targets(), None, nca_steps=[TT, TT], pool_size=2 * TB * world, loss=StandIn(), device=dev,
+                                   log_base_path=tempfile.mkdtemp(prefix="ncahip_bench_"), pool_dtype=dt)
+        tr._iteration(0, TB * world)                      # warm-up (allocator, first-touch)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        t0 = time.perf_counter()
+        for i in range(iters):
+            _, _, _, loss, _ = tr._iteration(i + 1, TB * world)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        dt_s = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt_s], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt_s = float(tt.item())
+        out[name] = {"ms_per_iteration": dt_s / iters * 1e3, "cell_updates_per_s_fwd_bwd": world * TB * H * W * TT * 2 * iters / dt_s,
+                     "last_loss": float(loss)}
+    out.update({"B_per_gpu": TB, "nca_steps": TT, "train_batches_per_iteration": 2, "iterations": iters,
+                "allreduce_floats": sum(p.numel() for p in nca.parameters() if p.requires_grad), "n_gpus": world,
+                "objective": "stand-in: MSE + overflow (VGG weights unobtainable offline)"})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline + rooflines only (profiling passes)")
+    ap.add_argument("--train-iters", type=int, default=3, help="iterations of the training-shaped leg (0: skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -174,13 +253,18 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         one_step_with_pool()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    med_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     if dist_on:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -203,9 +287,12 @@ def main():
         y = torch.empty(B, 4 * C, H, W, device=dev)
         ms_st = event_ms(lambda: ops.check(L.ncahip_dynca_perceive_f32(xd.data_ptr(), y.data_ptr(), B, C, H, W, 1, st), "perceive"), 200)
         gbs = cells * STENCIL_BYTES_PER_CELL / (ms_st * 1e-3) / 1e9
+        tr_step = pmc_traffic("cond_step_fwd_pc_kernel", "StF32, false")
+        tr_st = pmc_traffic("dynca_perceive_kernel")
         result = {
             "metric": "NCA cell-updates/sec (B*H*W*steps/s) at 256^2 C=16", "value": value, "unit": "cell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_median": med_ms, "value_from_median": B * H * W * T / (med_ms * 1e-3),   # rank 0's per-step HIP events (median of >= 10)
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: ConditionedNCA grow loop, B=8 C=16 256x256, 64 NCA steps per bench step, fp32 forward",
                        "B_per_gpu": B, "C": C, "H": H, "W": W, "nca_steps_per_bench_step": T, "hidden": HIDDEN,
@@ -214,45 +301,57 @@ def main():
                        "parallelism": f"pool-shard x{world} (no data-path collective)"},
             "roofline": {"kernel": "cond_step_fwd_pc_kernel<16,*>", "bound": "mfma", "achieved": tflops,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": pmc_traffic("cond_step_fwd_pc_kernel", "StF32, false"), "launch_ms": ms_launch, "flops_per_cell": FLOPS_PER_CELL,
+                         "traffic": tr_step[0], "traffic_provenance": tr_step[1], "launch_ms": ms_launch, "flops_per_cell": FLOPS_PER_CELL,
                          "algorithmic_bytes_per_cell": BYTES_PER_CELL_STEP, "cells_per_launch": cells},
             "roofline_stencil": {"kernel": "dynca_perceive_kernel<vec4>", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
-                                 "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": pmc_traffic("dynca_perceive_kernel"), "launch_ms": ms_st,
+                                 "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": tr_st[0], "traffic_provenance": tr_st[1], "launch_ms": ms_st,
                                  "bytes_per_cell": STENCIL_BYTES_PER_CELL, "cells_per_launch": cells,
                                  "cells_per_s": cells / (ms_st * 1e-3)},
         }
-        # ---- the same grow loop with bf16 state storage (ncahip_cond_grow_fwd_bf16; BASELINE configs[2]'s storage type):
-        # reported beside the fp32 headline, never as `value`
-        xb16, gb16 = xd.bfloat16(), gd.bfloat16()
-        ms_b = event_ms(lambda: ops.cond_grow(xb16, T, gb16, None, w, ALIVE_CH, seed=42), 5) / T
-        bpc = 2 * C * 2 + GOAL_CH * 2 + 2
-        result["bf16_storage"] = {"kernel": "cond_step_fwd_pc_kernel<16,true,StBF16>", "traffic": pmc_traffic("cond_step_fwd_pc_kernel", "StBF16"), "dtype": "bf16 storage, bf16 MFMA, f32 accumulate",
-                                  "value": cells / (ms_b * 1e-3), "unit": "cell-updates/s", "launch_ms": ms_b,
-                                  "algorithmic_bytes_per_cell": bpc, "hbm_GBs": cells * bpc / (ms_b * 1e-3) / 1e9,
-                                  "hbm_frac": cells * bpc / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                  "bound": "vector ALU / LDS issue (staging + perception), see DESIGN.md"}
-        # ---- opt-in bf16x3 emulation of the fp32 products (ncahip_cond_precision(1)): fp32 storage, ~1e-5 relative error
-        # per step -- informational, never `value`
-        ops.set_cond_precision("bf16x3")
-        try:
-            ms_x = event_ms(lambda: ops.cond_grow(xd, T, gd, None, w, ALIVE_CH, seed=42), 5) / T
-            x3, _ = ops.cond_step(xd, None, gd, None, w, ALIVE_CH, seed=7)
-        finally:
-            ops.set_cond_precision("exact")
-        xe, _ = ops.cond_step(xd, None, gd, None, w, ALIVE_CH, seed=7)
-        result["f32_bf16x3"] = {"value": cells / (ms_x * 1e-3), "unit": "cell-updates/s", "launch_ms": ms_x,
-                                "max_rel_err_vs_exact_step": float(((x3 - xe).abs() / xe.abs().clamp_min(1.0)).max()),
-                                "dtype": "f32 storage; products as 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi), f32 accumulate"}
-        # ---- the same loop started from ConditionedNCA.generate_seed (nca.py:130-150: one live centre cell, most of the grid
-        # dead): the kernels have no data-dependent early-out, so this must match `value` (SURVEY.md 8d asks for both)
-        xs = torch.zeros_like(xd)
-        xs[:, ALIVE_CH:, H // 2, W // 2] = 1.0
-        ms_s = event_ms(lambda: ops.cond_grow(xs, T, gd, None, w, ALIVE_CH, seed=42), 3) / T
-        result["from_seed"] = {"value": cells / (ms_s * 1e-3), "unit": "cell-updates/s", "launch_ms": ms_s,
-                               "alive_fraction_at_end": float(ops.cond_alive(ops.cond_grow(xs, T, gd, None, w, ALIVE_CH, seed=42)[0], ALIVE_CH).float().mean())}
+        if not args.no_extras:
+            # ---- the same grow loop with bf16 state storage (ncahip_cond_grow_fwd_bf16; BASELINE configs[2]'s storage type):
+            # reported beside the fp32 headline, never as `value`
+            xb16, gb16 = xd.bfloat16(), gd.bfloat16()
+            ms_b = event_ms(lambda: ops.cond_grow(xb16, T, gb16, None, w, ALIVE_CH, seed=42), 5) / T
+            bpc = 2 * C * 2 + GOAL_CH * 2 + 2
+            result["bf16_storage"] = {"kernel": "cond_step_fwd_pc_kernel<16,true,StBF16>", "traffic": pmc_traffic("cond_step_fwd_pc_kernel", "StBF16")[0], "dtype": "bf16 storage, bf16 MFMA, f32 accumulate",
+                                      "value": cells / (ms_b * 1e-3), "unit": "cell-updates/s", "launch_ms": ms_b,
+                                      "algorithmic_bytes_per_cell": bpc, "hbm_GBs": cells * bpc / (ms_b * 1e-3) / 1e9,
+                                      "hbm_frac": cells * bpc / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                      "bound": "vector ALU / LDS issue (staging + perception), see DESIGN.md"}
+            # ---- opt-in bf16x3 emulation of the fp32 products (ncahip_cond_precision(1)): fp32 storage, ~1e-5 relative error
+            # per step -- informational, never `value`
+            ops.set_cond_precision("bf16x3")
+            try:
+                ms_x = event_ms(lambda: ops.cond_grow(xd, T, gd, None, w, ALIVE_CH, seed=42), 5) / T
+                x3, _ = ops.cond_step(xd, None, gd, None, w, ALIVE_CH, seed=7)
+            finally:
+                ops.set_cond_precision("exact")
+            xe, _ = ops.cond_step(xd, None, gd, None, w, ALIVE_CH, seed=7)
+            result["f32_bf16x3"] = {"value": cells / (ms_x * 1e-3), "unit": "cell-updates/s", "launch_ms": ms_x,
+                                    "max_rel_err_vs_exact_step": float(((x3 - xe).abs() / xe.abs().clamp_min(1.0)).max()),
+                                    "dtype": "f32 storage; products as 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi), f32 accumulate"}
+            # ---- the same loop started from ConditionedNCA.generate_seed (nca.py:130-150: one live centre cell, most of the grid
+            # dead): the kernels have no data-dependent early-out, so this must match `value` (SURVEY.md 8d asks for both)
+            xs = torch.zeros_like(xd)
+            xs[:, ALIVE_CH:, H // 2, W // 2] = 1.0
+            ms_s = event_ms(lambda: ops.cond_grow(xs, T, gd, None, w, ALIVE_CH, seed=42), 3) / T
+            result["from_seed"] = {"value": cells / (ms_s * 1e-3), "unit": "cell-updates/s", "launch_ms": ms_s,
+                                   "alive_fraction_at_end": float(ops.cond_alive(ops.cond_grow(xs, T, gd, None, w, ALIVE_CH, seed=42)[0], ALIVE_CH).float().mean())}
+
+            # ---- the drop-in classes' DEFAULT mask source (mask_rng='torch': one torch.rand_like per step, the reference's RNG
+            # contract, nca.py:172) -- T extra launches and a [T,B,1,H,W] fp32 tensor per grow; informational
+            ms_t = event_ms(lambda: ops.cond_grow(xd, T, gd, torch.stack([torch.rand_like(xd[:, 0:1]) for _ in range(T)]), w, ALIVE_CH), 5) / T
+            result["mask_rng_torch"] = {"value": cells / (ms_t * 1e-3), "unit": "cell-updates/s", "launch_ms": ms_t,
+                                        "note": "explicit uniforms drawn with torch.rand_like per step (drop-in default)"}
+    # ---- training-shaped leg on EVERY rank (the path that contains the gradient all-reduce when N > 1): informational
+    train = train_leg(dev, world, args.train_iters) if (args.train_iters > 0 and not args.no_extras) else None
+    if rank == 0:
+        if train is not None:
+            result["train"] = train
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(prm, x0, goal)
-            result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+            result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result), flush=True)
     if dist_on:
         dist.barrier()

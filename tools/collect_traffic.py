@@ -22,5 +22,12 @@ for k, cs in acc.items():
         m = re.search(r"(\w+_kernel\w*(?:<[^>]*>)?)", k)
         res[m.group(1) if m else k[:80]] = {"FETCH_SIZE_KiB": fe, "WRITE_SIZE_KiB": wr, "hbm_bytes_per_launch": (2 * fe + wr) * 1024,
                                       "launches": len(cs["FETCH_SIZE"])}
+# stamp: which kernel sources these counters belong to (bench.py reports `traffic` only when the stamp matches the build it runs)
+import hashlib, os
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_h = hashlib.sha256()
+for _f in sorted(glob.glob(os.path.join(_root, "video-stylization-with-nca_amd", "csrc", "*"))):
+    _h.update(open(_f, "rb").read())
+res["_meta"] = {"csrc_sha16": _h.hexdigest()[:16]}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

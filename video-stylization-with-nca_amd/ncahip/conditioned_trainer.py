@@ -38,7 +38,7 @@ class ConditionedNCATrainer(NCATrainer):
                  pool_size: int = 512, num_damaged: int = 0, log_base_path: str = "test", damage_radius: int = 3,
                  appearance_loss_type: str = "OT", appearance_loss_weight: float = 1.0, content_loss_weight: float = 1.0,
                  overflow_loss_weight: float = 1.0, device: Optional[torch.device] = None, visualiser=None, loss=None,
-                 sample_seed: int = 0):
+                 sample_seed: int = 0, pool_dtype: torch.dtype = torch.float32):
         super().__init__(pool_size, num_damaged, log_base_path, device)
         self.nca, self.visualiser = nca, visualiser
         # data
@@ -58,6 +58,9 @@ class ConditionedNCATrainer(NCATrainer):
                         appearance_loss_weight=appearance_loss_weight, content_loss_weight=content_loss_weight,
                         overflow_loss_weight=overflow_loss_weight)
         self.loss = loss
+        # storage type of the pool and of the grow loop's history ring: float32 (the reference) or bfloat16 (BASELINE
+        # configs[2]: half the saved-for-backward set; bf16-storage kernels forward, fp32 gradients)
+        self.pool_dtype = pool_dtype
         # this rank's shard of the pool
         self.pool_size = ncadist.shard_size(pool_size)
         self.pool = SamplePool(self.pool_size)
@@ -78,7 +81,7 @@ class ConditionedNCATrainer(NCATrainer):
         return self.target_dataset[picks]
 
     def sample_batch(self, sampled_indices, sample_pool) -> torch.Tensor:
-        fresh = self.nca.generate_seed(1)[0].to(self.device)
+        fresh = self.nca.generate_seed(1)[0].to(self.device, self.pool_dtype)
         states = sample_pool.gather(sampled_indices, fresh).to(self.device)      # never-written slots come back as `fresh`
         any_alive = self.nca.alive(states).flatten(1).any(dim=1)
         return torch.where(any_alive.view(-1, 1, 1, 1), states, fresh.unsqueeze(0))
@@ -119,7 +122,8 @@ class ConditionedNCATrainer(NCATrainer):
     def train_batch(self, batch, targets):
         steps = ncadist.shared_int(random.randint(self.min_steps, self.max_steps))   # every rank: rank 0's draw
         grown = self.nca.grow(batch, num_steps=steps, goal=targets)
-        loss, parts = self.loss({"generated_images": grown[:, :self.num_target_channels], "nca_state": grown,
+        gf = grown.float()                                    # a bf16 pool: the objective is evaluated in fp32
+        loss, parts = self.loss({"generated_images": gf[:, :self.num_target_channels], "nca_state": gf,
                                  "target_images": targets})
         self.optimizer.zero_grad()
         loss.backward()
@@ -143,7 +147,7 @@ class ConditionedNCATrainer(NCATrainer):
             batch = self.sample_batch(idxs, self.pool).to(self.device)
             fresh = ncadist.global_slots(2)               # 2 fresh seeds per global batch (conditioned_trainer.py:167)
             if fresh:
-                batch[:fresh] = self.nca.generate_seed(fresh).to(self.device)
+                batch[:fresh] = self.nca.generate_seed(fresh).to(self.device, batch.dtype)
         outputs = batch
         for _ in range(2):                                # the reference trains twice on every sampled batch
             outputs, loss, metrics = self.train_batch(outputs, targets)
