@@ -9,7 +9,9 @@
  *   - plain C types only; every pointer is a DEVICE pointer (tensor.data_ptr()), contiguous NCHW;
  *   - the caller owns every buffer, nothing is allocated, freed or retained across calls;
  *   - work is enqueued asynchronously on `stream` (a hipStream_t; NULL = default stream), the
- *     call never synchronises and is safe from several host threads on distinct streams;
+ *     call never synchronises (ncahip_selftest and ncahip_check_errors excepted) and is safe from several host
+ *     threads on distinct streams and devices: launch state is cached per DEVICE (the device current at the call),
+ *     the two process-wide switches (ncahip_cond_precision, ncahip_debug_force_generic) are test / tuning hooks;
  *   - return 0 on success, a negative NCAHIP_E* on an argument error (nothing was launched),
  *     or a positive hipError_t if the launch failed; ncahip_last_error() describes the last
  *     failure of the calling thread.
@@ -30,6 +32,7 @@ extern "C" {
 /* argument errors */
 #define NCAHIP_EINVAL (-1)   /* null pointer / non-positive size / bad enum            */
 #define NCAHIP_ERANGE (-2)   /* shape outside what the kernels are instantiated for     */
+#define NCAHIP_EDEVICE 100001 /* a device-side failure was recorded (sticky error word)  */
 
 /* F.pad modes used by DyNCA perception (ConditioneDyNCA/models/dynca.py:85, default :31) */
 #define NCAHIP_PAD_ZERO      0   /* 'constant'  */
@@ -41,6 +44,16 @@ typedef void *ncahip_stream_t;   /* hipStream_t */
 
 int ncahip_version(void);
 const char *ncahip_last_error(void);
+
+/* Device-side failures.  The producer/consumer step kernels hand tiles over through bounded polls; a poll that expires (a
+ * stalled partner wave) cannot hang the device, but the launch then worked on a stale tile.  Such a launch sets a sticky,
+ * host-visible error word of its device.  The grow drivers (ncahip_cond_grow_fwd_*) refuse to enqueue with NCAHIP_EDEVICE
+ * while the word is set (checked without synchronising: it reflects launches that have completed), and
+ * ncahip_check_errors synchronises `stream`, returns NCAHIP_EDEVICE if the word is set and clears it when `clear` != 0.
+ * Callers that need certainty for a particular result call ncahip_check_errors after it (the Python layer does so wherever
+ * it synchronises anyway).  ncahip_debug_inject_error sets bits of the word (test hook for the return-code plumbing).       */
+int ncahip_check_errors(ncahip_stream_t stream, int clear);
+int ncahip_debug_inject_error(unsigned bits);
 
 /* Largest shapes the fused step kernels accept (C <= max_c, fc <= max_fc, hidden <= 64).  The fp32 DyNCA *forward* entry
  * points and ncahip_dynca_nsteps_bwd_f32 additionally take 16 < C <= 32 (BASELINE configs[4]) and fc up to 1024 (one launch
@@ -103,6 +116,23 @@ int ncahip_dynca_nsteps_fwd_f32(float *states, int ring, int T, const float *con
                                 int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
                                 float update_rate, uint64_t seed, uint64_t step0,
                                 ncahip_stream_t stream);
+
+/* The same step / loop with TWO-SCALE perception (DyNCA(perception_scales=[0, 1]): dynca.py:75-115 -- every video model the
+ * reference ships, docs/data/video_models/{small,large}/*.json, has n_perception_scales = 2; WebGL twin docs/dynca.js:288-355):
+ *     y = ( perc(x) + up2( perc( down2(x) ) ) ) / 2,   down2 / up2 = F.interpolate(bilinear, align_corners=False) by 2.
+ * Per step: one coarse pass (2x2 mean + fixed filters with F.pad(mode) on the coarse grid -> pc_scratch [B,4C,H/2,W/2]) and
+ * the fused step kernel, which up-samples the coarse tile from LDS on the fly.  H and W even, C <= 16, fc <= 128
+ * (NCAHIP_ERANGE otherwise: the Python layer then composes stencil + torch resampling).                                   */
+int ncahip_dynca_step_fwd_ms_f32(const float *x_in, float *x_out, const float *cond, const float *u,
+                                 const float *w1, const float *b1, const float *w2, const float *b2,
+                                 int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                                 float update_rate, uint64_t seed, uint64_t step, float *pc_scratch,
+                                 ncahip_stream_t stream);
+int ncahip_dynca_nsteps_fwd_ms_f32(float *states, int ring, int T, const float *cond, const float *u,
+                                   const float *w1, const float *b1, const float *w2, const float *b2,
+                                   int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                                   float update_rate, uint64_t seed, uint64_t step0, float *pc_scratch,
+                                   ncahip_stream_t stream);
 
 /* Backward of ONE DyNCA step (autograd through dynca.py:117-138; dynca.py:123: no gradient into cond).
  *   In : x_t (the step's input state), the same cond / u (or seed, step) / weights, g_next = dL/dx_{t+1}.

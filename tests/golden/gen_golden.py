@@ -14,6 +14,7 @@ Reference entry points exercised (file:line in the reference checkout):
   ConditioneDyNCA/models/dynca.py:7-253  DyNCA.forward / forward_nsteps / perceive_torch / seed, EdgeExtractor, CPE2D
   ExtraChannels/models/dynca.py:7-167    DyNCA (state-concat conditioning variant)
   docs/data/vec_field_models/large/starry-night.json   trained weights (data file)
+  docs/data/video_models/small/fountain_1.json         trained two-scale video model (data file; n_perception_scales = 2)
 """
 import importlib.util
 import json
@@ -250,6 +251,69 @@ def g5_real_weights():
     save("g5_real_weights", w1=w1, b1=b1, w2=w2, b2=b2, cond_img=cimg, rng_seed=2024, absmax=stats, **crops)
 
 
+# ---------------------------------------------------------------- G10: shipped two-scale video model (perception_scales = [0, 1])
+def g10_two_scale_video_model():
+    """DyNCA(perception_scales=[0, 1], conditioning='pos_emb') with the trained weights of a shipped video model
+    (docs/data/video_models/small/fountain_1.json: C = 12, fc = 96, n_perception_scales = 2), the reference's own forward at an
+    even, non-square size, plus a random-weight case at C = 16 / fc = 128 with each pad mode.  The raw layer tables of the JSON
+    are kept in the fixture as data so the WebGL importer can be checked against the same numbers."""
+    path = os.path.join(REF, "docs/data/video_models/small/fountain_1.json")
+    js = json.load(open(path))
+    l1, l2 = (decode_webgl_layer(l) for l in js["layers"])
+    w1 = torch.from_numpy(l1[:-1].T.copy())[:, :, None, None]; b1 = torch.from_numpy(l1[-1].copy())
+    w2 = torch.from_numpy(l2[:-1].T.copy())[:, :, None, None]; b2 = torch.from_numpy(l2[-1].copy())
+    out = {"n_perception_scales": int(js["n_perception_scales"]), "w1": w1, "b1": b1, "w2": w2, "b2": b2}
+    for i, l in enumerate(js["layers"]):     # raw tables (data): what ncahip.webgl.decode_layer must turn into w/b above
+        out[f"json.l{i}.data"] = np.asarray(l["data_flatten"], dtype=np.float64)
+        out[f"json.l{i}.meta"] = json.dumps({k: v for k, v in l.items() if k != "data_flatten"})
+    m = ref_dynca.DyNCA(12, 3, fc_dim=96, padding_mode="circular", conditioning="pos_emb", perception_scales=[0, 1], device=CPU)
+    with torch.no_grad():
+        m.w1.weight.copy_(w1); m.w1.bias.copy_(b1); m.w2.weight.copy_(w2); m.w2.bias.copy_(b2)
+    H, W, T = 32, 48, 24
+    gen = torch.Generator().manual_seed(7)
+    x0 = (torch.rand(1, 12, H, W, generator=gen) - 0.5) * 0.2
+    x = x0.clone()
+    with torch.no_grad():
+        torch.manual_seed(77)
+        us = torch.stack([torch.rand(1, 1, H, W) for _ in range(T)])
+        torch.manual_seed(77)
+        for t in range(T):
+            x, rgb = m(x, update_rate=0.5)
+            if t in (0, 7, 23):
+                out[f"vid.x_t{t + 1}"] = x.clone()
+        out["vid.perc0_crop"] = m.perceive_multiscale(x0, m.cond_layer(x0))[:, :, :12, -12:]
+    out.update({"vid.x0": x0, "vid.us": us})
+    cases = []
+    for k, pad in enumerate(["replicate", "circular", "reflect", "constant"]):
+        torch.manual_seed(40 + k)
+        cond = "edges" if k % 2 == 0 else "pos_emb"
+        mm = ref_dynca.DyNCA(16, 3, fc_dim=128, padding_mode=pad, conditioning=cond, edge_transform="tanh",
+                             perception_scales=[0, 1], device=CPU)
+        rand_biases_(mm)
+        B, Hh, Ww, Tn = 2, 16, 24, 4
+        xx0 = torch.rand(B, 16, Hh, Ww) - 0.5
+        cimg = torch.rand(B, 1, Hh, Ww) * 2 - 1 if cond == "edges" else None
+        with torch.no_grad():
+            torch.manual_seed(900 + k)
+            uu = torch.stack([torch.rand(B, 1, Hh, Ww) for _ in range(Tn)])
+            torch.manual_seed(900 + k)
+            xx, first = xx0, None
+            for t in range(Tn):
+                xx, _ = mm(xx, update_rate=0.5, cond_img=cimg)
+                first = xx.clone() if t == 0 else first
+        tag = f"ms{k}"
+        cases.append({"tag": tag, "pad": pad, "cond": cond, "T": Tn})
+        for kk, vv in mm.state_dict().items():
+            if kk.startswith(("w1", "w2")):
+                out[f"{tag}.{kk}"] = vv.detach()
+        out.update({f"{tag}.x0": xx0, f"{tag}.us": uu, f"{tag}.first": first, f"{tag}.last": xx})
+        if cimg is not None:
+            out[f"{tag}.cond_img"] = cimg
+    out["cases"] = json.dumps(cases)
+    out.update({"g10_final": os.path.basename(path)})
+    save("g10_two_scale", **out)
+
+
 # ---------------------------------------------------------------- G6: ExtraChannels variant
 def g6_extra_channels():
     torch.manual_seed(21)
@@ -353,8 +417,13 @@ def g9_seeds():
     save("g9_seeds", **arrs)
 
 
+if __name__ == "__main__" and len(sys.argv) > 1:      # regenerate selected fixtures only:  gen_golden.py g10_two_scale_video_model
+    for _n in sys.argv[1:]:
+        globals()[_n]()
+    sys.exit(0)
+
 if __name__ == "__main__":
     with torch.no_grad():
         pass
     g1_cond_step(); g2_cond_grow(); g2l_cfg1(); g3_dynca(); g4_perception(); g5_real_weights()
-    g6_extra_channels(); g7_encoders(); g8_grads(); g9_seeds()
+    g6_extra_channels(); g7_encoders(); g8_grads(); g9_seeds(); g10_two_scale_video_model()

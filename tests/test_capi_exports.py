@@ -93,6 +93,9 @@ def test_argument_validation_without_gpu():
     rc = L.ncahip_dynca_step_bwd_f32(one, None, None, one, one, one, one, 1, 16, 8, 8, 256, 0, 1, 0.5, 0, 0,
                                      one, two, one, one, one, None)
     assert rc == -2
+    # error-word entry points exist and fail soft without a device (no GPU in the build container: nothing to map)
+    assert L.ncahip_debug_inject_error(1) in (0, -1)
+    assert isinstance(L.ncahip_check_errors(None, 1), int)
     # precision switch: only 0 (exact) and 1 (bf16x3)
     assert L.ncahip_cond_precision(0) == 0 and L.ncahip_cond_precision(5) == -1
 

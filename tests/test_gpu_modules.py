@@ -376,3 +376,50 @@ def test_cond_forward_wide_channels_vs_oracle(C, gch):
             prev = d["x2"]
         got, _, _ = ops.cond_grow(x.to(DEV), 3, goal.to(DEV), None, w, 3, seed=3)      # pending protocol + in-kernel Philox
         assert bool(torch.isfinite(got).all())
+
+
+def test_two_scale_fused_step_golden_g10():
+    """perception_scales = [0, 1] on the fused two-scale kernels (coarse pass + step kernel with on-the-fly up-sampling):
+    the shipped video model of G10 (trained weights, pos_emb conditioning, 24 steps) and the four random-weight cases (every
+    pad mode, edges / pos_emb), through the C ABI and through the drop-in module + the WebGL importer."""
+    from ncahip import ops, webgl
+    g = load("g10_two_scale")
+    prm = {"w1.weight": T(g["w1"]), "w1.bias": T(g["b1"]), "w2.weight": T(g["w2"]), "w2.bias": T(g["b2"])}
+    x0, us = T(g["vid.x0"], DEV), T(g["vid.us"], DEV)
+    cond = O.cpe2d(1, x0.shape[2], x0.shape[3]).to(DEV)
+    w = ops.DyncaWeights(prm["w1.weight"], prm["w1.bias"], prm["w2.weight"], prm["w2.bias"], x0)
+    out, states = ops.dynca_nsteps(x0, us.shape[0], cond, us, w, "circular", 0.5, keep_history=True, two_scale=True)
+    for t in (1, 8, 24):
+        assert rel_err(states[t], T(g[f"vid.x_t{t}"])) < REL_TOL, t
+    for c in json.loads(str(g["cases"])):
+        t_ = c["tag"]
+        p = {k: T(g[f"{t_}.{k}"]) for k in ("w1.weight", "w1.bias", "w2.weight", "w2.bias")}
+        xx = T(g[f"{t_}.x0"], DEV)
+        cnd = (O.edge_extractor(T(g[f"{t_}.cond_img"]), "tanh") if c["cond"] == "edges" else O.cpe2d(*[xx.shape[i] for i in (0, 2, 3)])).to(DEV)
+        ww = ops.DyncaWeights(p["w1.weight"], p["w1.bias"], p["w2.weight"], p["w2.bias"], xx)
+        uu = T(g[f"{t_}.us"], DEV)
+        o1, _ = ops.dynca_nsteps(xx, 1, cnd, uu[:1], ww, c["pad"], 0.5, two_scale=True)
+        assert rel_err(o1, T(g[f"{t_}.first"])) < REL_TOL, c
+        oT, _ = ops.dynca_nsteps(xx, c["T"], cnd, uu, ww, c["pad"], 0.5, two_scale=True)
+        assert rel_err(oT, T(g[f"{t_}.last"])) < REL_TOL, c
+    # drop-in module built by the WebGL importer from the JSON tables: honours n_perception_scales, runs fused under no_grad
+    layers = []
+    for i in range(2):
+        meta = json.loads(str(g[f"json.l{i}.meta"]))
+        meta["data_flatten"] = g[f"json.l{i}.data"].tolist()
+        layers.append(meta)
+    m = webgl.load_dynca({"layers": layers, "n_perception_scales": 2}, padding_mode="circular", device=DEV)
+    assert list(m.perception_scales) == [0, 1] and m.conditioning == "pos_emb"
+    it = iter(us)
+    m._draw = lambda x, steps: torch.stack([next(it) for _ in range(steps)])
+    with torch.no_grad():
+        assert m._two_scale_fused(x0) and not m._composed(x0)
+        xT, rgb, mids = m.forward_nsteps(x0, 24, return_middle_feature=True)
+    assert rel_err(xT, T(g["vid.x_t24"])) < REL_TOL and len(mids) == 24 and torch.equal(mids[-1], rgb)
+    # odd sizes / training fall back to the composed pass and agree with the fused one where both apply
+    it2 = iter(us)
+    m._draw_one = lambda x: next(it2)
+    xg = x0.clone().requires_grad_(True)
+    assert m._composed(xg)
+    y, _ = m.forward_nsteps(xg, 8)
+    assert rel_err(y, T(g["vid.x_t8"])) < REL_TOL

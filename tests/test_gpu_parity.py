@@ -759,3 +759,23 @@ def test_dynca_step_shape_fuzz(ops):
         w = ops.DyncaWeights(prm["w1.weight"], prm["w1.bias"], prm["w2.weight"], prm["w2.bias"], x.to(DEV))
         got, _ = ops.dynca_nsteps(x.to(DEV), 1, None if cond is None else cond.to(DEV), u[None].to(DEV), w, pad, rate)
         assert rel_err(got.cpu(), ref) < REL_TOL, (case, C, fc, cc, B, H, W, pad, rate)
+
+
+def test_device_error_word_plumbing(ops):
+    """A hand-off poll that expires sets a sticky host-visible error word; the grow drivers then refuse with NCAHIP_EDEVICE and
+    ncahip_check_errors reports and clears it.  (The expiry itself cannot be provoked on a healthy device: the test hook sets
+    the word exactly as the kernel does.)"""
+    from ncahip._capi import NcaHipError
+    prm = rand_cond_prm(16, seed=1)
+    x = torch.rand(1, 16, 32, 32, device=DEV)
+    w = cond_w(ops, prm, x)
+    ops.cond_grow(x, 2, None, None, w, 3)
+    ops.check_errors()                                   # clean device: no error
+    assert ops.lib().ncahip_debug_inject_error(1) == 0
+    with pytest.raises(NcaHipError, match="hand-off"):
+        ops.cond_grow(x, 2, None, None, w, 3)            # refused before anything is enqueued
+    with pytest.raises(NcaHipError, match="error word"):
+        ops.check_errors()                               # reported once, and cleared
+    ops.check_errors()
+    out, _, _ = ops.cond_grow(x, 2, None, None, w, 3)
+    assert bool(torch.isfinite(out).all())

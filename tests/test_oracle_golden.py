@@ -231,3 +231,39 @@ def test_philox_known_answers():
     u = O.philox_uniform(42, 3, 2, 8, 8)
     assert u.shape == (2, 1, 8, 8) and u.dtype == np.float32 and 0 <= u.min() and u.max() < 1
     assert not np.array_equal(u, O.philox_uniform(42, 4, 2, 8, 8))
+
+
+# ------------------------------------------------------------------ two-scale perception (shipped video models)
+def test_g10_two_scale_video_model_and_webgl_tables(golden_dir):
+    """perception_scales = [0, 1]: the oracle against the reference's own forward with the trained weights of a shipped video
+    model (docs/data/video_models/small/fountain_1.json) and four random-weight cases; and the WebGL importer against the raw
+    layer tables of that JSON (data kept in the fixture)."""
+    import sys
+    from ncahip import webgl
+    g = load(golden_dir, "g10_two_scale")
+    assert int(g["n_perception_scales"]) == 2
+    layers = []
+    for i in range(2):
+        meta = json.loads(str(g[f"json.l{i}.meta"]))
+        meta["data_flatten"] = g[f"json.l{i}.data"].tolist()
+        layers.append(meta)
+    w = webgl.load_dynca_weights({"layers": layers, "n_perception_scales": 2})
+    for k, n in (("w1.weight", "w1"), ("w1.bias", "b1"), ("w2.weight", "w2"), ("w2.bias", "b2")):
+        assert same(w[k], g[n]), k
+    assert w["pos_emb"] and not w["edge_conditioning"] and w["n_perception_scales"] == 2
+    prm = {"w1.weight": T(g["w1"]), "w1.bias": T(g["b1"]), "w2.weight": T(g["w2"]), "w2.bias": T(g["b2"])}
+    x, us = T(g["vid.x0"]), T(g["vid.us"])
+    cond = O.cpe2d(1, x.shape[2], x.shape[3])
+    assert same(O.dynca_perceive_multiscale(x, "circular", (0, 1), cond)[:, :, :12, -12:], g["vid.perc0_crop"])
+    for t in range(us.shape[0]):
+        x = O.dynca_step(x, cond, us[t], prm, "circular", 0.5, scales=(0, 1))
+        if f"vid.x_t{t + 1}" in g:
+            assert same(x, g[f"vid.x_t{t + 1}"]), t
+    for c in json.loads(str(g["cases"])):
+        t_ = c["tag"]
+        p = {k: T(g[f"{t_}.{k}"]) for k in ("w1.weight", "w1.bias", "w2.weight", "w2.bias")}
+        x0 = T(g[f"{t_}.x0"])
+        cnd = O.edge_extractor(T(g[f"{t_}.cond_img"]), "tanh") if c["cond"] == "edges" else O.cpe2d(*[x0.shape[i] for i in (0, 2, 3)])
+        us_ = T(g[f"{t_}.us"])
+        assert same(O.dynca_step(x0, cnd, us_[0], p, c["pad"], 0.5, scales=(0, 1)), g[f"{t_}.first"]), c
+        assert same(O.dynca_nsteps(x0, cnd, list(us_), p, c["pad"], 0.5, scales=(0, 1)), g[f"{t_}.last"]), c

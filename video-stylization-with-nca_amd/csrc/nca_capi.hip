@@ -61,7 +61,69 @@ int check_cond(const void* x_in, const void* x_out, const void* pre_out, const v
 
 }  // namespace
 
+// ---- sticky device error word: one host-mapped word per device, written by kernels (system-scope atomic OR), read by the host
+// without synchronising -------------------------------------------------------------------------------------------------
+namespace {
+struct ErrWord {
+    std::atomic<int> state{0};   // 0 = not allocated, 1 = ready, 2 = allocation failed
+    unsigned* host = nullptr;
+    unsigned* dev = nullptr;
+};
+ErrWord g_errw[kNcaMaxDevices];
+ErrWord& errw() {
+    ErrWord& w = g_errw[nca_device_index()];
+    if (w.state.load(std::memory_order_acquire) == 0) {
+        static std::atomic_flag lock = ATOMIC_FLAG_INIT;
+        while (lock.test_and_set(std::memory_order_acquire)) {}
+        if (w.state.load(std::memory_order_relaxed) == 0) {
+            void *h = nullptr, *d = nullptr;
+            int st = 2;
+            if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+                *(volatile unsigned*)h = 0u;
+                w.host = (unsigned*)h;
+                w.dev = (unsigned*)d;
+                st = 1;
+            }
+            w.state.store(st, std::memory_order_release);
+        }
+        lock.clear(std::memory_order_release);
+    }
+    return w;
+}
+}  // namespace
+unsigned* nca_error_word_device() { return errw().dev; }
+unsigned nca_error_word_read(bool clear) {
+    ErrWord& w = errw();
+    if (!w.host) return 0u;
+    const unsigned v = *(volatile unsigned*)w.host;
+    if (clear && v) *(volatile unsigned*)w.host = 0u;
+    return v;
+}
+// positive return code of a recorded device-side failure (distinct from every hipError_t in use)
+static int device_error_rc(const char* where) {
+    const unsigned v = nca_error_word_read(false);
+    if (!v) return 0;
+    return fail(NCAHIP_EDEVICE, "%s: a device-side failure was recorded earlier on this device (error word 0x%x: bit 0 = "
+                "producer/consumer hand-off poll expired); results since the last ncahip_check_errors are not valid", where, v);
+}
+
 extern "C" {
+
+int ncahip_check_errors(ncahip_stream_t stream, int clear) {
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_result(e, "check_errors sync");
+    const unsigned v = nca_error_word_read(clear != 0);
+    if (!v) return 0;
+    return fail(NCAHIP_EDEVICE, "device error word 0x%x (bit 0: a producer/consumer hand-off poll expired -- the affected launch "
+                "produced stale tiles)", v);
+}
+
+int ncahip_debug_inject_error(unsigned bits) {   // test hook: what a kernel does when a poll expires
+    unsigned* h = errw().host;
+    if (!h) return fail(NCAHIP_EINVAL, "no error word on this device");
+    *(volatile unsigned*)h |= bits;
+    return 0;
+}
 
 int ncahip_version(void) { return NCAHIP_VERSION; }
 const char* ncahip_last_error(void) { return g_err; }
@@ -139,6 +201,47 @@ int ncahip_dynca_nsteps_fwd_f32(float* states, int ring, int T, const float* con
     return 0;
 }
 
+// ---- two-scale perception (perception_scales = [0, 1]): coarse pass + fused step with on-the-fly bilinear up-sampling --------
+static int check_ms(int C, int H, int W, int fc, const void* pc) {
+    if (!pc) return fail(NCAHIP_EINVAL, "dynca two-scale step: pc_scratch required");
+    if ((H | W) & 1) return fail(NCAHIP_ERANGE, "dynca two-scale step: H and W must be even (the x2 resampling is then the exact 2x2 mean / (0.25, 0.75) blend)");
+    if (C > kMaxC || fc > kMaxFc) return fail(NCAHIP_ERANGE, "dynca two-scale step: C=%d fc=%d exceeds (%d,%d)", C, fc, kMaxC, kMaxFc);
+    return 0;
+}
+
+int ncahip_dynca_step_fwd_ms_f32(const float* x_in, float* x_out, const float* cond, const float* u, const float* w1,
+                                 const float* b1, const float* w2, const float* b2, int B, int C, int H, int W, int fc,
+                                 int c_cond, int pad_mode, float update_rate, uint64_t seed, uint64_t step, float* pc_scratch,
+                                 ncahip_stream_t stream) {
+    if (int rc = check_dynca(x_in, x_out, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
+    if (int rc = check_ms(C, H, W, fc, pc_scratch)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = hip_result(nca_launch_dynca_coarse_perceive(x_in, pc_scratch, B, C, H, W, pad_mode, st), "dynca coarse perceive")) return rc;
+    NcaDyncaArgs a{x_in, x_out, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step};
+    a.pc = pc_scratch;
+    return hip_result(nca_launch_dynca_step_fwd(a, st), "dynca_step_fwd_ms");
+}
+
+int ncahip_dynca_nsteps_fwd_ms_f32(float* states, int ring, int T, const float* cond, const float* u, const float* w1,
+                                   const float* b1, const float* w2, const float* b2, int B, int C, int H, int W, int fc,
+                                   int c_cond, int pad_mode, float update_rate, uint64_t seed, uint64_t step0, float* pc_scratch,
+                                   ncahip_stream_t stream) {
+    if (ring < 2 || T < 0) return fail(NCAHIP_EINVAL, "dynca nsteps: ring >= 2 and T >= 0 required");
+    if (int rc = check_dynca(states, states + 1, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
+    if (int rc = check_ms(C, H, W, fc, pc_scratch)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t slot = (size_t)B * C * H * W, uslot = (size_t)B * H * W;
+    for (int t = 0; t < T; ++t) {
+        const float* const xi = states + (size_t)(t % ring) * slot;
+        if (int rc = hip_result(nca_launch_dynca_coarse_perceive(xi, pc_scratch, B, C, H, W, pad_mode, st), "dynca coarse perceive")) return rc;
+        NcaDyncaArgs a{xi, states + (size_t)((t + 1) % ring) * slot, cond, u ? u + (size_t)t * uslot : nullptr, w1, b1, w2, b2, B, C, H,
+                       W, fc, c_cond, pad_mode, update_rate, seed, step0 + (uint64_t)t};
+        a.pc = pc_scratch;
+        if (int rc = hip_result(nca_launch_dynca_step_fwd(a, st), "dynca_nsteps_fwd_ms")) return rc;
+    }
+    return 0;
+}
+
 int ncahip_cond_step_fwd_f32(const float* x_in, const uint8_t* pre_in, float* x_out, uint8_t* pre_out,
                              const float* goal, int goal_ch, const float* u, const float* wp, const float* w1,
                              const float* b1, const float* w2, const float* b2, const float* w3, int B, int C, int H,
@@ -202,6 +305,7 @@ int ncahip_cond_grow_fwd_bf16(uint16_t* states, uint8_t* pre, int ring, int T, u
     if (int rc = check_cond(states, states + 1, pre, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch))
         return rc;
     if (int rc = check_bf16_shape(states, states, goal, H, W)) return rc;
+    if (int rc = device_error_rc("cond grow (bf16)")) return rc;
     const size_t slot = (size_t)B * C * H * W, pslot = (size_t)B * H * W;
     if ((slot * sizeof(uint16_t)) % 8 != 0) return fail(NCAHIP_ERANGE, "bf16 cond grow: state slots must stay 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -235,6 +339,7 @@ int ncahip_cond_grow_fwd_f32(float* states, uint8_t* pre, int ring, int T, float
     if (ring < 2 || T < 1 || !pre || !x_final) return fail(NCAHIP_EINVAL, "cond grow: ring >= 2, T >= 1, buffers required");
     if (int rc = check_cond(states, states + 1, pre, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch, kMaxCCondFwd))
         return rc;
+    if (int rc = device_error_rc("cond grow")) return rc;
     const size_t slot = (size_t)B * C * H * W, pslot = (size_t)B * H * W;
     hipStream_t st = (hipStream_t)stream;
     const int sl = T % ring;

@@ -847,13 +847,8 @@ hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
     using K = BCfg<CP>;
     auto kern = cond_step_bwd_kernel<CP, ST>;
     const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
-    static thread_local bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static NcaLdsAttr attr;   // per instantiation; keyed by device inside
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
     const NcaCondArgs& a = ba.f;
     const int nst = a.B * ((a.W + 15) / 16) * ((a.H + 15) / 16);
     const int grid = nst < ba.nslab ? nst : ba.nslab;   // one slab per workgroup
@@ -873,13 +868,7 @@ hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
 }  // namespace
 
 int nca_cond_bwd_slab_floats(int C, int hidden) { return slab_floats(C, hidden); }
-int nca_cond_bwd_nslab() {
-    int dev = 0, v = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-        cus = v;
-    return cus;   // one persistent workgroup (and one slab) per CU
-}
+int nca_cond_bwd_nslab() { return nca_cu_count(); }   // one persistent workgroup (and one slab) per CU
 int nca_cond_bwd_nblk(int B, int C, int H, int W) { return B * C * ((((H + SROWS - 1) / SROWS) * (W / 4) + 255) / 256); }
 
 // W % 4 == 0 and 16-byte aligned tensors required (checked by the C ABI).

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
     // tile.  A workgroup barrier keeps the four pairs of a CU in lock-step, so their perception phases (LDS-bandwidth-bound)
     // and their stores all collide; with pair-local hand-offs the pairs drift apart.  LDS operations of one wave execute in
     // order, so "data, then counter" on the writer side and "counter, then data" on the reader side is all the ordering
-    // needed.  The polls are bounded (a broken hand-off gives wrong numbers, never a hung device).
+    // needed.  The polls are bounded (a broken hand-off never hangs the device; it sets the sticky error word, see await).
     int* const flags = reinterpret_cast<int*>(PR + PK::SCR_FLAG);
     auto post = [&](int idx, int round) {
         wave_sync();
@@ -222,6 +222,10 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
         int spins = 0;
         while (__hip_atomic_load(flags + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < round && ++spins < (1 << 20))
             __builtin_amdgcn_s_sleep(1);
+        // an expired poll means the partner wave never posted: the tile about to be used is stale.  The launch still drains (no
+        // hung device), but the failure is RECORDED in the sticky host-visible error word, which the grow drivers and
+        // ncahip_check_errors turn into a non-zero return code -- never silent wrong numbers.
+        if (spins >= (1 << 20) && lane == 0 && a.err) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         wave_sync();
     };
     // The two roles run separate loops (all branches are wave-uniform): the consumer's 128 weight registers are then not
@@ -287,21 +291,9 @@ hipError_t launch_cond_pc(const NcaCondArgs& a, hipStream_t st) {
     using PK = PCfg<CP>;
     auto kern = cond_step_fwd_pc_kernel<CP, EXACT, ST, SPLIT>;
     const size_t lds = (size_t)PK::LDS_FLOATS * sizeof(float);
-    static thread_local bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    static thread_local int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            cus = v;
-    }
+    static NcaLdsAttr attr;   // per instantiation; keyed by device inside
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
+    const int cus = nca_cu_count();
     const int nst = a.B * ((a.W + 15) / 16) * ((a.H + 15) / 16);
     hipLaunchKernelGGL(kern, dim3(nst < cus ? nst : cus), dim3(kThreadsW), lds, st, a);
     return hipGetLastError();
@@ -321,6 +313,7 @@ void nca_set_cond_precision(int mode) { g_cond_precision = mode; }
 hipError_t nca_launch_cond_step_fwd_pc(const NcaCondArgs& a_in, hipStream_t st) {
     NcaCondArgs a = a_in;
     a.dbg = g_stamp_pc;
+    a.err = nca_error_word_device();
     const bool h64 = a.hidden == 64;
     if (g_cond_precision == 1 && h64) {   // opt-in bf16x3 emulation of the fp32 products (exact shapes only)
         if (a.C == 12) return launch_cond_pc<12, true, StF32, true>(a, st);
@@ -338,6 +331,7 @@ hipError_t nca_launch_cond_step_fwd_pc(const NcaCondArgs& a_in, hipStream_t st) 
 hipError_t nca_launch_cond_step_fwd_bf16(const NcaCondArgs& a_in, hipStream_t st) {
     NcaCondArgs a = a_in;
     a.dbg = g_stamp_pc;
+    a.err = nca_error_word_device();
     const bool h64 = a.hidden == 64;
     if (a.C == 12 && h64) return launch_cond_pc<12, true, StBF16>(a, st);
     if (a.C == 16 && h64) return launch_cond_pc<16, true, StBF16>(a, st);

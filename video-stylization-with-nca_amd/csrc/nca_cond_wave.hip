@@ -119,21 +119,9 @@ hipError_t launch_cond_wave(const NcaCondArgs& a, hipStream_t st) {
     using K = WCfg<CP>;
     auto kern = cond_step_fwd_wave_kernel<CP>;
     const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
-    static thread_local bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    static thread_local int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            cus = v;
-    }
+    static NcaLdsAttr attr;   // per instantiation; keyed by device inside
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
+    const int cus = nca_cu_count();
     const int nst = a.B * ((a.W + STW - 1) / STW) * ((a.H + STH - 1) / STH);
     hipLaunchKernelGGL(kern, dim3(nst < cus ? nst : cus), dim3(kThreadsW), lds, st, a);
     return hipGetLastError();

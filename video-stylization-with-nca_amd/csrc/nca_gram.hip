@@ -158,10 +158,7 @@ hipError_t launch_gram(const GramArgs& a, int grid, hipStream_t st) {
 }  // namespace
 
 int nca_gram_grid(int B, int HW) {
-    int dev = 0, v = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-        v > 0)
-        cus = v;
+    const int cus = nca_cu_count();
     const long total = (long)B * ((HW + kGramChunk - 1) / kGramChunk);
     return (int)(total < 2L * cus ? total : 2L * cus);
 }

@@ -3,6 +3,45 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
+// ---- per-DEVICE launch state (the C ABI is legal from any host thread on any device: caches are keyed by the device that is
+// current at the call, never by the calling thread) -----------------------------------------------------------------------
+constexpr int kNcaMaxDevices = 64;
+inline int nca_device_index() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kNcaMaxDevices) d = 0;
+    return d;
+}
+// CU count of the current device (cached per device)
+inline int nca_cu_count() {
+    static std::atomic<int> cus[kNcaMaxDevices];
+    const int d = nca_device_index();
+    int v = cus[d].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int q = 0;
+        v = 256;
+        if (hipDeviceGetAttribute(&q, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && q > 0) v = q;
+        cus[d].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel instantiation, device): one static instance per launcher template
+struct NcaLdsAttr {
+    std::atomic<bool> done[kNcaMaxDevices];
+    hipError_t ensure(const void* kern, size_t bytes) {
+        const int d = nca_device_index();
+        if (done[d].load(std::memory_order_acquire)) return hipSuccess;
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) done[d].store(true, std::memory_order_release);
+        return e;
+    }
+};
+// Sticky device-side error word of the current device (host-mapped, so the host reads it without synchronising): bit 0 = a
+// producer/consumer hand-off poll expired (nca_cond_pc.hip).  nullptr when the allocation failed (errors are then not recorded).
+unsigned* nca_error_word_device();        // device-visible pointer for kernel arguments
+unsigned nca_error_word_read(bool clear); // host view of the current device's word
+
 struct NcaDyncaArgs {
     const float* x_in;
     float* x_out;
@@ -23,6 +62,7 @@ struct NcaDyncaArgs {
     int w2_ld;             // row stride of w2 (0: = fc); later slices run the accumulating instantiation (x_out += mask * slice)
     float* gw2_ws;         // backward, fused dW2: per-workgroup partials [grid][C*fc + C] (dW2 | db2); hbuf is then not written
     const float* g_extra;  // backward stencil: optional cotangent of x_t itself, added to g_out (forward_nsteps' middle features)
+    const float* pc;       // two-scale perception (perception_scales = [0, 1]): coarse-level perception [B,4C,H/2,W/2], or null
 };
 
 struct NcaCondArgs {
@@ -37,6 +77,7 @@ struct NcaCondArgs {
     float thr, fire_rate, lo, hi;
     uint64_t seed, step;
     unsigned long long* dbg;  // diagnostic builds (-DNCA_STAMPS) only: per-wave phase time stamps
+    unsigned* err;            // sticky error word (nca_error_word_device()), or null
 };
 
 // One backward step of the ConditionedNCA grow loop (nca_cond_bwd.hip).  f describes forward step t exactly as
@@ -93,6 +134,7 @@ void nca_set_force_generic(bool on);
 
 // stencils and small kernels (nca_stencil.hip)
 hipError_t nca_launch_dynca_perceive(const float* x, float* y, int B, int C, int H, int W, int pad, hipStream_t st);
+hipError_t nca_launch_dynca_coarse_perceive(const float* x, float* pc, int B, int C, int H, int W, int pad, hipStream_t st);
 hipError_t nca_launch_cond_perceive(const float* z, const float* wp, float* y, int B, int C, int H, int W, hipStream_t st);
 hipError_t nca_launch_cond_finalize(const float* x, const uint8_t* pre, float* out, int B, int C, int H, int W,
                                     int alive_ch, float thr, float lo, float hi, hipStream_t st);

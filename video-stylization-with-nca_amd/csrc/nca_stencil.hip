@@ -92,6 +92,42 @@ __global__ __launch_bounds__(256) void dynca_perceive_kernel(const float* __rest
     }
 }
 
+// Coarse level of the two-scale perception (dynca.py:75-100 with scale = 1, H and W even): the state is bilinearly reduced by
+// 2 -- for even sizes F.interpolate(align_corners=False) samples at 2i + 0.5, i.e. the 2x2 mean with lambdas 0.5 -- and the
+// fixed filters run on the coarse grid with F.pad(mode) resolved THERE.  One thread = one coarse cell of one (b, c) plane;
+// the 36 fine values it touches are 8-byte loads that hit L1/L2 (neighbouring threads share them).  Output: pc [B,4C,H/2,W/2]
+// in the blocked order [xc | Sx*xc | Sy*xc | L*xc]; the fused multi-scale step up-samples it on the fly.
+__global__ __launch_bounds__(256) void dynca_coarse_perceive_kernel(const float* __restrict__ x, float* __restrict__ pc, int B, int C,
+                                                                    int H, int W, int pad) {
+    const int Hc = H >> 1, Wc = W >> 1;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)B * C * Hc * Wc) return;
+    const int xc = (int)(id % Wc), yc = (int)((id / Wc) % Hc), c = (int)((id / ((size_t)Wc * Hc)) % C), b = (int)(id / ((size_t)Wc * Hc * C));
+    const float* const pl = x + ((size_t)b * C + c) * (size_t)H * W;
+    float a[3][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int sy = nca_pad_index(yc + dy - 1, Hc, pad);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int sx = nca_pad_index(xc + dx - 1, Wc, pad);
+            float v = 0.0f;
+            if (sy >= 0 && sx >= 0) {
+                const float2 r0 = *reinterpret_cast<const float2*>(pl + (size_t)(2 * sy) * W + 2 * sx);
+                const float2 r1 = *reinterpret_cast<const float2*>(pl + (size_t)(2 * sy + 1) * W + 2 * sx);
+                v = 0.5f * (0.5f * r0.x + 0.5f * r0.y) + 0.5f * (0.5f * r1.x + 0.5f * r1.y);   // upsample_bilinear2d's own expression
+            }
+            a[dy][dx] = v;
+        }
+    }
+    const size_t cp = (size_t)Hc * Wc;
+    float* const o = pc + ((size_t)b * 4 * C + c) * cp + (size_t)yc * Wc + xc;
+    o[0] = a[1][1];
+    o[(size_t)C * cp] = nca_sobel_x(a);
+    o[(size_t)2 * C * cp] = nca_sobel_y(a);
+    o[(size_t)3 * C * cp] = nca_laplacian(a);
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void cond_perceive_kernel(const float* __restrict__ z, const float* __restrict__ wp,
                                                             float* __restrict__ y, int B, int C, int H, int W) {
@@ -217,6 +253,12 @@ hipError_t nca_launch_dynca_perceive(const float* x, float* y, int B, int C, int
     else
         hipLaunchKernelGGL(dynca_perceive_kernel<false>, dim3(blocks_for((size_t)B * C * H * W)), dim3(256), 0, st, x,
                            y, B, C, H, W, pad);
+    return hipGetLastError();
+}
+
+hipError_t nca_launch_dynca_coarse_perceive(const float* x, float* pc, int B, int C, int H, int W, int pad, hipStream_t st) {
+    const size_t n = (size_t)B * C * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(dynca_coarse_perceive_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, pc, B, C, H, W, pad);
     return hipGetLastError();
 }
 

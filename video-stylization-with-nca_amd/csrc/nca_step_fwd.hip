@@ -187,6 +187,10 @@ struct DyncaCfg {
     static constexpr int OFF_MK = OFF_Z + CP * CS;
     static constexpr int OFF_CN = OFF_MK + TH * TW;
     static constexpr int LDS_FLOATS = OFF_CN + (HAS_COND ? 4 * TH * TW : 0);
+    // two-scale perception: coarse-level perception tile [4*CP planes][TH/2 + 2 rows][PCR], halo 1 (index-clamped: bilinear)
+    static constexpr int PCR = TW / 2 + 4, PCS = (TH / 2 + 2) * PCR;
+    static constexpr int OFF_PC = LDS_FLOATS;
+    static constexpr int LDS_FLOATS_MS = OFF_PC + 4 * CP * PCS;
     // backward variant: the transposed operands (W2^T for dh, W1^T for dL/dy) are 16-byte reads of the FORWARD images (see the
     // kernel), so the backward needs no weight images of its own.  dL/dy is produced in tiles of 16 rows = 4 channels x 4
     // filters (row i <-> channel 4mj + (i & 3), filter i >> 2): MJ = CP / 4 tiles, no conditioning rows (dynca.py:123).
@@ -206,8 +210,10 @@ struct DyncaCfg {
 // hidden layer, then dh = (W2^T (G*mask)) * 1[h>0] and dL/dy = W1^T dh on MFMA (accumulator tile == next B
 // operand, as in the forward); writes relu(h), dh and dL/dy[:4C].  The two weight-gradient GEMMs
 // (dW2 = (G*mask) h^T, dW1 = dh y^T, K = all cells) are plain library GEMMs on those buffers.
-template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT, bool VEC, bool BWD = false, bool B16 = false, bool ACC = false, bool W2F = false>
-__global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(const NcaDyncaArgs a) {
+template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT, bool VEC, bool BWD = false, bool B16 = false, bool ACC = false, bool W2F = false,
+          bool MS = false>
+__global__ __launch_bounds__(kThreads, (BWD || MS) ? 1 : 2) void dynca_step_fwd_kernel(const NcaDyncaArgs a) {
+    static_assert(!MS || (!BWD && !B16 && !ACC && TH % 2 == 0 && TW % 2 == 0), "the two-scale step is an fp32 forward kernel");
     static_assert(!W2F || BWD, "fused dW2 is an option of the backward kernel");
     static_assert(!ACC || !B16, "accumulating passes (fc slices beyond the first) read fp32 partial results");
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
@@ -320,6 +326,20 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) CN[cc * TH * TW + st] = (cin && cc < CC) ? cnv[cc] : 0.0f;
         }
+        if constexpr (MS) {
+            // coarse perception tile: rows ty0/2 - 1 .. ty0/2 + TH/2, columns tx0/2 - 1 .. tx0/2 + TW/2, indices clamped into the
+            // coarse image (what bilinear up-sampling does at the border, whatever the pad mode of the stencil was)
+            constexpr int NR = TH / 2 + 2, NC = TW / 2 + 2, PER_PLANE = NR * NC;
+            const int Hc = H >> 1, Wc = W >> 1;
+            const float* const pcb = a.pc + (size_t)b * 4 * C * Hc * Wc;
+            float* const PCL = smem + K::OFF_PC;
+            for (int i = st; i < 4 * CP * PER_PLANE; i += kThreads) {
+                const int pl = i / PER_PLANE, rc = i - pl * PER_PLANE, r = rc / NC, c = rc - r * NC;
+                const int f = pl / CP, ch = pl - f * CP;
+                const int sy = min(max((ty0 >> 1) - 1 + r, 0), Hc - 1), sx = min(max((tx0 >> 1) - 1 + c, 0), Wc - 1);
+                PCL[pl * K::PCS + r * K::PCR + c] = ch < C ? pcb[((size_t)(f * C + ch) * Hc + sy) * Wc + sx] : 0.0f;
+            }
+        }
         __syncthreads();
 
 #pragma unroll 1
@@ -347,6 +367,21 @@ __global__ __launch_bounds__(kThreads, BWD ? 1 : 2) void dynca_step_fwd_kernel(c
                     P[n][4 * cq4 + 1] = nca_sobel_x(nb);
                     P[n][4 * cq4 + 2] = nca_sobel_y(nb);
                     P[n][4 * cq4 + 3] = nca_laplacian(nb);
+                    if constexpr (MS) {
+                        // + bilinear x2 up-sampling (align_corners = False) of the coarse perception, then the mean over the two
+                        // scales (dynca.py:98, :105-110).  Fine row r = 2k: rows (k-1, k) with lambdas (0.25, 0.75); r = 2k+1:
+                        // (k, k+1) with (0.75, 0.25); the tile has a coarse halo of 1, indices clamped at staging.
+                        const int fr = r0[n], fq = q0[n];
+                        const int kr = (fr >> 1) + ((fr & 1) ? 1 : 0), kq = (fq >> 1) + ((fq & 1) ? 1 : 0);   // first of the two coarse rows / cols (tile coordinates incl. halo)
+                        const float h1 = (fr & 1) ? 0.25f : 0.75f, w1 = (fq & 1) ? 0.25f : 0.75f, h0 = 1.0f - h1, w0 = 1.0f - w1;
+                        const float* const pcp = smem + K::OFF_PC + (4 * cq4 + g) * K::PCS + kr * K::PCR + kq;
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) {
+                            const float* const q = pcp + f * CP * K::PCS;
+                            const float up = h0 * (w0 * q[0] + w1 * q[1]) + h1 * (w0 * q[K::PCR] + w1 * q[K::PCR + 1]);
+                            P[n][4 * cq4 + f] = (P[n][4 * cq4 + f] + up) / 2.0f;
+                        }
+                    }
                 }
             }
             if (HAS_COND) {
@@ -1008,15 +1043,7 @@ hipError_t set_lds(KernelT kern, size_t bytes) {
 }
 
 int grid_for(int ntiles, int wg_per_cu) {
-    static thread_local int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            cus = v;
-    }
-    const int cap = cus * wg_per_cu;
+    const int cap = nca_cu_count() * wg_per_cu;
     return ntiles < cap ? ntiles : cap;
 }
 
@@ -1028,16 +1055,32 @@ hipError_t launch_dynca_v(const NcaDyncaArgs& a, hipStream_t st) {
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
     auto kern = dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, VEC, false, B16, ACC>;
     const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
-    static thread_local bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = set_lds(kern, lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static NcaLdsAttr attr;   // per instantiation; keyed by device inside
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
     const int ntiles = a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
     const int grid = grid_for(ntiles, lds * 2 <= 160 * 1024 ? 2 : 1);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, a);
     return hipGetLastError();
+}
+
+// two-scale perception (a.pc = coarse-level perception of x_in, H and W even): one workgroup per CU (the coarse tile is in LDS)
+template <int CP, int FC, bool HAS_COND>
+hipError_t launch_dynca_ms(const NcaDyncaArgs& a, hipStream_t st) {
+    constexpr int TH = 8, TW = 32, NT = 4;
+    using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
+    static_assert(K::LDS_FLOATS_MS * 4 <= 160 * 1024, "LDS budget (two-scale step)");
+    const bool vec = (a.W % 4 == 0) && aligned16(a.x_in) && (((size_t)a.H * a.W) % 4 == 0);
+    const size_t lds = (size_t)K::LDS_FLOATS_MS * sizeof(float);
+    const int ntiles = a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+    const int grid = grid_for(ntiles, 1);
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = set_lds(kern, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, a);
+        return hipGetLastError();
+    };
+    return vec ? go(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, true, false, false, false, false, true>)
+               : go(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, false, false, false, false, false, true>);
 }
 
 template <int CP, int FC, bool HAS_COND, bool ACC = false>
@@ -1184,12 +1227,8 @@ hipError_t launch_cond_v(const NcaCondArgs& a, hipStream_t st) {
     using K = CondCfg<CP, TH, TW, NT>;
     auto kern = cond_step_fwd_kernel<CP, TH, TW, NT, VEC>;
     const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
-    static thread_local bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = set_lds(kern, lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static NcaLdsAttr attr;   // per instantiation; keyed by device inside
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
     const int ntiles = a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
     const int grid = grid_for(ntiles, lds * 2 <= 160 * 1024 ? 2 : 1);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, a);
@@ -1212,6 +1251,12 @@ void nca_set_cond_variant(int v) { g_cond_variant = v; }
 // ---- dispatch: smallest instantiation that covers (C, fc); padding lanes carry zero weights ---
 hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st) {
     const bool hc = a.c_cond > 0;
+    if (a.pc) {   // two-scale perception: the shipped video models (C = 12 / fc = 96 and C = 16 / fc = 128, pos_emb conditioning)
+        if ((a.H | a.W) & 1) return hipErrorInvalidValue;
+        if (a.C <= 12 && a.fc <= 96) return hc ? launch_dynca_ms<12, 96, true>(a, st) : launch_dynca_ms<12, 96, false>(a, st);
+        if (a.C <= 16 && a.fc <= 128) return hc ? launch_dynca_ms<16, 128, true>(a, st) : launch_dynca_ms<16, 128, false>(a, st);
+        return hipErrorInvalidValue;
+    }
     if (a.C <= 12 && a.fc <= 96) return hc ? launch_dynca<12, 96, true>(a, st) : launch_dynca<12, 96, false>(a, st);
     if (a.C <= 16 && a.fc <= 128) return hc ? launch_dynca<16, 128, true>(a, st) : launch_dynca<16, 128, false>(a, st);
     if (a.C <= 32 && a.fc <= 128) return hc ? launch_dynca<32, 128, true>(a, st) : launch_dynca<32, 128, false>(a, st);   // configs[4]

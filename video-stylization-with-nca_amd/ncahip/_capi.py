@@ -18,11 +18,15 @@ SIGNATURES = {
     "ncahip_last_error": [],
     "ncahip_limits": [_P, _P, _P],
     "ncahip_selftest": [_P, _P],
+    "ncahip_check_errors": [_P, _I],
+    "ncahip_debug_inject_error": [ctypes.c_uint],
     "ncahip_debug_force_generic": [_I],
     "ncahip_dynca_perceive_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
     "ncahip_cond_perceive_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
     "ncahip_dynca_step_fwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P],
     "ncahip_dynca_nsteps_fwd_f32": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P],
+    "ncahip_dynca_step_fwd_ms_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P, _P],
+    "ncahip_dynca_nsteps_fwd_ms_f32": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P, _P],
     "ncahip_dynca_step_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P, _P, _P, _P, _P, _P],
     "ncahip_cond_step_fwd_f32": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F,
                                  _F, _F, _U64, _U64, _P],

@@ -112,6 +112,9 @@ class ConditionedNCATrainer(NCATrainer):
     def _report(self, loss: torch.Tensor, parts: Optional[Dict]) -> Dict[str, float]:
         named = [(n, p.grad) for n, p in self.nca.named_parameters() if p.grad is not None]
         fetched = torch.stack([g.sum() for _, g in named] + [loss.detach()]).tolist()     # the step's only host sync
+        if loss.is_cuda:
+            from . import ops
+            ops.check_errors()              # the stream is drained anyway: surface any recorded device-side failure now
         value = fetched.pop()
         report = {"loss": value}
         report.update({k: float(v) for k, v in (parts or {}).items()})

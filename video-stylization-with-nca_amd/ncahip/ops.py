@@ -51,6 +51,12 @@ def set_cond_precision(mode) -> None:
     check(lib().ncahip_cond_precision({"exact": 0, "bf16x3": 1}.get(mode, mode)), "cond_precision")
 
 
+def check_errors(clear: bool = True) -> None:
+    """Synchronise the current stream and raise NcaHipError if a kernel recorded a device-side failure (a producer/consumer
+    hand-off poll that expired) since the last check -- see ncahip_check_errors in include/ncahip.h."""
+    check(lib().ncahip_check_errors(_stream(), int(clear)), "ncahip_check_errors")
+
+
 def selftest(device=None) -> None:
     scratch = torch.zeros(1024, dtype=torch.int32, device=device or "cuda")
     check(lib().ncahip_selftest(scratch.data_ptr(), _stream()), "ncahip_selftest")
@@ -112,11 +118,16 @@ def dynca_step(x: torch.Tensor, cond: Optional[torch.Tensor], u: Optional[torch.
     return out
 
 
+def two_scale_fused_ok(C: int, H: int, W: int, fc: int) -> bool:
+    """Shapes ncahip_dynca_*_fwd_ms_f32 covers (perception_scales = [0, 1] fused): even sizes, C <= 16, fc <= 128."""
+    return H % 2 == 0 and W % 2 == 0 and C <= 16 and fc <= 128
+
+
 def dynca_nsteps(x: torch.Tensor, T: int, cond: Optional[torch.Tensor], us: Optional[torch.Tensor], w: DyncaWeights,
                  pad_mode: str = "replicate", update_rate: float = 0.5, seed: int = 0, step0: int = 0,
-                 keep_history: bool = False):
+                 keep_history: bool = False, two_scale: bool = False):
     """T fused steps.  Returns (x_T, states) where states is the [ring,B,C,H,W] buffer (ring=T+1 when
-    keep_history, else 2)."""
+    keep_history, else 2).  two_scale: perception_scales = [0, 1] (ncahip_dynca_nsteps_fwd_ms_f32, fp32 states)."""
     dt, sfx = _state_dtype(x)           # bfloat16 state -> bf16-storage entry points (forward only)
     x = _dev(x, "x", dt)
     B, C, H, W = x.shape
@@ -132,6 +143,13 @@ def dynca_nsteps(x: torch.Tensor, T: int, cond: Optional[torch.Tensor], us: Opti
     ring = T + 1 if keep_history else 2
     states = torch.empty(ring, B, C, H, W, device=x.device, dtype=dt)
     states[0].copy_(x)
+    if two_scale:
+        assert sfx == "f32", "the two-scale step is an fp32 kernel"
+        pc = torch.empty(B, 4 * C, H // 2, W // 2, device=x.device, dtype=torch.float32)
+        check(lib().ncahip_dynca_nsteps_fwd_ms_f32(_p(states), ring, T, _p(cond), _p(us), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C,
+                                                   H, W, w.fc, c_cond, PAD_MODES[pad_mode], update_rate, seed, step0, _p(pc), _stream()),
+              "dynca_nsteps_fwd_ms")
+        return states[T % ring], states
     check(getattr(lib(), "ncahip_dynca_nsteps_fwd_" + sfx)(_p(states), ring, T, _p(cond), _p(us), _p(w.w1), _p(w.b1), _p(w.w2),
                                                            _p(w.b2), B, C, H, W, w.fc, c_cond, PAD_MODES[pad_mode],
                                                            update_rate, seed, step0, _stream()), "dynca_nsteps_fwd_" + sfx)

@@ -46,6 +46,7 @@ def load_dynca_weights(src: Union[str, Dict], index: int = 0) -> Dict[str, torch
         out["w2.bias"] = torch.zeros(l2.shape[1])
     out["pos_emb"] = bool(js["layers"][0].get("pos_emb", False))
     out["edge_conditioning"] = bool(js["layers"][0].get("edge_conditioning", False))
+    out["n_perception_scales"] = int(js.get("n_perception_scales", 1))     # every shipped video model: 2 (docs/dynca.js:288-355)
     return out
 
 
@@ -57,6 +58,7 @@ def load_dynca(src: Union[str, Dict], index: int = 0, c_out: int = 3, padding_mo
     fc, k1 = w["w1.weight"].shape[:2]
     c_in = w["w2.weight"].shape[0]
     cond = "edges" if w["edge_conditioning"] else ("pos_emb" if w["pos_emb"] else "none")
+    kw.setdefault("perception_scales", list(range(w["n_perception_scales"])))      # the file's n_perception_scales (dynca.js:288-355)
     m = DyNCA(c_in, c_out, fc_dim=fc, padding_mode=padding_mode, conditioning=cond, device=torch.device(device), **kw)
     if m.w1.weight.shape[1] != k1:
         raise ValueError(f"webgl model: layer 0 has {k1} inputs, DyNCA(c_in={c_in}, conditioning={cond!r}) expects {m.w1.weight.shape[1]}")
@@ -83,7 +85,7 @@ def export_dynca_json(models: Sequence, model_names: Sequence[str], path: str = 
             w = conv.weight.detach().float().cpu().numpy()[:, :, 0, 0]
             b = conv.bias.detach().float().cpu().numpy()[:, None]
             per_layer[i].append(np.concatenate([w, b], axis=1).T)      # [rows = in + 1, cols = out]
-    out = {"model_names": list(model_names), "layers": []}
+    out = {"model_names": list(model_names), "layers": [], "n_perception_scales": len(getattr(models[0], "perception_scales", [0]))}
     for i, mats in enumerate(per_layer):
         layer = np.stack(mats)                                          # [n, rows, cols]
         n, rows, cols = layer.shape
