@@ -93,6 +93,24 @@ int ncahip_cond_perceive_f32(const float *z, const float *wp, float *y, int B, i
                              ncahip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Conditioning front ends: the fixed-filter part of the encoders that produce the step's other input
+ * ---------------------------------------------------------------------------------------- */
+
+/* ImageEncoder.forward up to `embed`         EncoderConditioning/encoder.py:37-52
+ *   feat[B,3+ch,H,W] = [ sobel_x(gray) | sobel_y(gray) | laplacian(gray) | gaussian_blur(img[c]) for c < ch ],
+ *   gray = mean over the ch image channels; 3x3 filters k3 [3][9] = the module's sobel_x / sobel_y / laplacian weights,
+ *   5x5 blur k5 [25] = gaussian_blur.weight (frozen parameters, :12-27, :60-64); zero padding.  ch <= 8.
+ *   The learned convolutions (embed, :30-34) stay with the caller (MIOpen through PyTorch: their weights train).          */
+int ncahip_image_encoder_front_f32(const float *img, const float *k3, const float *k5, float *feat,
+                                   int B, int ch, int H, int W, ncahip_stream_t stream);
+
+/* EdgeExtractor.forward                      ConditioneDyNCA/models/dynca.py:204-213
+ *   out[B,3,H,W] = transform([ sobel_x | sobel_y | laplacian ](img[B,1,H,W])), zero padding, transform = tanh iff
+ *   apply_tanh != 0 (edge_transform == 'tanh'); k3 [3][9] = the module's three frozen filters.                           */
+int ncahip_edge_extractor_f32(const float *img, const float *k3, float *out, int B, int H, int W,
+                              int apply_tanh, ncahip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * DyNCA fused step                          ConditioneDyNCA/models/dynca.py:117-138
  *   (ExtraChannels/models/dynca.py:113-128 is the same step with c_cond = 2 or 0)
  *   x_out = x_in + (w2 relu(w1 [perc(x_in) | cond] + b1) + b2) * floor(u + update_rate)

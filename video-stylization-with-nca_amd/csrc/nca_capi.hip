@@ -201,6 +201,21 @@ int ncahip_dynca_nsteps_fwd_f32(float* states, int ring, int T, const float* con
     return 0;
 }
 
+// ---- conditioning front ends (fixed-filter part of the encoders) ---------------------------------------------------------
+int ncahip_image_encoder_front_f32(const float* img, const float* k3, const float* k5, float* feat, int B, int ch, int H, int W,
+                                   ncahip_stream_t stream) {
+    if (!img || !k3 || !k5 || !feat || img == feat) return fail(NCAHIP_EINVAL, "image_encoder_front: null or aliased pointer");
+    if (!dims_ok(B, ch, H, W)) return fail(NCAHIP_EINVAL, "image_encoder_front: bad size");
+    if (ch > 8) return fail(NCAHIP_ERANGE, "image_encoder_front: %d image channels (at most 8)", ch);
+    return hip_result(nca_launch_image_encoder_front(img, k3, k5, feat, B, ch, H, W, (hipStream_t)stream), "image_encoder_front");
+}
+
+int ncahip_edge_extractor_f32(const float* img, const float* k3, float* out, int B, int H, int W, int apply_tanh, ncahip_stream_t stream) {
+    if (!img || !k3 || !out || img == out) return fail(NCAHIP_EINVAL, "edge_extractor: null or aliased pointer");
+    if (!dims_ok(B, 1, H, W)) return fail(NCAHIP_EINVAL, "edge_extractor: bad size");
+    return hip_result(nca_launch_edge_extractor(img, k3, out, B, H, W, apply_tanh != 0, (hipStream_t)stream), "edge_extractor");
+}
+
 // ---- two-scale perception (perception_scales = [0, 1]): coarse pass + fused step with on-the-fly bilinear up-sampling --------
 static int check_ms(int C, int H, int W, int fc, const void* pc) {
     if (!pc) return fail(NCAHIP_EINVAL, "dynca two-scale step: pc_scratch required");

@@ -134,6 +134,9 @@ void nca_set_force_generic(bool on);
 
 // stencils and small kernels (nca_stencil.hip)
 hipError_t nca_launch_dynca_perceive(const float* x, float* y, int B, int C, int H, int W, int pad, hipStream_t st);
+hipError_t nca_launch_image_encoder_front(const float* img, const float* k3, const float* k5, float* feat, int B, int ch, int H, int W,
+                                          hipStream_t st);
+hipError_t nca_launch_edge_extractor(const float* img, const float* k3, float* out, int B, int H, int W, int do_tanh, hipStream_t st);
 hipError_t nca_launch_dynca_coarse_perceive(const float* x, float* pc, int B, int C, int H, int W, int pad, hipStream_t st);
 hipError_t nca_launch_cond_perceive(const float* z, const float* wp, float* y, int B, int C, int H, int W, hipStream_t st);
 hipError_t nca_launch_cond_finalize(const float* x, const uint8_t* pre, float* out, int B, int C, int H, int W,

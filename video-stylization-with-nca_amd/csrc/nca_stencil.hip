@@ -128,6 +128,78 @@ __global__ __launch_bounds__(256) void dynca_coarse_perceive_kernel(const float*
     o[(size_t)3 * C * cp] = nca_laplacian(a);
 }
 
+// ---- conditioning front ends (the fixed-filter part of the encoders that feed the step) ----------------------------------
+// ImageEncoder (EncoderConditioning/encoder.py:37-52): gray = mean over channels; [sobel_x, sobel_y, laplacian](gray), 3x3, zero
+// pad; per-channel 5x5 blur, zero pad 2.  One pass: one thread = one pixel of one batch item, every output plane of it; the
+// <= 25*ch + 9 inputs are L1/L2 hits (neighbouring threads share them).  feat [B, 3+ch, H, W] = [sx | sy | lap | blur(ch)],
+// the input of the learned `embed` convolutions.  k3: the three 3x3 filters [3][9]; k5: the blur taps [25] (the module's
+// frozen parameters, so a loaded state_dict is honoured).  MAXCH image channels (3 or 4 in the reference's targets).
+template <int MAXCH>
+__global__ __launch_bounds__(256) void image_encoder_front_kernel(const float* __restrict__ img, const float* __restrict__ k3,
+                                                                  const float* __restrict__ k5, float* __restrict__ feat, int B, int ch,
+                                                                  int H, int W) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t plane = (size_t)H * W;
+    if (id >= (size_t)B * plane) return;
+    const int px = (int)(id % W), py = (int)((id / W) % H), b = (int)(id / plane);
+    const float* const ib = img + (size_t)b * ch * plane;
+    float blur[MAXCH], g[3][3];
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) blur[c] = 0.0f;
+    const float inv = 1.0f / (float)ch;
+#pragma unroll
+    for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int y = py + dy, x = px + dx;
+            const bool in = y >= 0 && y < H && x >= 0 && x < W;
+            const float kw = k5[(dy + 2) * 5 + dx + 2];
+            float sum = 0.0f;
+#pragma unroll
+            for (int c = 0; c < MAXCH; ++c) {
+                const float v = (in && c < ch) ? ib[(size_t)c * plane + (size_t)y * W + x] : 0.0f;
+                blur[c] = fmaf(kw, v, blur[c]);
+                sum += v;
+            }
+            if (dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1) g[dy + 1][dx + 1] = sum * inv;   // torch.mean: sum / ch
+        }
+    float* const ob = feat + (size_t)b * (3 + ch) * plane + (size_t)py * W + px;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc = fmaf(k3[f * 9 + t], g[t / 3][t % 3], acc);
+        ob[(size_t)f * plane] = acc;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c)
+        if (c < ch) ob[(size_t)(3 + c) * plane] = blur[c];
+}
+
+// EdgeExtractor (ConditioneDyNCA/models/dynca.py:182-213): [sobel_x, sobel_y, laplacian] of a 1-channel image, zero pad, then tanh
+// when edge_transform == 'tanh'.  out [B,3,H,W] is the step's conditioning input.
+__global__ __launch_bounds__(256) void edge_extractor_kernel(const float* __restrict__ img, const float* __restrict__ k3,
+                                                             float* __restrict__ out, int B, int H, int W, int do_tanh) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t plane = (size_t)H * W;
+    if (id >= (size_t)B * plane) return;
+    const int px = (int)(id % W), py = (int)((id / W) % H), b = (int)(id / plane);
+    const float* const ib = img + (size_t)b * plane;
+    float g[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int y = py + t / 3 - 1, x = px + t % 3 - 1;
+        g[t] = (y >= 0 && y < H && x >= 0 && x < W) ? ib[(size_t)y * W + x] : 0.0f;
+    }
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc = fmaf(k3[f * 9 + t], g[t], acc);
+        out[((size_t)b * 3 + f) * plane + (size_t)py * W + px] = do_tanh ? tanhf(acc) : acc;
+    }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void cond_perceive_kernel(const float* __restrict__ z, const float* __restrict__ wp,
                                                             float* __restrict__ y, int B, int C, int H, int W) {
@@ -253,6 +325,22 @@ hipError_t nca_launch_dynca_perceive(const float* x, float* y, int B, int C, int
     else
         hipLaunchKernelGGL(dynca_perceive_kernel<false>, dim3(blocks_for((size_t)B * C * H * W)), dim3(256), 0, st, x,
                            y, B, C, H, W, pad);
+    return hipGetLastError();
+}
+
+hipError_t nca_launch_image_encoder_front(const float* img, const float* k3, const float* k5, float* feat, int B, int ch, int H, int W,
+                                          hipStream_t st) {
+    const size_t n = (size_t)B * H * W;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (ch <= 4) hipLaunchKernelGGL(image_encoder_front_kernel<4>, grid, dim3(256), 0, st, img, k3, k5, feat, B, ch, H, W);
+    else if (ch <= 8) hipLaunchKernelGGL(image_encoder_front_kernel<8>, grid, dim3(256), 0, st, img, k3, k5, feat, B, ch, H, W);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t nca_launch_edge_extractor(const float* img, const float* k3, float* out, int B, int H, int W, int do_tanh, hipStream_t st) {
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(edge_extractor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, img, k3, out, B, H, W, do_tanh);
     return hipGetLastError();
 }
 

@@ -21,6 +21,8 @@ SIGNATURES = {
     "ncahip_check_errors": [_P, _I],
     "ncahip_debug_inject_error": [ctypes.c_uint],
     "ncahip_debug_force_generic": [_I],
+    "ncahip_image_encoder_front_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "ncahip_edge_extractor_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
     "ncahip_dynca_perceive_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
     "ncahip_cond_perceive_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
     "ncahip_dynca_step_fwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P],

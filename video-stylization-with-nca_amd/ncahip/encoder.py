@@ -3,9 +3,10 @@
 Conditioning precompute for ConditionedNCA.grow (runs ONCE per grow, nca.py:198): grayscale ->
 Sobel-x / Sobel-y / Laplacian, per-channel 5x5 Gaussian blur (sigma 1), then a learned
 3x3 conv -> ReLU -> 3x3 conv giving `embedding_dim` channels per pixel.  This is the "next" row f1
-of SURVEY.md section 8 (adjacent to the hot path): it stays on PyTorch-ROCm ops (autograd flows into
-`embed`), with the three fixed filters fused into one conv call and the blur done as one depthwise
-conv instead of a Python loop.  state_dict keys match the reference
+of SURVEY.md section 8 (adjacent to the hot path): on the device the fixed-filter front (gray, three 3x3
+filters, per-channel blur) is ONE hand-written HIP pass (ncahip_image_encoder_front_f32, no gradient
+needed: the target image is data); the learned `embed` convolutions stay on PyTorch-ROCm ops (autograd
+flows into them).  CPU tensors (host-side tests) take the equivalent torch ops.  state_dict keys match the reference
 (sobel_x/sobel_y/gaussian_blur/laplacian .weight frozen, embed.0.{weight,bias}, embed.2.weight).
 """
 import math
@@ -47,6 +48,11 @@ class ImageEncoder(nn.Module):
         )
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and self.channels <= 8 and not (torch.is_grad_enabled() and x.requires_grad):
+            # the fixed-filter front as ONE HIP pass (ncahip_image_encoder_front_f32); the learned convolutions follow on MIOpen
+            from . import ops
+            k3 = torch.cat((self.sobel_x.weight, self.sobel_y.weight, self.laplacian.weight), dim=0)
+            return self.embed(ops.image_encoder_front(x, k3, self.gaussian_blur.weight))
         gray = x.mean(dim=1, keepdim=True)
         edge_bank = torch.cat((self.sobel_x.weight, self.sobel_y.weight, self.laplacian.weight), dim=0)
         edges = F.conv2d(gray, edge_bank, padding=1)                                   # [B,3,H,W]

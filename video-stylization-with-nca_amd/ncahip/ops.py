@@ -81,6 +81,28 @@ def cond_perceive(z: torch.Tensor, wp: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def image_encoder_front(img: torch.Tensor, k3: torch.Tensor, k5: torch.Tensor) -> torch.Tensor:
+    """[sobel_x | sobel_y | laplacian](mean over channels) and the per-channel 5x5 blur in one pass (encoder.py:37-52)."""
+    img = _dev(img, "img")
+    B, ch, H, W = img.shape
+    k3, k5 = _w(k3.reshape(-1), "k3", img), _w(k5.reshape(-1), "k5", img)
+    assert k3.numel() == 27 and k5.numel() == 25
+    feat = torch.empty(B, 3 + ch, H, W, device=img.device, dtype=torch.float32)
+    check(lib().ncahip_image_encoder_front_f32(_p(img), _p(k3), _p(k5), _p(feat), B, ch, H, W, _stream()), "image_encoder_front")
+    return feat
+
+
+def edge_extractor(img: torch.Tensor, k3: torch.Tensor, apply_tanh: bool) -> torch.Tensor:
+    """[sobel_x | sobel_y | laplacian] of a 1-channel image, zero pad, optional tanh (dynca.py:204-213)."""
+    img = _dev(img, "img")
+    B, one, H, W = img.shape
+    assert one == 1
+    k3 = _w(k3.reshape(-1), "k3", img)
+    out = torch.empty(B, 3, H, W, device=img.device, dtype=torch.float32)
+    check(lib().ncahip_edge_extractor_f32(_p(img), _p(k3), _p(out), B, H, W, int(apply_tanh), _stream()), "edge_extractor")
+    return out
+
+
 def philox_uniform(B: int, H: int, W: int, seed: int, step: int, device="cuda") -> torch.Tensor:
     u = torch.empty(B, 1, H, W, device=device, dtype=torch.float32)
     check(lib().ncahip_philox_uniform_f32(_p(u), B, H, W, seed, step, _stream()), "philox_uniform")
