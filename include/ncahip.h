@@ -70,7 +70,8 @@ int ncahip_cond_precision(int mode);
 
 /* Test hook (process-wide) selecting which kernel family serves the fused steps, so every variant can be checked
  * against the oracle on the same inputs: bit 0 = generic any-shape kernels instead of the aligned fast paths;
- * bit 1 = symmetric wave-private ConditionedNCA kernel instead of the default producer/consumer one. */
+ * bit 1 = symmetric wave-private ConditionedNCA kernel instead of the default producer/consumer one;
+ * bit 2 = ncahip_cond_grow_bwd_bf16 evaluates its matrix products in exact fp32 instead of on bf16 MFMA. */
 int ncahip_debug_force_generic(int on);
 
 /* Device-side check that the MFMA operand/accumulator lane maps the kernels assume hold on
@@ -329,10 +330,13 @@ int ncahip_cond_grow_bwd_f32(const float *states, const uint8_t *pre, int T,
                              void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
 
 /* The same backward over a bf16 history: states [T+1 slots] and goal as stored by ncahip_cond_grow_fwd_bf16 with ring = T+1
- * (BASELINE configs[2]: a bf16 pool halves the saved-for-backward set).  The stored values are widened exactly, the step is
- * recomputed in fp32 from them and EVERY gradient (inputs g_final, outputs, scratch) is fp32: the gradient of the fp32 step
- * function evaluated along the bf16 trajectory (straight-through with respect to the storage rounding and the bf16 matrix
- * operands of the forward; bound against the fp32 gradients in tests/).  W % 4 == 0, states / goal 8-byte aligned.           */
+ * (BASELINE configs[2]: a bf16 pool halves the saved-for-backward set).  Mixed precision as in the forward: the stored values
+ * are widened exactly; perception, masks, gating and every stored gradient (g_final, outputs, scratch) are fp32; the matrix
+ * products -- the recomputed UpdateNet with the forward's rounding points, the data path through W3^T / W2^T / W1^T, and
+ * the three weight-gradient products over the cell axis -- run on v_mfma_f32_16x16x16_bf16 with fp32 accumulation (92 MFMAs
+ * of 8 cycles per 16 cells instead of 368 exact-f32 ones of 32).  Straight-through with respect to the storage rounding;
+ * bound against the exact-fp32 products of the same history and against the fp32 gradients in tests/.
+ * W % 4 == 0, states / goal 8-byte aligned.                                                                             */
 int ncahip_cond_grow_bwd_bf16(const uint16_t *states, const uint8_t *pre, int T,
                               const uint16_t *goal, int goal_ch, const float *u,
                               const float *wp, const float *w1, const float *b1,

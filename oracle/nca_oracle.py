@@ -444,3 +444,32 @@ def cond_step_bf16(x, goal_pad, u, prm, alive_ch=3, thr=0.1, fire_rate=0.5, lo=-
     post = cond_alive(x_pend, alive_ch, thr) if alive_ch >= 0 else torch.ones_like(pre)
     x_next = (x_pend * (pre & post).float()).clamp(lo, hi)
     return x_next, pre, x_pend
+
+
+def _bf_ste(t):
+    """round to bf16 in the forward, identity in the backward (straight-through)"""
+    return t + (_bf(t) - t).detach()
+
+
+def cond_grow_bf16_loss_grads(x0, goal_pad, us, prm, alive_ch, thr, fire_rate, cot, lo=-10.0, hi=10.0):
+    """Autograd through T bf16-storage steps with the rounding points of include/ncahip.h (bf16 state / goal, f32 perception,
+    bf16 matrix operands and weights, f32 accumulation, bf16 store), every rounding straight-through.  This is the function
+    whose gradient ncahip_cond_grow_bwd_bf16 evaluates (its own extra rounding: the gradient operands d out, d2, d1 of the
+    backward products are bf16 as well).  Returns (x_T, dL/dx0, dL/dgoal_pad, {param: grad}) for L = <cot, x_T>."""
+    x = x0.clone().requires_grad_(True)
+    g = goal_pad.clone().requires_grad_(True)
+    p = {k: v.clone().requires_grad_(True) for k, v in prm.items() if k.startswith(("perception_net", "update_net"))}
+    w1, w2, w3 = (_bf_ste(p[f"update_net.out.{i}.weight"]) for i in (0, 2, 4))
+    cur = x
+    for u in us:
+        pre = cond_alive(cur, alive_ch, thr) if alive_ch >= 0 else torch.ones_like(cur[:, :1], dtype=torch.bool)
+        z = cur + g * pre.float()
+        pc = cond_perceive(z, p["perception_net.weight"])
+        h1 = F.relu(F.conv2d(_bf_ste(pc), w1, p["update_net.out.0.bias"]))
+        h2 = F.relu(F.conv2d(_bf_ste(h1), w2, p["update_net.out.2.bias"]))
+        out = F.conv2d(_bf_ste(h2), w3, None)
+        x1 = _bf_ste(cur + cond_fire_mask(u, fire_rate) * out)
+        post = cond_alive(x1, alive_ch, thr) if alive_ch >= 0 else torch.ones_like(pre)
+        cur = torch.clamp(x1 * (pre & post).float(), lo, hi)
+    (cur * cot).sum().backward()
+    return cur.detach(), x.grad, g.grad, {k: v.grad for k, v in p.items()}

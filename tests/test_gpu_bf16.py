@@ -162,11 +162,12 @@ def test_module_grow_bf16(ops):
 
 @pytest.mark.parametrize("C,shape,gch,Tn", [(16, (2, 32, 48), 12, 4), (12, (2, 24, 32), 8, 3), (16, (1, 16, 16), 16, 2)])
 def test_cond_grow_backward_bf16_history(ops, C, shape, gch, Tn):
-    """ncahip_cond_grow_bwd_bf16: the gradient of the fp32 step function along the bf16 trajectory.  Checked two ways:
-    (i) exactly that definition -- the fp32 backward kernel fed the widened bf16 history must agree bit for bit;
-    (ii) against oracle autograd through the fp32 steps started from the same bf16-representable inputs (different
+    """ncahip_cond_grow_bwd_bf16 (bf16 history, matrix products on bf16 MFMA, everything else fp32).  Checked three ways:
+    (i) the storage plumbing: with the exact-f32 product hook the bf16-history kernel equals the fp32 kernel fed the widened
+    history bit for bit; (ii) the bf16-MFMA products against those exact-f32 products of the SAME history (relative L2);
+    (iii) against oracle autograd through the fp32 steps started from the same bf16-representable inputs (different
     trajectory: bf16 storage + bf16 matrix operands in the forward), within the bf16 budget.  The alpha channel is held
-    fixed (zero output row) so no life mask sits near its threshold and the comparison is smooth."""
+    fixed (zero output row) so no life mask sits near its threshold and the comparisons are smooth."""
     B, H, W = shape
     gen = torch.Generator().manual_seed(C + Tn)
     from test_gpu_parity import rand_cond_prm
@@ -184,25 +185,34 @@ def test_cond_grow_backward_bf16_history(ops, C, shape, gch, Tn):
     assert states.dtype == torch.bfloat16
     g16 = ops.cond_grow_backward(states, pre, gd, ud, w, cd, Tn, 3)
     g32 = ops.cond_grow_backward(states.float(), pre, gd.float(), ud, w, cd, Tn, 3)
-    for k in g16:
-        assert g16[k].dtype == torch.float32 and torch.equal(g16[k], g32[k]), k
-    _, gx, gg, gw = O.cond_grow_loss_grads(x0, O.cond_pad_goal(goal, C), list(us), prm, 3, 0.1, 0.5, cot)
-    # a ReLU whose pre-activation changes sign between the two trajectories moves ONE cell's gradient by O(1), so the bound is
-    # on the relative L2 error (2 %), with a loose cap on the largest single-element deviation
-    def rel2(a, b):
-        a, b = a.cpu().double().reshape(-1), b.double().reshape(-1)
-        return float((a - b).norm() / b.norm().clamp_min(1e-12)), float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
-    for got, ref in ((g16["x0"], gx), (g16["goal"], gg[:, C - gch:])):
-        l2, mx = rel2(got, ref)
-        assert l2 < 2e-2 and mx < 0.25, (l2, mx)
+    ops.force_generic(4)
+    try:
+        g16x = ops.cond_grow_backward(states, pre, gd, ud, w, cd, Tn, 3)
+    finally:
+        ops.force_generic(0)
+    rel2 = lambda a, b: float((a.cpu().double().reshape(-1) - b.cpu().double().reshape(-1)).norm() / b.double().norm().clamp_min(1e-12))
     names = {"wp": "perception_net.weight", "w1": "update_net.out.0.weight", "b1": "update_net.out.0.bias",
              "w2": "update_net.out.2.weight", "b2": "update_net.out.2.bias", "w3": "update_net.out.4.weight"}
+    for k in g16:
+        assert g16x[k].dtype == torch.float32 and torch.equal(g16x[k], g32[k]), k          # (i) storage plumbing, bit for bit
+        # (ii) bf16-MFMA products vs exact-f32 products of the same history.  The two evaluate ReLU' on different
+        # pre-activations (bf16-operand vs exact recomputation): a fraction p of hidden units near zero flips and moves the
+        # relative L2 distance by ~sqrt(p) -- a few per cent, the price of gates that are consistent with the bf16 forward
+        assert g16[k].dtype == torch.float32 and rel2(g16[k], g32[k]) < 8e-2, (k, rel2(g16[k], g32[k]))
+    # (iii) the function the kernel differentiates: oracle autograd through the bf16-faithful steps (straight-through
+    # roundings).  Same gates, same operands; the kernel additionally rounds the gradient operands of its products to bf16.
+    _, gx, gg, gw = O.cond_grow_bf16_loss_grads(x0, O.cond_pad_goal(goal, C), list(us), prm, 3, 0.1, 0.5, cot)
+    tol = 2e-2 if Tn <= 2 else 4e-2          # longer roll-outs: the two trajectories drift apart by final-rounding flips
+    assert rel2(g16["x0"], gx) < tol and rel2(g16["goal"], gg[:, C - gch:]) < tol, (rel2(g16["x0"], gx), rel2(g16["goal"], gg[:, C - gch:]))
     for k, n in names.items():
-        l2, mx = rel2(g16[k], gw[n])
-        assert l2 < 2e-2 and mx < 5e-2, (k, l2, mx)
+        assert rel2(g16[k], gw[n]) < tol, (k, rel2(g16[k], gw[n]))
+    # (iv) and the fp32 oracle (exact step function, fp32 trajectory from the same inputs): the bf16 budget end to end
+    _, gx, gg, gw = O.cond_grow_loss_grads(x0, O.cond_pad_goal(goal, C), list(us), prm, 3, 0.1, 0.5, cot)
+    assert rel2(g16["x0"], gx) < 8e-2 and rel2(g16["goal"], gg[:, C - gch:]) < 8e-2
+    for k, n in names.items():
+        assert rel2(g16[k], gw[n]) < 8e-2, (k, rel2(g16[k], gw[n]))
 
 
-# ------------------------------------------------------------------------------------------------ DyNCA, bf16 storage
 @pytest.mark.parametrize("C,fc,cc,pad,shape", [(12, 96, 3, "circular", (2, 24, 32)), (16, 128, 3, "replicate", (1, 16, 48)),
                                                (12, 96, 0, "reflect", (2, 9, 11)), (16, 128, 2, "constant", (1, 8, 36))])
 def test_dynca_bf16_storage(ops, C, fc, cc, pad, shape):

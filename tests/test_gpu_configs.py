@@ -210,9 +210,11 @@ def test_cfg3_forward_backward_vs_oracle_on_crops(ops, storage):
     w = cond_w(ops, prm, xd)
     out, states, pre = ops.cond_grow(xd, Tn, gd, us.to(DEV), w, 3, keep_history=True)
     gr = ops.cond_grow_backward(states, pre, gd, us.to(DEV), w, cot.to(DEV), Tn, 3)
-    # fp32: max-norm, the north_star's bar.  bf16 (storage rounding of T states, bf16 matrix operands in the forward): the
-    # trajectory differs from the fp32 oracle's, so forward within 3e-2 max-norm and gradients within 2 % relative L2
-    ftol, gtol = (REL_TOL, 2e-4) if not bf else (3e-2, 2e-2)
+    # fp32: max-norm, the north_star's bar.  bf16 (storage rounding of T states, bf16 matrix operands, ReLU gates taken from the
+    # bf16 recomputation): the trajectory and a few per cent of the gates differ from the fp32 oracle's, so forward within 3e-2
+    # max-norm and gradients within 8 % relative L2 (tests/test_gpu_bf16.py bounds the same kernel at 2-4 % against the oracle
+    # that shares its rounding points)
+    ftol, gtol = (REL_TOL, 2e-4) if not bf else (3e-2, 8e-2)
     gerr = _rel2 if bf else _rel
     for b in range(B):
         y0, x0_ = wins[b]

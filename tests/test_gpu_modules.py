@@ -461,3 +461,33 @@ def test_conditioning_front_ends_golden_g7():
             assert rel_err(ee(T(g["gray"], DEV)), T(g[key])) < 1e-5
     img = torch.rand(2, 1, 9, 31, generator=torch.Generator().manual_seed(1)) * 2 - 1
     assert rel_err(EdgeExtractor("tanh").to(DEV)(img.to(DEV)), O.edge_extractor(img, "tanh")) < 1e-5
+
+
+def test_loss_on_the_device_f2():
+    """f2 on ROCm: the objective (overflow + OT appearance + content, VGG16 features as a pure-torch definition -- weights
+    are unobtainable offline, so VALUES vs the reference are 'parity unpinned') evaluated on the GPU: batched OT == the
+    per-sample loop, bf16 features close to fp32 features, gradients reach the generated images."""
+    import warnings
+    from ncahip.loss import Loss, STYLE_LAYERS, ot_loss_batched, ot_loss_single
+    dev = torch.device(DEV)
+    style = (np.random.RandomState(0).rand(64, 64, 3) * 255).astype(np.uint8)        # H x W x C uint8, as the reference loads it
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        L32 = Loss(dev, target_style_image=style)
+        L16 = Loss(dev, target_style_image=style, feature_dtype=torch.bfloat16)
+    gen = torch.rand(4, 3, 64, 64, device=dev, requires_grad=True)
+    d = {"generated_images": gen, "nca_state": torch.rand(4, 16, 64, 64, device=dev) * 3 - 1.5, "target_images": torch.rand(4, 3, 64, 64, device=dev)}
+    np.random.seed(1)
+    v32, parts = L32(d)
+    v32.backward()
+    assert set(parts) == {"overflow", "appearance", "content"} and bool(torch.isfinite(gen.grad).all()) and float(gen.grad.abs().max()) > 0
+    np.random.seed(1)
+    v16, _ = L16(d)
+    assert abs(float(v16) - float(v32)) < 0.05 * abs(float(v32))
+    feats = L32.vgg(gen.detach(), STYLE_LAYERS)
+    tgt = [L32.style_feats[l] for l in STYLE_LAYERS]
+    np.random.seed(2)
+    loop = sum(ot_loss_single(tgt, [feats[l][b:b + 1] for l in STYLE_LAYERS]) for b in range(4)) / 4
+    np.random.seed(2)
+    bat = ot_loss_batched(tgt, [feats[l] for l in STYLE_LAYERS])
+    assert abs(float(loop) - float(bat)) < 1e-4 * abs(float(loop))

@@ -7,6 +7,7 @@ HIP events on the launch stream).  `python tools/bench_paths.py [names...]`; wit
   dynca_fwd       DyNCA forward steps: C=16/fc=128, C=12/fc=96, C=32/fc=128 and C=32/fc=256 at 2x512^2 (configs[4])
   dynca_train     DyNCA forward with history + backward (the C driver): C=16/fc=128, C=12/fc=96, C=32/fc=256 at 2x512^2
   big             working sets beyond the 256 MiB Infinity Cache: perception stencil and fused fp32 step at B=64
+  loss            the default objective (VGG16 features + batched OT + content + overflow) at 32 x 3 x 256^2, fp32 / bf16 features
 """
 import json
 import os
@@ -129,6 +130,30 @@ def big():
          state_MB=x.numel() * 4 / 1e6)
 
 
+def loss_leg():
+    """The reference's default objective at BASELINE configs[2]'s batch (32 x 3 x 256^2): VGG16 features (seeded random weights:
+    the ImageNet weights cannot be fetched here, the WORK is the same) + OT appearance (batched) + content + overflow, forward and
+    backward to the generated images, fp32 and bf16 features."""
+    import warnings
+    import numpy as np
+    from ncahip.loss import Loss
+    dev = torch.device(DEV)
+    style = (np.random.RandomState(0).rand(256, 256, 3) * 255).astype(np.uint8)
+    for name, dt in (("float32", torch.float32), ("bfloat16", torch.bfloat16)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            L = Loss(dev, target_style_image=style, feature_dtype=dt)
+        gen = torch.rand(32, 3, 256, 256, device=dev, requires_grad=True)
+        d = {"generated_images": gen, "nca_state": torch.rand(32, 16, 256, 256, device=dev) * 3 - 1.5,
+             "target_images": torch.rand(32, 3, 256, 256, device=dev)}
+
+        def f():
+            gen.grad = None
+            L(d)[0].backward()
+        (ms,), (mn,) = timed([f], iters=10)
+        emit(path="cfg3_loss", features=name, B=32, ms_fwd_bwd=ms, min_ms=mn, objective="overflow + OT appearance (batched) + content, VGG16 random weights")
+
+
 def main(names):
     allp = not names
     if allp or "cond_train" in names:
@@ -148,6 +173,8 @@ def main(names):
         dynca(2, 32, 256, 512, 512, 8, True)
     if allp or "big" in names:
         big()
+    if allp or "loss" in names:
+        loss_leg()
 
 
 if __name__ == "__main__":

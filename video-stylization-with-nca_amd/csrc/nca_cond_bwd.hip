@@ -14,6 +14,8 @@
 //   B  cond_step_bwd_stencil_kernel   HBM-bound: dL/ds_t = dL/dx'_t + depthwise-stencil^T(dL/dperception),
 //      dL/dgoal += dz * pre_t, per-block partials of the perception-weight gradient.
 // One wave per SIMD (the persistent accumulators need the registers); 4 waves / workgroup / CU.
+#include <cstdlib>
+
 #include "nca_cond_tile.h"
 
 #if defined(NCA_STAMPS)
@@ -92,7 +94,33 @@ __device__ __forceinline__ void piped(LD&& ld, MM&& mm) {
 
 // ST = storage type of the history (states / pending states) and of the goal encoding: StF32, or StBF16 for a bf16 pool
 // (BASELINE configs[2]): the values are widened exactly on load and the whole recomputation and every gradient stay f32.
-template <int CP, typename ST = StF32>
+// BFM: the matrix products (forward recomputation, data path, weight gradients) on bf16 MFMA (v_mfma_f32_16x16x16_bf16, f32
+// accumulation) with the rounding points of the bf16 forward kernel (perception vector, hidden activations, weights; see
+// include/ncahip.h): 92 bf16 MFMAs of 8 cycles per 16 cells instead of 368 exact-f32 ones of 32.  Cell-axis-as-K operands
+// are transposed through LDS with ds_read_b64_tr_b16.  Everything that is not a matrix product (staging, gating, masks, the
+// stencil kernel B, every stored gradient) stays f32.
+typedef short bf_s16x4 __attribute__((ext_vector_type(4)));
+// transposition buffer of the BFM path: [16 cells][TBH halfwords], 8 tiles of 16 features (32 B) per row + 16 B pad: pitch
+// 72 dwords makes the transposed reads conflict-free; the 8-byte chunk of a tile is XOR-swizzled by (cell >> 2) so the
+// 8-byte accumulator-layout writes are conflict-free too.
+constexpr int TBH = 144;
+__device__ __forceinline__ bf_s16x4 tb_tr_read(const short* tb, int tile, int lane) {
+    // operand [feature i][cells 4g .. 4g+3] of a 16-feature tile: lane 4q+p of group g supplies row (cell) 4g+q, chunk p
+    const int g = (lane >> 4) & 3, i = lane & 15, q = i >> 2, p = i & 3;
+    const short* a = tb + (4 * g + q) * TBH + tile * 16 + 4 * (p ^ g);
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf_s16x4 __attribute__((address_space(3)))*)(a));
+}
+__device__ __forceinline__ void tb_write(short* tb, int tile, int lane, bf_s16x4 v) {
+    // accumulator layout: lane (g, cell c) holds features 4g .. 4g+3 of the tile for its cell: chunk g of row c
+    const int g = (lane >> 4) & 3, c = lane & 15;
+    *reinterpret_cast<bf_s16x4*>(tb + c * TBH + tile * 16 + 4 * (g ^ ((c >> 2) & 3))) = v;
+}
+__device__ __forceinline__ void tb_write_chunk(short* tb, int chunk, int lane, bf_s16x4 v) {   // chunk = 4 * tile + position
+    const int c = lane & 15;
+    *reinterpret_cast<bf_s16x4*>(tb + c * TBH + (chunk >> 2) * 16 + 4 * ((chunk & 3) ^ ((c >> 2) & 3))) = v;
+}
+
+template <int CP, typename ST = StF32, bool BFM = false>
 __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const NcaCondBwdArgs ba) {
     using K = BCfg<CP>;
     using FK = WCfg<CP>;
@@ -175,6 +203,54 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
     float* const TB = PWR + K::PW_TB;
     float* const A1 = PWR + K::PW_A1;
 
+    // BFM: bf16 A operands of every product, built once per launch from the f32 LDS images (same k orders as the f32 path) and
+    // kept as ONE packed image in LDS, [operand][lane] x 8 bytes, over the (then dead) f32 images: 120 operand registers per
+    // lane would not fit beside the 128 weight-gradient accumulators.
+    constexpr int KS1 = (K::K1S + 3) / 4;                 // bf16 k-steps of layer 1 (slots q = 3*c4 + f, zero padded)
+    constexpr int OP_W1 = 0, OP_W2 = OP_W1 + 4 * KS1, OP_W3T = OP_W2 + 16, OP_W2T = OP_W3T + 4, OP_W1T = OP_W2T + 16, OP_N = OP_W1T + 4 * K::MJ;
+    static_assert(OP_N * 64 * 2 <= FK::OFF_B1, "bf16 operand image fits over the f32 W1 | W2 | W3 images");
+    const bf_s16x4* const BW = reinterpret_cast<const bf_s16x4*>(smem) + lane;      // operand o of this lane: BW[o * 64]
+    if constexpr (BFM) {
+        bf_s16x4 img[(OP_N + kBwdWaves - 1) / kBwdWaves];    // this wave's share of the operands (round robin)
+        const int w2t_lane0 = (ci & 3) * 64 + (ci >> 2) * 16 + 4 * g;
+        auto build = [&](int o) -> bf_s16x4 {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (o < OP_W2) {                           // W1 forward: (m, s)
+                const int m = o / KS1, s_ = o % KS1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = 4 * s_ + r < K::K1S ? W1L[(m * K::K1S + 4 * s_ + r) * 64 + lane] : 0.0f;
+            } else if (o < OP_W3T) {                   // W2 forward: (m2, kk)
+                const int m2 = (o - OP_W2) >> 2, kk = (o - OP_W2) & 3;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = W2L[(m2 * 16 + 4 * kk + r) * 64 + lane];
+            } else if (o < OP_W2T) {                   // W3^T: m
+                const int m = o - OP_W3T;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = W3T[(m * 4 + r) * 64 + lane];
+            } else if (o < OP_W1T) {                   // W2^T: (m, mp) = W2[h2 = 16mp+4g+r][h1 = 16m+ci]
+                const int m = (o - OP_W2T) >> 2, mp = (o - OP_W2T) & 3;
+                const f32x4 t = ld4(W2L + (mp * 16 + 4 * m) * 64 + w2t_lane0);
+                v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+            } else {                                   // W1^T: (mj, kk)
+                const int mj = (o - OP_W1T) >> 2, kk = (o - OP_W1T) & 3;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = W1T[(mj * 16 + 4 * kk + r) * 64 + lane];
+            }
+            return pack4(v[0], v[1], v[2], v[3]);
+        };
+#pragma unroll
+        for (int k = 0; k < (OP_N + kBwdWaves - 1) / kBwdWaves; ++k) {
+            const int o = k * kBwdWaves + wave;
+            img[k] = o < OP_N ? build(o) : bf_s16x4{0, 0, 0, 0};
+        }
+        __syncthreads();                               // every wave has read what it needs of the f32 images
+#pragma unroll
+        for (int k = 0; k < (OP_N + kBwdWaves - 1) / kBwdWaves; ++k) {
+            const int o = k * kBwdWaves + wave;
+            if (o < OP_N) *(reinterpret_cast<bf_s16x4*>(smem) + o * 64 + lane) = img[k];
+        }
+        __syncthreads();
+    }
     // persistent weight-gradient accumulators (D = A * B^T with the cell axis as K)
     f32x4 aW1[4][K::MJ], aW2[4][4], aW3[4];
     float db1[4][4], db2[4][4];
@@ -335,6 +411,135 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             float P[NT][K::K1S];
             perceive_tile<CP, NT>(smem, Z, lane, n0, P);
             NCA_BPHASE(4);   // perception
+            f32x4 dp[K::MJ][NT];
+            if constexpr (BFM) {
+                short* const tb16 = reinterpret_cast<short*>(TB);
+                // ---- forward recompute on bf16 MFMA (rounding points of the bf16 forward kernel) ---------------------------
+                bf_s16x4 pb[NT][KS1];
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int s_ = 0; s_ < KS1; ++s_) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = 4 * s_ + r < K::K1S ? P[n][4 * s_ + r] : 0.0f;
+                        pb[n][s_] = pack4(v[0], v[1], v[2], v[3]);
+                    }
+                f32x4 h1f[4][NT], h2f[4][NT];              // pre-ReLU accumulators (gates), f32
+                bf_s16x4 h1b[4][NT], h2b[4][NT];           // ReLU'd, bf16: operands of layer 2 / 3 and of the weight gradients
+#pragma unroll
+                for (int m2 = 0; m2 < 4; ++m2) {
+                    const f32x4 b = ld4(B2L + 16 * m2 + 4 * g);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) h2f[m2][n] = b;
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const f32x4 b = ld4(B1L + 16 * m + 4 * g);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        f32x4 a1 = b;
+#pragma unroll
+                        for (int s_ = 0; s_ < KS1; ++s_) a1 = mfma_bf16(BW[(OP_W1 + m * KS1 + s_) * 64], pb[n][s_], a1);
+                        h1f[m][n] = a1;
+                        h1b[m][n] = pack4_relu(a1);
+#pragma unroll
+                        for (int m2 = 0; m2 < 4; ++m2) h2f[m2][n] = mfma_bf16(BW[(OP_W2 + m2 * 4 + m) * 64], h1b[m][n], h2f[m2][n]);
+                    }
+                }
+#pragma unroll
+                for (int m2 = 0; m2 < 4; ++m2)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) h2b[m2][n] = pack4_relu(h2f[m2][n]);
+                NCA_BPHASE(5);   // forward recompute
+                bf_s16x4 dOb[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int rw = pass ? NT + n : n;
+                    dOb[n] = pack4(dOall[rw][0], dOall[rw][1], dOall[rw][2], dOall[rw][3]);
+                }
+                bf_s16x4 d2b[4][NT], d1b[4][NT];
+                // ---- layer 3: dW3 += dO x h2 (cells as K);  d2 = (W3^T dO) * 1[h2 > 0] ---------------------------------------
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    wave_sync();
+                    tb_write(tb16, 0, lane, dOb[n]);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) tb_write(tb16, 1 + m, lane, h2b[m][n]);
+                    wave_sync();
+                    const bf_s16x4 ta = tb_tr_read(tb16, 0, lane);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) aW3[nb] = mfma_bf16(ta, tb_tr_read(tb16, 1 + nb, lane), aW3[nb]);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        f32x4 d = mfma_bf16(BW[(OP_W3T + m) * 64], dOb[n], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { d[r] = h2f[m][n][r] > 0.0f ? d[r] : 0.0f; db2[m][r] += d[r]; }
+                        d2b[m][n] = pack4(d[0], d[1], d[2], d[3]);
+                    }
+                NCA_BPHASE(6);   // layer 3
+                // ---- layer 2: dW2 += d2 x h1;  d1 = (W2^T d2) * 1[h1 > 0] ----------------------------------------------------
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    wave_sync();
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { tb_write(tb16, m, lane, d2b[m][n]); tb_write(tb16, 4 + m, lane, h1b[m][n]); }
+                    wave_sync();
+                    bf_s16x4 tbv[4];
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) tbv[nb] = tb_tr_read(tb16, 4 + nb, lane);
+#pragma unroll
+                    for (int ma = 0; ma < 4; ++ma) {
+                        const bf_s16x4 ta = tb_tr_read(tb16, ma, lane);
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) aW2[ma][nb] = mfma_bf16(ta, tbv[nb], aW2[ma][nb]);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int mp = 0; mp < 4; ++mp) d = mfma_bf16(BW[(OP_W2T + m * 4 + mp) * 64], d2b[mp][n], d);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { d[r] = h1f[m][n][r] > 0.0f ? d[r] : 0.0f; db1[m][r] += d[r]; }
+                        d1b[m][n] = pack4(d[0], d[1], d[2], d[3]);
+                    }
+                NCA_BPHASE(7);   // layer 2
+                // ---- layer 1: dW1 += d1 x P (P columns in slot order: column 12 g' + q, un-permuted at the slab flush);  dp = W1^T d1
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    wave_sync();
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) tb_write(tb16, m, lane, d1b[m][n]);
+#pragma unroll
+                    for (int s_ = 0; s_ < KS1; ++s_) tb_write_chunk(tb16, 16 + 3 * g + s_, lane, pb[n][s_]);   // columns 12g + 4s .. of tiles 4..6
+                    wave_sync();
+                    bf_s16x4 tbv[K::MJ];
+#pragma unroll
+                    for (int nb = 0; nb < K::MJ; ++nb) tbv[nb] = tb_tr_read(tb16, 4 + nb, lane);
+#pragma unroll
+                    for (int ma = 0; ma < 4; ++ma) {
+                        const bf_s16x4 ta = tb_tr_read(tb16, ma, lane);
+#pragma unroll
+                        for (int nb = 0; nb < K::MJ; ++nb) aW1[ma][nb] = mfma_bf16(ta, tbv[nb], aW1[ma][nb]);
+                    }
+                }
+#pragma unroll
+                for (int mj = 0; mj < K::MJ; ++mj)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) d = mfma_bf16(BW[(OP_W1T + mj * 4 + kk) * 64], d1b[kk][n], d);
+                        dp[mj][n] = d;
+                    }
+                NCA_BPHASE(8);   // layer 1
+            } else {
             f32x4 h1[4][NT], h2[4][NT];
             constexpr int G1 = 3, NG1 = K::K1S / G1;   // layer-1 k-steps in groups of 3 (K1S = 9 or 12)
             static_assert(K::K1S % G1 == 0, "layer-1 operand groups");
@@ -404,7 +609,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             // B[k=g][j] = TB[4s+g][rowB+j] are 16 consecutive floats per lane group.
             float* const tw_ = TB + ci * TBS + 4 * g;            // this lane's cell row, accumulator-row offset
             const float* const tr_ = TB + g * TBS + ci;           // operand reads: cell 4s+g -> + 4*s*TBS
-            f32x4 d2[4][NT], d1[4][NT], dp[K::MJ][NT];
+            f32x4 d2[4][NT], d1[4][NT];
             // ---- layer 3: dW3 = dO (rows 0..15) x h2 (rows 16..79);  d2 = (W3^T dO) * 1[h2 > 0] ---------------------------
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -550,6 +755,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
                         for (int n = 0; n < NT; ++n) dp[mj][n] = nca_mfma(o.v[r], d1[mp][n][r], dp[mj][n]);
                 });
             NCA_BPHASE(8);   // layer 1
+            }
             // ---- dL/dperception out: [j][2 rows][16] via TB, 16-byte stores -----------------------------------
             wave_sync();
 #pragma unroll
@@ -610,8 +816,12 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             const int o = 16 * ma + 4 * g + r;
             if (o < hid) {
 #pragma unroll
-                for (int nb = 0; nb < K::MJ; ++nb)
-                    if (16 * nb + ci < K1) sw[o * K1 + 16 * nb + ci] = aW1[ma][nb][r];
+                for (int nb = 0; nb < K::MJ; ++nb) {
+                    if constexpr (BFM) {   // column 16nb + ci = 12 g' + q, q = 3 c4 + f: channel 4 c4 + g', filter f
+                        const int col = 16 * nb + ci, gp = col / 12, q = col - 12 * gp, j = 3 * (4 * (q / 3) + gp) + q % 3;
+                        if (gp < 4 && q < K::K1S && j < K1) sw[o * K1 + j] = aW1[ma][nb][r];
+                    } else if (16 * nb + ci < K1) sw[o * K1 + 16 * nb + ci] = aW1[ma][nb][r];
+                }
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
                     if (16 * nb + ci < hid) sw[slab_off_w2(C, hid) + o * hid + 16 * nb + ci] = aW2[ma][nb][r];
@@ -842,10 +1052,10 @@ __global__ __launch_bounds__(64) void reduce_wp_kernel(const float* __restrict__
     dst[c * 27 + i] = acc;
 }
 
-template <int CP, typename ST>
+template <int CP, typename ST, bool BFM = false>
 hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
     using K = BCfg<CP>;
-    auto kern = cond_step_bwd_kernel<CP, ST>;
+    auto kern = cond_step_bwd_kernel<CP, ST, BFM>;
     const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
     static NcaLdsAttr attr;   // per instantiation; keyed by device inside
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
@@ -871,11 +1081,19 @@ int nca_cond_bwd_slab_floats(int C, int hidden) { return slab_floats(C, hidden);
 int nca_cond_bwd_nslab() { return nca_cu_count(); }   // one persistent workgroup (and one slab) per CU
 int nca_cond_bwd_nblk(int B, int C, int H, int W) { return B * C * ((((H + SROWS - 1) / SROWS) * (W / 4) + 255) / 256); }
 
+static bool g_bwd_bf16_exact = getenv("NCAHIP_BWD_BF16_EXACT") != nullptr;
+void nca_set_bwd_bf16_exact(bool on) { g_bwd_bf16_exact = on; }
+
 // W % 4 == 0 and 16-byte aligned tensors required (checked by the C ABI).
 hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st, bool bf16) {
     if (bf16) {   // history (f.x_in, x_next) and goal hold bf16; gradients and scratch stay f32
-        if (ba.f.C <= 12) return launch_bwd<12, StBF16>(ba, st);
-        if (ba.f.C <= 16) return launch_bwd<16, StBF16>(ba, st);
+        if (g_bwd_bf16_exact) {   // test hook: exact-f32 recomputation from the widened history
+            if (ba.f.C <= 12) return launch_bwd<12, StBF16>(ba, st);
+            if (ba.f.C <= 16) return launch_bwd<16, StBF16>(ba, st);
+            return hipErrorInvalidValue;
+        }
+        if (ba.f.C <= 12) return launch_bwd<12, StBF16, true>(ba, st);
+        if (ba.f.C <= 16) return launch_bwd<16, StBF16, true>(ba, st);
         return hipErrorInvalidValue;
     }
     if (ba.f.C <= 12) return launch_bwd<12, StF32>(ba, st);

@@ -124,6 +124,7 @@ hipError_t nca_launch_cond_step_fwd_bf16(const NcaCondArgs& a, hipStream_t st);
 hipError_t nca_launch_cond_finalize_bf16(const uint16_t* x, const uint8_t* pre, uint16_t* out, int B, int C, int H, int W,
                                          int alive_ch, float thr, float lo, float hi, hipStream_t st);
 void nca_set_cond_precision(int mode);   // 0 = exact-f32 MFMA (default), 1 = bf16x3 emulation in the producer/consumer kernel
+void nca_set_bwd_bf16_exact(bool on);  // test hook: the bf16-history backward recomputes in exact f32 instead of on bf16 MFMA
 void nca_set_cond_variant(int v);  // 0 = producer/consumer (default), 1 = symmetric wave-private
 
 // diagnostic build hook (-DNCA_STAMPS): buffer that receives s_memtime stamps, [wave][tile][8]
