@@ -13,8 +13,9 @@ B, C, H, W, T = 8, 16, 256, 256, 2
 dev = "cuda"
 gen = torch.Generator().manual_seed(0)
 prm = bench.make_weights(gen)
-x = torch.rand(B, C, H, W, generator=gen).to(dev)
-goal = (torch.randn(B, 12, H, W, generator=gen) * 0.5).to(dev)
+DT = torch.bfloat16 if "bf16" in sys.argv[1:] else torch.float32      # bf16: the bf16-history / bf16-MFMA backward
+x = torch.rand(B, C, H, W, generator=gen).to(dev, DT)
+goal = (torch.randn(B, 12, H, W, generator=gen) * 0.5).to(dev, DT)
 cot = torch.randn(B, C, H, W, generator=gen).to(dev)
 w = ops.CondWeights(prm["perception_net.weight"], prm["update_net.out.0.weight"], prm["update_net.out.0.bias"],
                     prm["update_net.out.2.weight"], prm["update_net.out.2.bias"], prm["update_net.out.4.weight"], x)

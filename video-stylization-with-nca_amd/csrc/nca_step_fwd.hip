@@ -468,6 +468,19 @@ __global__ __launch_bounds__(kThreads, (BWD || MS) ? 1 : 2) void dynca_step_fwd_
 #pragma unroll
                     for (int mj = 0; mj < K::MJ; ++mj) wt1[mj] = *reinterpret_cast<const f32x4*>(W1L + (m * K::K1S + 4 * mj) * 64 + w1t_lane);
                 };
+                // later slices of a wide hidden layer add to the dL/dy the earlier launches wrote: those partial sums are requested
+                // here, a whole MFMA phase ahead of their use (one wave per SIMD: a load issued next to its use costs its full latency)
+                float prev[ACC ? NT : 1][ACC ? K::MJ : 1][4];
+                if constexpr (ACC) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int mj = 0; mj < K::MJ; ++mj)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                prev[n][mj][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                    rdy, (int)voy[n], (int)((unsigned)min(4 * mj + r, C - 1) * plane4), 0));
+                }
                 fetch1(0);
                 float hT[W2F ? NT : 1][4];
 #pragma unroll (W2F ? K::M1T : 1)
@@ -539,23 +552,13 @@ __global__ __launch_bounds__(kThreads, (BWD || MS) ? 1 : 2) void dynca_step_fwd_
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     if (!live[n]) continue;
-                    float prev[K::MJ][4];
-                    if constexpr (ACC) {
-#pragma unroll
-                        for (int mj = 0; mj < K::MJ; ++mj)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                prev[mj][r] = (4 * mj + r < C) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                                                                     rdy, (int)voy[n], (int)((unsigned)(4 * mj + r) * plane4), 0))
-                                                               : 0.0f;
-                    }
 #pragma unroll
                     for (int mj = 0; mj < K::MJ; ++mj)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             if (4 * mj + r < C) {
                                 float v = dY[mj][n][r];
-                                if constexpr (ACC) v += prev[mj][r];
+                                if constexpr (ACC) v += prev[n][mj][r];
                                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rdy, (int)voy[n],
                                                                       (int)((unsigned)(4 * mj + r) * plane4), 0);
                             }
@@ -573,6 +576,19 @@ __global__ __launch_bounds__(kThreads, (BWD || MS) ? 1 : 2) void dynca_step_fwd_
                     const f32x4 bias = *reinterpret_cast<const f32x4*>(B2L + 16 * m2 + 4 * g);
     #pragma unroll
                     for (int n = 0; n < NT; ++n) acc2[m2][n] = bias;
+                }
+                // later fc slice: the partial result of the earlier launches is requested now, a whole MLP ahead of its use
+                float xprev[ACC ? NT : 1][K::M2T][4];
+                if constexpr (ACC) {
+    #pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int gy = min(ty0 + r0[n], H - 1), gx = min(tx0 + q0[n], W - 1);
+                        const float* const ob = a.x_out + (size_t)b * C * plane + (size_t)gy * W + gx;
+    #pragma unroll
+                        for (int m2 = 0; m2 < K::M2T; ++m2)
+    #pragma unroll
+                            for (int r = 0; r < 4; ++r) xprev[n][m2][r] = ob[(size_t)min(16 * m2 + 4 * g + r, C - 1) * plane];
+                    }
                 }
                 float wa1[K::K1S], wa2[4][K::M2T];
                 f32x4 bias1;
@@ -636,7 +652,7 @@ __global__ __launch_bounds__(kThreads, (BWD || MS) ? 1 : 2) void dynca_step_fwd_
                                 const int ch = 16 * m2 + 4 * g + r;
                                 if (ch < C) {
                                     float xo = Z[ch * K::CS + (r0[n] + 1) * K::RS + q0[n] + 4];
-                                    if constexpr (ACC) xo = ob[(size_t)ch * plane];   // later fc slice: add to the partial result
+                                    if constexpr (ACC) xo = xprev[n][m2][r];           // later fc slice: add to the partial result
                                     const float xn = xo + acc2[m2][n][r] * mk;
                                     if constexpr (B16) ob16[ch * plane] = nca_f32_to_b16(xn);
                                     else   // write-through (sc1): no dirty lines left for the end-of-kernel L2 write-back
