@@ -436,7 +436,7 @@ int ncahip_dynca_step_bwd_w2_f32(const float* x_t, const float* cond, const floa
                    g_next, nullptr, dh_out, dy_scratch, g_x};
     a.gw2_ws = (float*)workspace;
     if (int rc = hip_result(nca_launch_dynca_step_bwd(a, (hipStream_t)stream), "dynca_step_bwd_w2")) return rc;
-    return hip_result(nca_launch_reduce_rows((const float*)workspace, gw2_out, nca_dynca_bwd_grid(B, H, W), C * fc + C,
+    return hip_result(nca_launch_reduce_rows((const float*)workspace, gw2_out, nca_dynca_bwd_grid_c(B, C, H, W), C * fc + C,
                                              (hipStream_t)stream, accumulate != 0), "dynca_step_bwd_w2 reduce");
 }
 
@@ -453,7 +453,7 @@ DyncaBwdPlan dynca_bwd_plan(int B, int C, int H, int W, int fc, int c_cond) {
     p.fs = fc < 128 ? fc : 128;
     p.K1 = 4 * C + c_cond;
     p.n = (size_t)B * C * H * W;
-    p.grid2 = nca_dynca_bwd_grid(B, H, W);
+    p.grid2 = nca_dynca_bwd_grid_c(B, C, H, W);
     p.gridg = nca_gram_grid(B, H * W);
     size_t o = 0;
     auto take = [&](size_t floats) { size_t at = o; o += (floats * sizeof(float) + 255) & ~(size_t)255; return at; };

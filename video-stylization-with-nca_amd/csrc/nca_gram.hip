@@ -25,7 +25,7 @@ struct GramArgs {
 
 // ROWSPLIT: wave w owns out row tiles [w*RT, (w+1)*RT) x all CT column tiles; else all RT row tiles x column tiles
 // [w*CT, (w+1)*CT).  MA_T x NB_T 16-row tiles are staged per chunk.
-template <int RT, int CT, bool ROWSPLIT>
+template <int RT, int CT, bool ROWSPLIT, bool ONES>
 __global__ __launch_bounds__(kGramThreads, 2) void gram_rows_kernel(const GramArgs a) {
     constexpr int MA_T = ROWSPLIT ? 4 * RT : RT, NB_T = ROWSPLIT ? CT : 4 * CT;
     constexpr int ROWS = 16 * (MA_T + NB_T), PER = ROWS / 4;   // rows staged per chunk; rows per wave
@@ -35,6 +35,10 @@ __global__ __launch_bounds__(kGramThreads, 2) void gram_rows_kernel(const GramAr
     const int nb = a.nb1 + a.nb2, HW = a.HW;
     const int cpb = (HW + kGramChunk - 1) / kGramChunk, total = a.B * cpb;
 
+    // Row sums of A (the bias gradient): as ONE MORE B COLUMN of ones when the column tiles have room for it (nb < 16 * NB_T:
+    // the dW1-like shapes) -- it then rides on the MFMAs; a vector add inside an exact-f32 MFMA stream drains the matrix pipe
+    // (~25 cycles each), and there were 2 per k-step.  Full column tiles (dW2-like, nb = 128) keep the adds.
+    constexpr bool ones_col = ONES;      // the launcher picks ONES = (nb < 16 * NB_T)
     f32x4 acc[RT][CT];
     float rs[RT];
 #pragma unroll
@@ -82,13 +86,15 @@ __global__ __launch_bounds__(kGramThreads, 2) void gram_rows_kernel(const GramAr
         // Rows beyond the real counts hold copies of the last real row: they only reach output rows / columns that are never
         // written.  Cells beyond HW (last chunk of a batch item) would reach every output: zeroed here.
         const int cell0 = (c % cpb) * kGramChunk;
+        // (ONES: staged B row nb is the ones column -- a scalar select at store time, the load of that slot is simply unused)
+        const int ones_row = ONES ? 16 * MA_T + nb : -1;
         if (cell0 + kGramChunk <= HW) {
 #pragma unroll
-            for (int k = 0; k < PER; ++k) lds[(4 * k + wave) * kGramLS + lane] = pre[k];
+            for (int k = 0; k < PER; ++k) lds[(4 * k + wave) * kGramLS + lane] = (4 * k + wave == ones_row) ? 1.0f : pre[k];
         } else {
             const bool in = cell0 + lane < HW;
 #pragma unroll
-            for (int k = 0; k < PER; ++k) lds[(4 * k + wave) * kGramLS + lane] = in ? pre[k] : 0.0f;
+            for (int k = 0; k < PER; ++k) lds[(4 * k + wave) * kGramLS + lane] = in ? ((4 * k + wave == ones_row) ? 1.0f : pre[k]) : 0.0f;
         }
         __syncthreads();
         if (c + (int)gridDim.x < total) issue(c + gridDim.x);   // next chunk's rows fly during this chunk's products
@@ -114,8 +120,10 @@ __global__ __launch_bounds__(kGramThreads, 2) void gram_rows_kernel(const GramAr
 #pragma unroll
                 for (int j = 0; j < CT; ++j) acc[i][j] = nca_mfma(av[q][i], bv[q][j], acc[i][j]);
             }
+            if (!ones_col) {
 #pragma unroll
-            for (int i = 0; i < RT; ++i) rs[i] += av[q][i];
+                for (int i = 0; i < RT; ++i) rs[i] += av[q][i];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -132,27 +140,36 @@ __global__ __launch_bounds__(kGramThreads, 2) void gram_rows_kernel(const GramAr
             for (int r = 0; r < 4; ++r) {
                 const int o = 16 * rt + 4 * g + r;
                 if (o < a.ma && col < nb) ws[(size_t)o * nb + col] = acc[i][j][r];
+                if (ones_col && o < a.ma && col == nb) ws[(size_t)a.ma * nb + o] = acc[i][j][r];   // row sums = the ones column
             }
         }
-        float v = rs[i];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        const int o = 16 * rt + ci;
-        if (g == 0 && o < a.ma && (ROWSPLIT || wave == 0)) ws[(size_t)a.ma * nb + o] = v;
+        if (!ones_col) {
+            float v = rs[i];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int o = 16 * rt + ci;
+            if (g == 0 && o < a.ma && (ROWSPLIT || wave == 0)) ws[(size_t)a.ma * nb + o] = v;
+        }
     }
 }
 
-template <int RT, int CT, bool ROWSPLIT>
-hipError_t launch_gram(const GramArgs& a, int grid, hipStream_t st) {
+template <int RT, int CT, bool ROWSPLIT, bool ONES>
+hipError_t launch_gram_o(const GramArgs& a, int grid, hipStream_t st) {
     constexpr int MA_T = ROWSPLIT ? 4 * RT : RT, NB_T = ROWSPLIT ? CT : 4 * CT;
     constexpr size_t lds = (size_t)16 * (MA_T + NB_T) * kGramLS * sizeof(float);
-    auto kern = gram_rows_kernel<RT, CT, ROWSPLIT>;
+    auto kern = gram_rows_kernel<RT, CT, ROWSPLIT, ONES>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kGramThreads), lds, st, a);
     return hipGetLastError();
+}
+
+template <int RT, int CT, bool ROWSPLIT>
+hipError_t launch_gram(const GramArgs& a, int grid, hipStream_t st) {
+    constexpr int NB_T = ROWSPLIT ? CT : 4 * CT;
+    return (a.nb1 + a.nb2 < 16 * NB_T) ? launch_gram_o<RT, CT, ROWSPLIT, true>(a, grid, st) : launch_gram_o<RT, CT, ROWSPLIT, false>(a, grid, st);
 }
 
 }  // namespace

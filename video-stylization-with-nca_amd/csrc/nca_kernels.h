@@ -102,7 +102,8 @@ int nca_cond_bwd_nblk(int B, int C, int H, int W);
 hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& a, hipStream_t st, bool bf16 = false);   // bf16: f.x_in / x_next / f.goal hold bf16
 hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st, bool accumulate = false);   // dst (+)= column sums
 // nca_gram.hip: out[ma*nb + ma] = [sum_n a[i][n] * b[j][n] | sum_n a[i][n]] over all B*HW cells; b rows from two tensors
-int nca_dynca_bwd_grid(int B, int H, int W);   // workgroups of the DyNCA backward kernel (= partial slabs of its fused dW2)
+int nca_dynca_bwd_grid(int B, int H, int W);   // upper bound over C (workspace sizing)
+int nca_dynca_bwd_grid_c(int B, int C, int H, int W);   // the grid the backward kernel actually runs with = number of slabs it writes   // workgroups of the DyNCA backward kernel (= partial slabs of its fused dW2)
 int nca_gram_grid(int B, int HW);
 hipError_t nca_launch_gram_rows(const float* a, int ma, const float* b1, int nb1, const float* b2, int nb2, int B, int HW,
                                 float* out, float* ws, hipStream_t st, bool accumulate = false);

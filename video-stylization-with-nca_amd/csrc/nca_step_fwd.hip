@@ -195,7 +195,7 @@ struct DyncaCfg {
     // kernel), so the backward needs no weight images of its own.  dL/dy is produced in tiles of 16 rows = 4 channels x 4
     // filters (row i <-> channel 4mj + (i & 3), filter i >> 2): MJ = CP / 4 tiles, no conditioning rows (dynca.py:123).
     static constexpr int MJ = CP / 4;
-    static constexpr int LDS_FLOATS_BWD = LDS_FLOATS;
+    static constexpr int LDS_FLOATS_BWD = OFF_CN;                     // the backward reads the conditioning straight from memory (no CN tile)
     static constexpr int TBS = M2T == 1 ? 20 : 36;                    // transposition tiles [16 cells][TBS] (16-byte rows)
     static constexpr int OFF_TB = LDS_FLOATS_BWD;                     // fused dW2: per wave NT tiles
     static constexpr int LDS_FLOATS_BWD_W2 = OFF_TB + 4 * NT * 16 * TBS;
@@ -212,7 +212,7 @@ struct DyncaCfg {
 // (dW2 = (G*mask) h^T, dW1 = dh y^T, K = all cells) are plain library GEMMs on those buffers.
 template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT, bool VEC, bool BWD = false, bool B16 = false, bool ACC = false, bool W2F = false,
           bool MS = false>
-__global__ __launch_bounds__(kThreads, (BWD || MS) ? 1 : 2) void dynca_step_fwd_kernel(const NcaDyncaArgs a) {
+__global__ __launch_bounds__(kThreads, ((BWD && CP > 16) || MS) ? 1 : 2) void dynca_step_fwd_kernel(const NcaDyncaArgs a) {
     static_assert(!MS || (!BWD && !B16 && !ACC && TH % 2 == 0 && TW % 2 == 0), "the two-scale step is an fp32 forward kernel");
     static_assert(!W2F || BWD, "fused dW2 is an option of the backward kernel");
     static_assert(!ACC || !B16, "accumulating passes (fc slices beyond the first) read fp32 partial results");
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kThreads, (BWD || MS) ? 1 : 2) void dynca_step_fwd_
         const size_t cell = (size_t)b * plane + (cin ? (size_t)cgy * W + cgx : 0);
         float uu = 0.0f, cnv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (a.u) uu = a.u[cell];
-        if (HAS_COND) {
+        if (HAS_COND && !BWD) {
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc)
                 cnv[cc] = a.cond[((size_t)b * CC + min(cc, CC - 1)) * plane + (cell - (size_t)b * plane)];
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kThreads, (BWD || MS) ? 1 : 2) void dynca_step_fwd_
         }
         if (!a.u) uu = nca_philox_cell(a.seed, a.step, cell);
         MK[st] = cin ? floorf(uu + a.rate) : 0.0f;  // dynca.py:131
-        if (HAS_COND) {
+        if (HAS_COND && !BWD) {
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) CN[cc * TH * TW + st] = (cin && cc < CC) ? cnv[cc] : 0.0f;
         }
@@ -386,7 +386,13 @@ __global__ __launch_bounds__(kThreads, (BWD || MS) ? 1 : 2) void dynca_step_fwd_
             }
             if (HAS_COND) {
 #pragma unroll
-                for (int n = 0; n < NT; ++n) P[n][CP] = CN[g * TH * TW + r0[n] * TW + q0[n]];
+                for (int n = 0; n < NT; ++n) {
+                    if constexpr (BWD) {   // conditioning channel g of the lane's cell, straight from memory (64-byte segments per lane group)
+                        const int gy = min(ty0 + r0[n], H - 1), gx = min(tx0 + q0[n], W - 1);
+                        const float cv = a.cond[((size_t)b * CC + min(g, CC - 1)) * plane + (size_t)gy * W + gx];
+                        P[n][CP] = (g < CC && ty0 + r0[n] < H && tx0 + q0[n] < W) ? cv : 0.0f;
+                    } else P[n][CP] = CN[g * TH * TW + r0[n] * TW + q0[n]];
+                }
             }
             if constexpr (BWD) {
                 // ---- backward data path -----------------------------------------------------------------
@@ -1107,12 +1113,13 @@ hipError_t launch_dynca(const NcaDyncaArgs& a, hipStream_t st) {
 
 template <int CP, int FC, bool HAS_COND, bool ACC>
 hipError_t launch_dynca_bwd(const NcaDyncaArgs& a, hipStream_t st) {
-    constexpr int TH = 8, TW = 32, NT = CP > 16 ? 2 : 4;
+    constexpr int TH = 8, TW = 32, NT = 2;       // two 16-cell groups per pass: 2 workgroups per CU at C <= 16 (registers and LDS)
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
     static_assert(K::LDS_FLOATS_BWD_W2 * 4 <= 160 * 1024 && 4 * (16 * K::M2T * FC + 16 * K::M2T) <= K::LDS_FLOATS_BWD_W2, "LDS budget (backward)");
     const bool vec = (a.W % 4 == 0) && aligned16(a.x_in);
     const int ntiles = a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
-    const int grid = grid_for(ntiles, 1);
+    const int grid = nca_dynca_bwd_grid_c(a.B, a.C, a.H, a.W);
+    (void)ntiles;
     auto go = [&](auto kern, size_t lds) -> hipError_t {
         hipError_t e = set_lds(kern, lds);
         if (e != hipSuccess) return e;
@@ -1336,10 +1343,11 @@ hipError_t nca_launch_dynca_step_fwd_bf16(const NcaDyncaArgs& a, hipStream_t st)
     return hipErrorInvalidValue;
 }
 
-int nca_dynca_bwd_grid(int B, int H, int W) {
+int nca_dynca_bwd_grid_c(int B, int C, int H, int W) {
     const int ntiles = B * ((W + 31) / 32) * ((H + 7) / 8);
-    return grid_for(ntiles, 1);
+    return grid_for(ntiles, C > 16 ? 1 : 2);
 }
+int nca_dynca_bwd_grid(int B, int H, int W) { return nca_dynca_bwd_grid_c(B, 16, H, W); }   // upper bound (slab workspace sizing)
 
 // The MLP part of one backward step (writes dh, dL/dy and, with gw2_ws, the per-workgroup dW2 | db2 partials).  acc: a later
 // 128-wide slice of a wide hidden layer -- dL/dy is added to what the earlier slices wrote.
