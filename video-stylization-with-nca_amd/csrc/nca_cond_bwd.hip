@@ -264,7 +264,6 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
     }
 
     NCA_BPHASE(10);  // start-up: weight images, accumulators
-    float l2warm = 0.0f;   // landing register of the L2 warm-up reads (never consumed)
     // ---- tile walk: super-tiles of 16 x 16 (4 waves stacked vertically) ------------------------------------
     constexpr int BSTH = 16, BSTW = 16;
     const int st_x = (W + BSTW - 1) / BSTW, st_y = (H + BSTH - 1) / BSTH;
@@ -342,35 +341,44 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
         }
 
         // ---- warm the L2 for the NEXT tile: one 4-byte read per row segment it will load (state and goal rows with halo 1,
-        //      pending state and gradient rows), ~5 instructions.  There are no registers to hold the real loads a tile ahead
-        //      (one wave per SIMD, 256 + 200 in use), but these only need ONE landing register: they are issued here, return
-        //      during the pass loop, and the tile's real requests then meet the L2 instead of HBM.
+        //      pending state and gradient rows).  There are no registers to hold the real loads a tile ahead (one wave per SIMD,
+        //      256 + 200 in use), but these need only a handful of landing registers: they are issued here, return during the
+        //      pass loop, and the tile's real requests then meet the L2 instead of HBM.  They are ordinary loads the compiler
+        //      tracks (issue pinned by the scheduling fence, values "consumed" by an empty asm after the pass loop): an
+        //      inline-asm load into a register the allocator may copy or re-use while the load is in flight is a race.
+        constexpr int NW1 = (8 * 2 * CP + 63) / 64, NW2 = (8 * CP + 63) / 64;
+        float warm[NW1 + NW2];
+#pragma unroll
+        for (int k = 0; k < NW1 + NW2; ++k) warm[k] = 0.0f;
         if (tw.t + tw.stride < tw.end) {
             const int tnx = tw.t + tw.stride, gch = a.goal_ch;
             const int nb = tnx / (st_x * st_y), ny0 = ((tnx / st_x) % st_y) * BSTH + wave * WTH, nx0 = (tnx % st_x) * BSTW;
-            constexpr unsigned SB = ST::BYTES;      // state-type tensors are addressed in bytes; the 4-byte warm-up read may
-            // straddle into the next element of a bf16 row, which is fine: the value is never consumed
+            constexpr unsigned SB = ST::BYTES;      // state-type tensors are addressed in bytes; a 4-byte read of a bf16 row
+            // covers two elements (even column: aligned), which is fine: the value is never used
             const char* const bx = reinterpret_cast<const char*>(a.x_in) + (size_t)nb * C * plane * SB;
             const char* const bg = gch ? reinterpret_cast<const char*>(a.goal) + (size_t)nb * gch * plane * SB : bx;
             const char* const bn = reinterpret_cast<const char*>(ba.x_next) + (size_t)nb * C * plane * SB;
             const float* const bq = ba.g_next + (size_t)nb * C * plane;
-            const unsigned col = (unsigned)min(nx0, W - 1);
+            const unsigned col = (unsigned)min(nx0, W - 1) & ~1u;
             // state + goal planes: 8 rows each (ty0-1 ..; two more than needed keeps the index arithmetic to shifts)
-            for (int base = 0; base < 8 * (C + gch); base += 64) {
-                const int i = min(base + lane, 8 * (C + gch) - 1), pl = i >> 3;
-                const unsigned rowo = (unsigned)min(max(ny0 + (i & 7) - 1, 0), H - 1) * (unsigned)W + (col & ~1u);
+#pragma unroll
+            for (int k = 0; k < NW1; ++k) {
+                const int i = min(64 * k + lane, 8 * (C + gch) - 1), pl = i >> 3;
+                const unsigned rowo = (unsigned)min(max(ny0 + (i & 7) - 1, 0), H - 1) * (unsigned)W + col;
                 const char* const p = (pl < C ? bx + (size_t)((unsigned)pl * plane + rowo) * SB : bg + (size_t)((unsigned)(pl - C) * plane + rowo) * SB);
-                asm volatile("global_load_dword %0, %1, off" : "+v"(l2warm) : "v"(p) : "memory");
+                warm[k] = *reinterpret_cast<const float*>(p);
             }
             // pending state + incoming gradient: 4 rows each
-            for (int base = 0; base < 8 * C; base += 64) {
-                const int i = min(base + lane, 8 * C - 1), pl = i >> 2;
-                const unsigned rowo = (unsigned)min(ny0 + (i & 3), H - 1) * (unsigned)W + (col & ~1u);
+#pragma unroll
+            for (int k = 0; k < NW2; ++k) {
+                const int i = min(64 * k + lane, 8 * C - 1), pl = i >> 2;
+                const unsigned rowo = (unsigned)min(ny0 + (i & 3), H - 1) * (unsigned)W + col;
                 const void* const p = pl < C ? (const void*)(bn + (size_t)((unsigned)pl * plane + rowo) * SB)
                                              : (const void*)(bq + (unsigned)(pl - C) * plane + rowo);
-                asm volatile("global_load_dword %0, %1, off" : "+v"(l2warm) : "v"(p) : "memory");
+                warm[NW1 + k] = *reinterpret_cast<const float*>(p);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);   // the requests stay HERE (not sunk to their "use" after the pass loop)
         NCA_BPHASE(2);   // x'/g loads, z out
         // ---- dL/dx'_t = G * 1[lo <= x'*life <= hi] * life (nca.py:191-194);  d out = . * fire mask.  All four
         //      rows now: TB (the staged incoming gradient) is reused for the transposes inside the pass loop.
@@ -779,6 +787,9 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             }
             NCA_BPHASE(9);   // dP out
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NW1 + NW2; ++k) asm volatile("" ::"v"(warm[k]));   // the warm-up reads have long returned
         // ---- dL/dx'_t out (XR), 16-byte stores ---------------------------------------------------------------
         wave_sync();
         {
@@ -863,7 +874,6 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
         const int i = tid + kBwdThreads * k;
         if (i < sf) slab[i] = cur[k] + ((smem[i] + smem[sf + i]) + (smem[2 * sf + i] + smem[3 * sf + i]));
     }
-    asm volatile("" ::"v"(l2warm));   // the landing register stays reserved until every warm-up read has returned
 #if defined(NCA_STAMPS)
     NCA_BPHASE(11);  // slab flush
     if (a.dbg && lane == 0) a.dbg[(size_t)(blockIdx.x * kBwdWaves + wave) * 16 + 11] = ph_acc[11];
