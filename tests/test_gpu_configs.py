@@ -186,12 +186,15 @@ def test_cfg3_forward_backward_vs_oracle_on_crops(ops, storage):
     x, goal, cot, wins = _patch_case(B, C, S, P, CR, seed=9)
     us = torch.rand(Tn, B, 1, S, S, generator=torch.Generator().manual_seed(10))
     bf = storage == "bf16"
+    # Gradients through 6 FREE-RUNNING steps are compared, so no life mask may sit within rounding distance of its threshold
+    # (a mask that resolves differently on the two sides is a legitimate O(1) difference: with evolving alpha this test flipped
+    # with the host's thread count, i.e. with the ORACLE's summation order).  Hold the alpha channel fixed: zero output row,
+    # alpha in {0} u [0.5, 1].  The live region is then each patch plus its one-cell frontier, for every step; evolving masks are
+    # covered strictly by the teacher-forced tests (cfg2 above, G1/G2/G8 goldens) and by the fuzz tests at small shapes.
+    prm["update_net.out.4.weight"][3] = 0.0
+    live = (x[:, 3:4] > 0).float()
+    x[:, 3:4] = live * (0.5 + 0.5 * x[:, 3:4])
     if bf:
-        # bf16 trajectory vs fp32 oracle: hold the alpha channel fixed (zero output row, alpha >= 0.5 inside the patches)
-        # so that no life mask sits near its threshold and the comparison is a smooth one
-        prm["update_net.out.4.weight"][3] = 0.0
-        live = (x[:, 3:4] > 0).float()
-        x[:, 3:4] = live * (0.5 + 0.5 * x[:, 3:4])
         x, goal = x.bfloat16().float(), goal.bfloat16().float()
     # oracle on the crops
     gx_ref = torch.zeros(B, C, CR, CR)

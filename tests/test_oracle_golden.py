@@ -10,7 +10,7 @@ import torch
 
 from oracle import nca_oracle as O
 
-torch.set_num_threads(1)
+torch.set_num_threads(1)   # NOTE: process-wide (the GPU suite imports this module at collection): oracle summation order
 
 
 def load(golden_dir, name):
