@@ -217,11 +217,12 @@ def test_cfg3_forward_backward_vs_oracle_on_crops(ops, storage):
     # bf16 recomputation): the trajectory and a few per cent of the gates differ from the fp32 oracle's, so forward within 3e-2
     # max-norm and gradients within 8 % relative L2 (tests/test_gpu_bf16.py bounds the same kernel at 2-4 % against the oracle
     # that shares its rounding points)
-    # fp32 gradients: relative L2 within 2e-4 plus a cap of 1e-2 on the largest single deviation.  Not a max-norm bound of 2e-4:
+    # fp32 gradients: relative L2 within 1e-3 plus a cap of 1e-2 on the largest single deviation.  Not a max-norm bound of 2e-4:
     # with ~1e8 hidden pre-activations in this test a handful lie within fp32 rounding of zero, their ReLU gate resolves differently
     # under the MFMA's and the CPU convolution's summation orders, and each such unit moves ONE cell's gradient by ~1e-3 of the
-    # maximum (seen: 1e-3 and 3e-3 at single cells, different cells for different host thread counts).
-    ftol, gtol = (REL_TOL, 2e-4) if not bf else (3e-2, 8e-2)
+    # maximum and, carried through the later steps' stencils, the item's relative L2 by ~2.5e-4 (seen: 1e-3 and 3e-3 at single
+    # cells, L2 2.6e-4 for that item, different items for different host thread counts; items without such a unit sit at ~1e-6).
+    ftol, gtol = (REL_TOL, 1e-3) if not bf else (3e-2, 8e-2)
 
     def gerr(a, b_):
         if not bf:
