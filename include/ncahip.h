@@ -201,6 +201,19 @@ int ncahip_dynca_nsteps_bwd_f32(const float *states, int T, const float *cond, c
                                 float *g_x0, float *g_w1, float *g_b1, float *g_w2, float *g_b2,
                                 void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
 
+/* The same backward through the TWO-SCALE steps of ncahip_dynca_nsteps_fwd_ms_f32 (training with perception_scales = [0, 1]:
+ * ExtraChannels/fit_video_motion.py:129-130 defaults to it).  dL/dy splits evenly over the two levels: the fine level goes
+ * through the stencil adjoint as before; the coarse level through the adjoint of the bilinear x2 up-sampling, the stencil
+ * adjoint on the COARSE grid (pad mode resolved there) and the adjoint of the 2x2 mean.  Even H and W, C <= 16, fc <= 128.     */
+size_t ncahip_dynca_nsteps_bwd_ms_workspace(int B, int C, int H, int W, int fc, int c_cond);
+int ncahip_dynca_nsteps_bwd_ms_f32(const float *states, int T, const float *cond, const float *u,
+                                   const float *w1, const float *b1, const float *w2, const float *b2,
+                                   int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                                   float update_rate, uint64_t seed, uint64_t step0,
+                                   const float *g_final, const float *g_states,
+                                   float *g_x0, float *g_w1, float *g_b1, float *g_w2, float *g_b2,
+                                   void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
+
 /* Weight-gradient products of the DyNCA backward with the cell axis as K (replaces the library GEMMs over transposed
  * copies that autograd through dynca.py:127-128 amounts to):
  *     out[i*nb + j] = sum over all B*HW cells of a[., i, .] * b[., j, .]     i < ma, j < nb = nb1 + nb2

@@ -284,10 +284,10 @@ def cond_grow_loss_grads(x0, goal_enc_padded, us, prm, alive_ch, thr, fire_rate,
     return xT.detach(), x0.grad, g.grad, grads
 
 
-def dynca_nsteps_loss_grads(x0, cond, us, prm, pad_mode, update_rate, cot):
+def dynca_nsteps_loss_grads(x0, cond, us, prm, pad_mode, update_rate, cot, scales=(0,)):
     x0 = x0.clone().requires_grad_(True)
     p = {k: prm[k].clone().requires_grad_(True) for k in ("w1.weight", "w1.bias", "w2.weight", "w2.bias")}
-    xT = dynca_nsteps(x0, cond, us, p, pad_mode, update_rate)
+    xT = dynca_nsteps(x0, cond, us, p, pad_mode, update_rate, scales)
     (xT * cot).sum().backward()
     return xT.detach(), x0.grad, {k: v.grad for k, v in p.items()}
 

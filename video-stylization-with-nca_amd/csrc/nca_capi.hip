@@ -444,16 +444,16 @@ int ncahip_dynca_step_bwd_w2_f32(const float* x_t, const float* cond, const floa
 namespace {
 struct DyncaBwdPlan {
     int nsl, fs;                 // hidden-layer slices of at most 128 units (fs = width of the full slices)
-    size_t n, off_g[2], off_y, off_dy, off_dh, off_ws2, off_wsg, off_acc1, off_acc2, total;
+    size_t n, off_g[2], off_y, off_dy, off_dh, off_ws2, off_wsg, off_acc1, off_acc2, off_pc, off_dpc, off_dxc, total;
     int grid2, gridg, K1;
 };
-DyncaBwdPlan dynca_bwd_plan(int B, int C, int H, int W, int fc, int c_cond) {
+DyncaBwdPlan dynca_bwd_plan(int B, int C, int H, int W, int fc, int c_cond, bool two_scale = false) {
     DyncaBwdPlan p{};
     p.nsl = (fc + 127) / 128;
     p.fs = fc < 128 ? fc : 128;
     p.K1 = 4 * C + c_cond;
     p.n = (size_t)B * C * H * W;
-    p.grid2 = nca_dynca_bwd_grid_c(B, C, H, W);
+    p.grid2 = two_scale ? nca_dynca_bwd_ms_grid(B, H, W) : nca_dynca_bwd_grid_c(B, C, H, W);
     p.gridg = nca_gram_grid(B, H * W);
     size_t o = 0;
     auto take = [&](size_t floats) { size_t at = o; o += (floats * sizeof(float) + 255) & ~(size_t)255; return at; };
@@ -466,6 +466,11 @@ DyncaBwdPlan dynca_bwd_plan(int B, int C, int H, int W, int fc, int c_cond) {
     p.off_wsg = take((size_t)p.gridg * ((size_t)p.fs * p.K1 + p.fs));
     p.off_acc1 = take((size_t)p.nsl * ((size_t)p.fs * p.K1 + p.fs));
     p.off_acc2 = take((size_t)p.nsl * ((size_t)C * p.fs + C));
+    if (two_scale) {   // coarse-level perception, its gradient, and dL/dx of the coarse level
+        p.off_pc = take(p.n);      // 4C * (H/2) * (W/2) = C*H*W floats
+        p.off_dpc = take(p.n);
+        p.off_dxc = take(p.n / 4);
+    }
     p.total = o;
     return p;
 }
@@ -475,8 +480,12 @@ size_t ncahip_dynca_nsteps_bwd_workspace(int B, int C, int H, int W, int fc, int
     if (!dims_ok(B, C, H, W) || fc <= 0 || c_cond < 0) return 0;
     return dynca_bwd_plan(B, C, H, W, fc, c_cond).total;
 }
+size_t ncahip_dynca_nsteps_bwd_ms_workspace(int B, int C, int H, int W, int fc, int c_cond) {
+    if (!dims_ok(B, C, H, W) || fc <= 0 || c_cond < 0) return 0;
+    return dynca_bwd_plan(B, C, H, W, fc, c_cond, true).total;
+}
 
-int ncahip_dynca_nsteps_bwd_f32(const float* states, int T, const float* cond, const float* u, const float* w1, const float* b1,
+static int dynca_nsteps_bwd_impl(bool two_scale, const float* states, int T, const float* cond, const float* u, const float* w1, const float* b1,
                                 const float* w2, const float* b2, int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
                                 float update_rate, uint64_t seed, uint64_t step0, const float* g_final, const float* g_states,
                                 float* g_x0, float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* workspace,
@@ -486,7 +495,10 @@ int ncahip_dynca_nsteps_bwd_f32(const float* states, int T, const float* cond, c
     if (int rc = check_dynca(states, g_x0, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, kMaxFcFwd)) return rc;
     if ((size_t)(128 > 4 * C ? 128 : 4 * C) * H * W * sizeof(float) >= ((size_t)1 << 32))
         return fail(NCAHIP_ERANGE, "dynca nsteps bwd: 4C*H*W*4 must stay below 4 GiB (32-bit store offsets inside a batch item)");
-    const DyncaBwdPlan p = dynca_bwd_plan(B, C, H, W, fc, c_cond);
+    if (two_scale) {
+        if (int rc = check_ms(C, H, W, fc, workspace)) return rc;
+    }
+    const DyncaBwdPlan p = dynca_bwd_plan(B, C, H, W, fc, c_cond, two_scale);
     if (workspace_bytes < p.total) return fail(NCAHIP_EINVAL, "dynca nsteps bwd: workspace too small");
     if (((uintptr_t)workspace & 15) != 0) return fail(NCAHIP_ERANGE, "dynca nsteps bwd: workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -499,6 +511,9 @@ int ncahip_dynca_nsteps_bwd_f32(const float* states, int T, const float* cond, c
     float* const wsg = (float*)(ws + p.off_wsg);
     float* const acc1 = (float*)(ws + p.off_acc1);
     float* const acc2 = (float*)(ws + p.off_acc2);
+    float* const pcb = two_scale ? (float*)(ws + p.off_pc) : nullptr;
+    float* const dpc = two_scale ? (float*)(ws + p.off_dpc) : nullptr;
+    float* const dxc = two_scale ? (float*)(ws + p.off_dxc) : nullptr;
     const size_t a1n = (size_t)p.fs * p.K1 + p.fs, a2n = (size_t)C * p.fs + C;
     hipError_t e = hipMemsetAsync(acc1, 0, (size_t)p.nsl * a1n * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(acc2, 0, (size_t)p.nsl * a2n * sizeof(float), st);
@@ -509,12 +524,17 @@ int ncahip_dynca_nsteps_bwd_f32(const float* states, int T, const float* cond, c
         const float* const x_t = states + (size_t)t * slot;
         float* const g_out = t == 0 ? g_x0 : gbuf[t & 1];
         if (int rc = hip_result(nca_launch_dynca_perceive(x_t, y, B, C, H, W, pad_mode, st), "dynca nsteps bwd perceive")) return rc;
+        if (two_scale) {   // y <- two-scale perception of x_t (the B rows of the layer-1 weight-gradient product)
+            if (int rc = hip_result(nca_launch_dynca_coarse_perceive(x_t, pcb, B, C, H, W, pad_mode, st), "dynca nsteps bwd coarse perceive")) return rc;
+            if (int rc = hip_result(nca_launch_dynca_ms_combine(y, pcb, B, C, H, W, st), "dynca nsteps bwd combine")) return rc;
+        }
         for (int sl = 0; sl < p.nsl; ++sl) {
             const int h0 = sl * 128, fs = fc - h0 < 128 ? fc - h0 : 128;
             NcaDyncaArgs a{x_t, nullptr, cond, u ? u + (size_t)t * uslot : nullptr, w1 + (size_t)h0 * p.K1, b1 + h0, w2 + h0, b2, B, C, H, W,
                            fs, c_cond, pad_mode, update_rate, seed, step0 + (uint64_t)t, gcur, nullptr, dh, dy, g_out};
             a.w2_ld = fc;
             a.gw2_ws = ws2;
+            a.pc = pcb;
             if (int rc = hip_result(nca_launch_dynca_step_bwd_mlp(a, st, sl > 0), "dynca nsteps bwd step")) return rc;
             // slabs hold [C x fs | C] of THIS slice (compact); slices narrower than p.fs use the front of their accumulator
             if (int rc = hip_result(nca_launch_reduce_rows(ws2, acc2 + (size_t)sl * a2n, p.grid2, C * fs + C, st, true), "dynca nsteps bwd reduce")) return rc;
@@ -524,6 +544,16 @@ int ncahip_dynca_nsteps_bwd_f32(const float* states, int T, const float* cond, c
         NcaDyncaArgs s{x_t, nullptr, cond, nullptr, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step0 + (uint64_t)t,
                        gcur, nullptr, dh, dy, g_out};
         s.g_extra = g_states ? g_states + (size_t)t * slot : nullptr;
+        if (two_scale) {
+            // dL/dy splits evenly over the two levels: coarse level = up2^T, then the coarse grid's stencil adjoint (pad mode
+            // resolved there), then the adjoint of the 2x2 mean inside the fine-level kernel
+            if (int rc = hip_result(nca_launch_dynca_ms_upT(dy, dpc, B, C, H, W, st), "dynca nsteps bwd upT")) return rc;
+            NcaDyncaArgs cs{nullptr, nullptr, nullptr, nullptr, w1, b1, w2, b2, B, C, H / 2, W / 2, fc, c_cond, pad_mode, update_rate, seed, 0,
+                            nullptr, nullptr, nullptr, dpc, dxc};
+            if (int rc = hip_result(nca_launch_dynca_step_bwd_stencil(cs, st), "dynca nsteps bwd coarse stencil")) return rc;
+            s.coarse_add = dxc;
+            s.dy_half = 1;
+        }
         if (int rc = hip_result(nca_launch_dynca_step_bwd_stencil(s, st), "dynca nsteps bwd stencil")) return rc;
         gcur = g_out;
     }
@@ -540,6 +570,23 @@ int ncahip_dynca_nsteps_bwd_f32(const float* states, int T, const float* cond, c
         if (e == hipSuccess && sl == 0) e = hipMemcpyAsync(g_b2, s2 + (size_t)C * fs, C * sizeof(float), hipMemcpyDeviceToDevice, st);
     }
     return hip_result(e, "dynca nsteps bwd copy");
+}
+
+int ncahip_dynca_nsteps_bwd_f32(const float* states, int T, const float* cond, const float* u, const float* w1, const float* b1,
+                                const float* w2, const float* b2, int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                                float update_rate, uint64_t seed, uint64_t step0, const float* g_final, const float* g_states,
+                                float* g_x0, float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* workspace,
+                                size_t workspace_bytes, ncahip_stream_t stream) {
+    return dynca_nsteps_bwd_impl(false, states, T, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step0, g_final,
+                                 g_states, g_x0, g_w1, g_b1, g_w2, g_b2, workspace, workspace_bytes, stream);
+}
+int ncahip_dynca_nsteps_bwd_ms_f32(const float* states, int T, const float* cond, const float* u, const float* w1, const float* b1,
+                                   const float* w2, const float* b2, int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                                   float update_rate, uint64_t seed, uint64_t step0, const float* g_final, const float* g_states,
+                                   float* g_x0, float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* workspace,
+                                   size_t workspace_bytes, ncahip_stream_t stream) {
+    return dynca_nsteps_bwd_impl(true, states, T, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step0, g_final,
+                                 g_states, g_x0, g_w1, g_b1, g_w2, g_b2, workspace, workspace_bytes, stream);
 }
 
 // ---- weight-gradient products of the DyNCA backward (cell axis as K) -------------------------------------------------

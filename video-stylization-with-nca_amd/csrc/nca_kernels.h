@@ -63,6 +63,8 @@ struct NcaDyncaArgs {
     float* gw2_ws;         // backward, fused dW2: per-workgroup partials [grid][C*fc + C] (dW2 | db2); hbuf is then not written
     const float* g_extra;  // backward stencil: optional cotangent of x_t itself, added to g_out (forward_nsteps' middle features)
     const float* pc;       // two-scale perception (perception_scales = [0, 1]): coarse-level perception [B,4C,H/2,W/2], or null
+    const float* coarse_add;  // backward stencil, two-scale: dL/dx of the coarse level [B,C,H/2,W/2]; 0.25 * parent is added to g_out
+    int dy_half;              // backward stencil, two-scale: the fine level carries 0.5 * dL/dy
 };
 
 struct NcaCondArgs {
@@ -139,6 +141,9 @@ hipError_t nca_launch_dynca_perceive(const float* x, float* y, int B, int C, int
 hipError_t nca_launch_image_encoder_front(const float* img, const float* k3, const float* k5, float* feat, int B, int ch, int H, int W,
                                           hipStream_t st);
 hipError_t nca_launch_edge_extractor(const float* img, const float* k3, float* out, int B, int H, int W, int do_tanh, hipStream_t st);
+hipError_t nca_launch_dynca_ms_combine(float* y, const float* pc, int B, int C, int H, int W, hipStream_t st);   // y <- (y + up2(pc)) / 2
+hipError_t nca_launch_dynca_ms_upT(const float* dy, float* dpc, int B, int C, int H, int W, hipStream_t st);    // dpc = 0.5 * up2^T(dy)
+int nca_dynca_bwd_ms_grid(int B, int H, int W);
 hipError_t nca_launch_dynca_coarse_perceive(const float* x, float* pc, int B, int C, int H, int W, int pad, hipStream_t st);
 hipError_t nca_launch_cond_perceive(const float* z, const float* wp, float* y, int B, int C, int H, int W, hipStream_t st);
 hipError_t nca_launch_cond_finalize(const float* x, const uint8_t* pre, float* out, int B, int C, int H, int W,

@@ -128,6 +128,62 @@ __global__ __launch_bounds__(256) void dynca_coarse_perceive_kernel(const float*
     o[(size_t)3 * C * cp] = nca_laplacian(a);
 }
 
+// Two-scale perception, pieces of the backward pass (forward: dynca_coarse_perceive_kernel + the fused step).
+// bilinear x2 up-sampling weights of fine index y (align_corners = False, even sizes): rows (r0, r1) with lambdas (1 - l1, l1)
+__device__ __forceinline__ void nca_up2_taps(int y, int nc, int& r0, int& r1, float& l1) {
+    const int k = y >> 1;
+    if (y & 1) { r0 = k; r1 = min(k + 1, nc - 1); l1 = 0.25f; }
+    else { r0 = max(k - 1, 0); r1 = k; l1 = 0.75f; }
+}
+// y <- (y + up2(pc)) / 2 in place: the two-scale perception [B,4C,H,W] the layer-1 weight-gradient product needs (dynca.py:98-110)
+__global__ __launch_bounds__(256) void dynca_ms_combine_kernel(float* __restrict__ y, const float* __restrict__ pc, int B, int C4, int H, int W) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)B * C4 * H * W) return;
+    const int px = (int)(id % W), py = (int)((id / W) % H);
+    const size_t pl = id / ((size_t)H * W);
+    const int Hc = H >> 1, Wc = W >> 1;
+    int r0, r1, c0, c1;
+    float h1, w1;
+    nca_up2_taps(py, Hc, r0, r1, h1);
+    nca_up2_taps(px, Wc, c0, c1, w1);
+    const float* const q = pc + pl * (size_t)Hc * Wc;
+    const float h0 = 1.0f - h1, w0 = 1.0f - w1;
+    const float up = h0 * (w0 * q[(size_t)r0 * Wc + c0] + w1 * q[(size_t)r0 * Wc + c1]) + h1 * (w0 * q[(size_t)r1 * Wc + c0] + w1 * q[(size_t)r1 * Wc + c1]);
+    y[id] = (y[id] + up) / 2.0f;
+}
+// dpc = 0.5 * up2^T(dy): gradient of the coarse-level perception [B,4C,H/2,W/2] from dL/d(two-scale perception) [B,4C,H,W].
+// Gather form: coarse cell k receives from the fine cells 2k-1 .. 2k+2 of each axis whatever weight their taps put on k
+// (border clamping included, so the weights of a fine row always sum to 1 over the coarse rows).
+__global__ __launch_bounds__(256) void dynca_ms_upT_kernel(const float* __restrict__ dy, float* __restrict__ dpc, int B, int C4, int H, int W) {
+    const int Hc = H >> 1, Wc = W >> 1;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)B * C4 * Hc * Wc) return;
+    const int kx = (int)(id % Wc), ky = (int)((id / Wc) % Hc);
+    const size_t pl = id / ((size_t)Hc * Wc);
+    float wy[4], wx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = 2 * ky - 1 + i, x = 2 * kx - 1 + i;
+        int r0, r1;
+        float l1;
+        wy[i] = 0.0f;
+        wx[i] = 0.0f;
+        if (y >= 0 && y < H) { nca_up2_taps(y, Hc, r0, r1, l1); wy[i] = (r0 == ky ? 1.0f - l1 : 0.0f) + (r1 == ky ? l1 : 0.0f); }
+        if (x >= 0 && x < W) { nca_up2_taps(x, Wc, r0, r1, l1); wx[i] = (r0 == kx ? 1.0f - l1 : 0.0f) + (r1 == kx ? l1 : 0.0f); }
+    }
+    const float* const src = dy + pl * (size_t)H * W;
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = min(max(2 * ky - 1 + i, 0), H - 1);
+        float row = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) row = fmaf(wx[j], src[(size_t)y * W + min(max(2 * kx - 1 + j, 0), W - 1)], row);
+        acc = fmaf(wy[i], row, acc);
+    }
+    dpc[id] = 0.5f * acc;
+}
+
 // ---- conditioning front ends (the fixed-filter part of the encoders that feed the step) ----------------------------------
 // ImageEncoder (EncoderConditioning/encoder.py:37-52): gray = mean over channels; [sobel_x, sobel_y, laplacian](gray), 3x3, zero
 // pad; per-channel 5x5 blur, zero pad 2.  One pass: one thread = one pixel of one batch item, every output plane of it; the
@@ -341,6 +397,17 @@ hipError_t nca_launch_image_encoder_front(const float* img, const float* k3, con
 hipError_t nca_launch_edge_extractor(const float* img, const float* k3, float* out, int B, int H, int W, int do_tanh, hipStream_t st) {
     const size_t n = (size_t)B * H * W;
     hipLaunchKernelGGL(edge_extractor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, img, k3, out, B, H, W, do_tanh);
+    return hipGetLastError();
+}
+
+hipError_t nca_launch_dynca_ms_combine(float* y, const float* pc, int B, int C, int H, int W, hipStream_t st) {
+    const size_t n = (size_t)B * 4 * C * H * W;
+    hipLaunchKernelGGL(dynca_ms_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, pc, B, 4 * C, H, W);
+    return hipGetLastError();
+}
+hipError_t nca_launch_dynca_ms_upT(const float* dy, float* dpc, int B, int C, int H, int W, hipStream_t st) {
+    const size_t n = (size_t)B * 4 * C * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(dynca_ms_upT_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, dpc, B, 4 * C, H, W);
     return hipGetLastError();
 }
 

@@ -213,7 +213,7 @@ struct DyncaCfg {
 template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT, bool VEC, bool BWD = false, bool B16 = false, bool ACC = false, bool W2F = false,
           bool MS = false>
 __global__ __launch_bounds__(kThreads, ((BWD && CP > 16) || MS) ? 1 : 2) void dynca_step_fwd_kernel(const NcaDyncaArgs a) {
-    static_assert(!MS || (!BWD && !B16 && !ACC && TH % 2 == 0 && TW % 2 == 0), "the two-scale step is an fp32 forward kernel");
+    static_assert(!MS || (!B16 && !ACC && TH % 2 == 0 && TW % 2 == 0 && (!BWD || W2F)), "the two-scale step: fp32, one hidden slice");
     static_assert(!W2F || BWD, "fused dW2 is an option of the backward kernel");
     static_assert(!ACC || !B16, "accumulating passes (fc slices beyond the first) read fp32 partial results");
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kThreads, ((BWD && CP > 16) || MS) ? 1 : 2) void dy
             constexpr int NR = TH / 2 + 2, NC = TW / 2 + 2, PER_PLANE = NR * NC;
             const int Hc = H >> 1, Wc = W >> 1;
             const float* const pcb = a.pc + (size_t)b * 4 * C * Hc * Wc;
-            float* const PCL = smem + K::OFF_PC;
+            float* const PCL = smem + (BWD ? K::LDS_FLOATS_BWD_W2 : K::OFF_PC);
             for (int i = st; i < 4 * CP * PER_PLANE; i += kThreads) {
                 const int pl = i / PER_PLANE, rc = i - pl * PER_PLANE, r = rc / NC, c = rc - r * NC;
                 const int f = pl / CP, ch = pl - f * CP;
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(kThreads, ((BWD && CP > 16) || MS) ? 1 : 2) void dy
                         const int fr = r0[n], fq = q0[n];
                         const int kr = (fr >> 1) + ((fr & 1) ? 1 : 0), kq = (fq >> 1) + ((fq & 1) ? 1 : 0);   // first of the two coarse rows / cols (tile coordinates incl. halo)
                         const float h1 = (fr & 1) ? 0.25f : 0.75f, w1 = (fq & 1) ? 0.25f : 0.75f, h0 = 1.0f - h1, w0 = 1.0f - w1;
-                        const float* const pcp = smem + K::OFF_PC + (4 * cq4 + g) * K::PCS + kr * K::PCR + kq;
+                        const float* const pcp = smem + (BWD ? K::LDS_FLOATS_BWD_W2 : K::OFF_PC) + (4 * cq4 + g) * K::PCS + kr * K::PCR + kq;
 #pragma unroll
                         for (int f = 0; f < 4; ++f) {
                             const float* const q = pcp + f * CP * K::PCS;
@@ -1147,8 +1147,11 @@ __device__ float dynca_bwd_cell(const NcaDyncaArgs& a, int b, int c, int py, int
     const size_t plane = (size_t)H * W;
     const float* const dy = a.dybuf + (size_t)b * 4 * C * plane;
     const size_t off = (size_t)py * W + px;
-    float acc = a.g_next[((size_t)b * C + c) * plane + off] + dy[(size_t)c * plane + off];
-    if (a.g_extra) acc += a.g_extra[((size_t)b * C + c) * plane + off];   // cotangent of the intermediate state itself
+    float base = a.g_next ? a.g_next[((size_t)b * C + c) * plane + off] : 0.0f;
+    if (a.g_extra) base += a.g_extra[((size_t)b * C + c) * plane + off];   // cotangent of the intermediate state itself
+    if (a.coarse_add)   // two-scale perception: adjoint of the 2x2 mean, 0.25 * dL/dx_coarse of the cell's coarse parent
+        base += 0.25f * a.coarse_add[((size_t)b * C + c) * (size_t)(H >> 1) * (W >> 1) + (size_t)(py >> 1) * (W >> 1) + (px >> 1)];
+    float acc = dy[(size_t)c * plane + off];
     // per axis: for candidate offset iq in {-1,0,1} and tap t in {-1,0,1}: does pad(q + t) land on p ?
     int qy[3], qx[3];
     bool hy[3][3], hx[3][3];
@@ -1187,7 +1190,7 @@ __device__ float dynca_bwd_cell(const NcaDyncaArgs& a, int b, int c, int py, int
             acc = fmaf(wsy, dy[(size_t)(2 * C + c) * plane + qo], acc);
             acc = fmaf(wl, dy[(size_t)(3 * C + c) * plane + qo], acc);
         }
-    return acc;
+    return base + (a.dy_half ? 0.5f * acc : acc);   // two-scale perception: the fine level carries half of dL/dy
 }
 
 // any shape: one thread per cell
@@ -1216,12 +1219,19 @@ __global__ __launch_bounds__(256) void dynca_step_bwd_stencil_vec_kernel(const N
     // border band of two cells: with 'reflect' a border cell's out-of-range taps land one cell INSIDE the image
     if (py < 2 || py > H - 3 || x0 < 4 || x0 + 8 > W) return;   // the border band belongs to dynca_step_bwd_stencil_border_kernel
     const float* const dy = a.dybuf + (size_t)b * 4 * C * plane + (size_t)py * W + x0;
-    const float4 gv = *reinterpret_cast<const float4*>(a.g_next + ((size_t)b * C + c) * plane + (size_t)py * W + x0);
+    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.g_next) gv = *reinterpret_cast<const float4*>(a.g_next + ((size_t)b * C + c) * plane + (size_t)py * W + x0);
     const float4 d0 = *reinterpret_cast<const float4*>(dy + (size_t)c * plane);
-    float acc[4] = {gv.x + d0.x, gv.y + d0.y, gv.z + d0.z, gv.w + d0.w};
+    float base[4] = {gv.x, gv.y, gv.z, gv.w};
+    float acc[4] = {d0.x, d0.y, d0.z, d0.w};
     if (a.g_extra) {
         const float4 ge = *reinterpret_cast<const float4*>(a.g_extra + ((size_t)b * C + c) * plane + (size_t)py * W + x0);
-        acc[0] += ge.x; acc[1] += ge.y; acc[2] += ge.z; acc[3] += ge.w;
+        base[0] += ge.x; base[1] += ge.y; base[2] += ge.z; base[3] += ge.w;
+    }
+    if (a.coarse_add) {   // W % 4 == 0: the 4 cells have the coarse parents x0/2 and x0/2 + 1 (8-byte aligned pair)
+        const float2 cp = *reinterpret_cast<const float2*>(a.coarse_add + ((size_t)b * C + c) * (size_t)(H >> 1) * (W >> 1) +
+                                                           (size_t)(py >> 1) * (W >> 1) + (x0 >> 1));
+        base[0] += 0.25f * cp.x; base[1] += 0.25f * cp.x; base[2] += 0.25f * cp.y; base[3] += 0.25f * cp.y;
     }
     float v[3][3][6];   // [filter plane][row y-1..y+1][col x0-1..x0+4]
 #pragma unroll
@@ -1240,6 +1250,7 @@ __global__ __launch_bounds__(256) void dynca_step_bwd_stencil_vec_kernel(const N
         const float lp = (v[2][0][j] + v[2][0][j + 2] + v[2][2][j] + v[2][2][j + 2]) +
                          2.0f * (v[2][0][j + 1] + v[2][1][j] + v[2][1][j + 2] + v[2][2][j + 1]) - 12.0f * v[2][1][j + 1];
         acc[j] += sx + sy + lp;
+        acc[j] = base[j] + (a.dy_half ? 0.5f * acc[j] : acc[j]);
     }
     *reinterpret_cast<float4*>(out) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
@@ -1349,10 +1360,39 @@ int nca_dynca_bwd_grid_c(int B, int C, int H, int W) {
 }
 int nca_dynca_bwd_grid(int B, int H, int W) { return nca_dynca_bwd_grid_c(B, 16, H, W); }   // upper bound (slab workspace sizing)
 
+// two-scale perception in the backward: the same recomputation as the forward's (coarse tile in LDS); one workgroup per CU
+template <int CP, int FC, bool HAS_COND>
+hipError_t launch_dynca_bwd_ms(const NcaDyncaArgs& a, hipStream_t st) {
+    constexpr int TH = 8, TW = 32, NT = 2;
+    using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
+    constexpr int LDSF = K::LDS_FLOATS_BWD_W2 + 4 * CP * K::PCS;
+    static_assert(LDSF * 4 <= 160 * 1024, "LDS budget (two-scale backward)");
+    if (!a.gw2_ws) return hipErrorInvalidValue;
+    const bool vec = (a.W % 4 == 0) && aligned16(a.x_in);
+    const size_t lds = (size_t)LDSF * sizeof(float);
+    const int ntiles = a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+    const int grid = grid_for(ntiles, 1);
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = set_lds(kern, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, a);
+        return hipGetLastError();
+    };
+    return vec ? go(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, true, true, false, false, true, true>)
+               : go(dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, false, true, false, false, true, true>);
+}
+int nca_dynca_bwd_ms_grid(int B, int H, int W) { return grid_for(B * ((W + 31) / 32) * ((H + 7) / 8), 1); }
+
 // The MLP part of one backward step (writes dh, dL/dy and, with gw2_ws, the per-workgroup dW2 | db2 partials).  acc: a later
 // 128-wide slice of a wide hidden layer -- dL/dy is added to what the earlier slices wrote.
 hipError_t nca_launch_dynca_step_bwd_mlp(const NcaDyncaArgs& a, hipStream_t st, bool acc) {
     const bool hc = a.c_cond > 0;
+    if (a.pc) {   // two-scale perception (C <= 16, fc <= 128, even sizes: checked by the C ABI)
+        if (acc || ((a.H | a.W) & 1)) return hipErrorInvalidValue;
+        if (a.C <= 12 && a.fc <= 96) return hc ? launch_dynca_bwd_ms<12, 96, true>(a, st) : launch_dynca_bwd_ms<12, 96, false>(a, st);
+        if (a.C <= 16 && a.fc <= 128) return hc ? launch_dynca_bwd_ms<16, 128, true>(a, st) : launch_dynca_bwd_ms<16, 128, false>(a, st);
+        return hipErrorInvalidValue;
+    }
     if (!acc) {
         if (a.C <= 12 && a.fc <= 96) return hc ? launch_dynca_bwd<12, 96, true, false>(a, st) : launch_dynca_bwd<12, 96, false, false>(a, st);
         if (a.C <= 16 && a.fc <= 128) return hc ? launch_dynca_bwd<16, 128, true, false>(a, st) : launch_dynca_bwd<16, 128, false, false>(a, st);
@@ -1367,8 +1407,9 @@ hipError_t nca_launch_dynca_step_bwd_mlp(const NcaDyncaArgs& a, hipStream_t st, 
 // The stencil-adjoint part: g_out = g_next (+ g_extra) + adj(perception)(dybuf).
 hipError_t nca_launch_dynca_step_bwd_stencil(const NcaDyncaArgs& a, hipStream_t st) {
     const size_t n = (size_t)a.B * a.C * a.H * a.W;
-    const bool vec = (a.W % 4 == 0) && a.W >= 12 && a.H >= 3 && aligned16(a.g_next) && aligned16(a.g_out) && aligned16(a.dybuf) &&
-                     (a.g_extra == nullptr || aligned16(a.g_extra));
+    const bool vec = (a.W % 4 == 0) && a.W >= 12 && a.H >= 3 && (a.g_next == nullptr || aligned16(a.g_next)) && aligned16(a.g_out) &&
+                     aligned16(a.dybuf) && (a.g_extra == nullptr || aligned16(a.g_extra)) &&
+                     (a.coarse_add == nullptr || (((uintptr_t)a.coarse_add & 7u) == 0 && a.H % 2 == 0));
     if (vec && a.H >= 5) {
         hipLaunchKernelGGL(dynca_step_bwd_stencil_vec_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, a);
         const size_t nb = (size_t)a.B * a.C * (4 * a.W + 8 * (a.H - 4));

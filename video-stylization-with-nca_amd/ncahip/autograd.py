@@ -111,7 +111,7 @@ class _DyncaNSteps(torch.autograd.Function):
     def forward(ctx, x, cond, w1, b1, w2, b2, cfg):
         w = ops.DyncaWeights(w1, b1, w2, b2, x)
         out, states = ops.dynca_nsteps(x, cfg["T"], cond, cfg["us"], w, cfg["pad"], cfg["rate"], cfg["seed"],
-                                       cfg["step0"], keep_history=True)
+                                       cfg["step0"], keep_history=True, two_scale=cfg.get("two_scale", False))
         ctx.cfg, ctx.w = cfg, w
         ctx.save_for_backward(states, cond if cond is not None else x.new_empty(0))
         return out.clone(), states if cfg["want_states"] else None
@@ -124,11 +124,12 @@ class _DyncaNSteps(torch.autograd.Function):
         if g_states is not None:                       # cotangents of intermediate states (return_middle_feature)
             gfin = gfin + g_states[cfg["T"]]
         g = ops.dynca_nsteps_backward(states, cond if cond.numel() else None, cfg["us"], ctx.w, gfin,
-                                      g_states, cfg["T"], cfg["pad"], cfg["rate"], cfg["seed"], cfg["step0"])
+                                      g_states, cfg["T"], cfg["pad"], cfg["rate"], cfg["seed"], cfg["step0"],
+                                      two_scale=cfg.get("two_scale", False))
         return g["x0"], None, g["w1"][:, :, None, None], g["b1"], g["w2"][:, :, None, None], g["b2"], None  # no grad to cond (dynca.py:123)
 
 
-def dynca_nsteps_autograd(model, x, cond, T, update_rate, want_states=False):
+def dynca_nsteps_autograd(model, x, cond, T, update_rate, want_states=False, two_scale=False):
     bf16 = x.dtype == torch.bfloat16      # bf16 pool: bf16-storage entry points, inference only
     x = x.contiguous() if bf16 else x.float().contiguous()
     params = (model.w1.weight, model.w1.bias, model.w2.weight, model.w2.bias)
@@ -137,13 +138,13 @@ def dynca_nsteps_autograd(model, x, cond, T, update_rate, want_states=False):
                                   "them under torch.no_grad()")
     us = model._draw(x, T)
     cfg = dict(T=T, us=us, pad=model.padding_mode, rate=float(update_rate), seed=model.mask_seed, step0=model._mask_step,
-               want_states=want_states)
+               want_states=want_states, two_scale=two_scale)
     model._mask_step += T
     if _needs_grad(x, *params):
         return _DyncaNSteps.apply(x, cond, *params, cfg)
     w = ops.DyncaWeights(*params, x)
     out, states = ops.dynca_nsteps(x, T, cond, us, w, cfg["pad"], cfg["rate"], cfg["seed"], cfg["step0"],
-                                   keep_history=want_states)
+                                   keep_history=want_states, two_scale=two_scale)
     return out, (states if want_states else None)
 
 

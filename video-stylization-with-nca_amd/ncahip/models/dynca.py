@@ -120,15 +120,14 @@ class DyNCA(nn.Module):
         return list(self.perception_scales) != [0]
 
     def _two_scale_fused(self, x) -> bool:
-        """perception_scales == [0, 1] (every shipped video model) on the fused two-scale kernels: forward passes (inference /
-        video synthesis) at even sizes, C <= 16, fc <= 128, fp32 states."""
-        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        return (list(self.perception_scales) == [0, 1] and not needs_grad and x.dtype == torch.float32
+        """perception_scales == [0, 1] (every shipped video model; the default of fit_video_motion.py) on the fused two-scale
+        kernels, forward and backward: even sizes, C <= 16, fc <= 128, fp32 states."""
+        return (list(self.perception_scales) == [0, 1] and x.dtype == torch.float32
                 and ops.two_scale_fused_ok(self.c_in, x.shape[2], x.shape[3], self.w1.out_channels))
 
     def _composed(self, x) -> bool:
         """True when the step runs as HIP stencil + device resampling + library GEMMs instead of the fused kernels:
-        multi-scale perception outside what _two_scale_fused covers (training through it, other scale sets, odd sizes).
+        multi-scale perception outside what _two_scale_fused covers (other scale sets, odd sizes, C > 16, fc > 128).
         Single-scale forward and backward are fused for every C <= 32 and fc <= 1024 (BASELINE configs[4] trains at C = 32,
         fc = 256: hidden layers wider than 128 run as one launch per 128-wide slice)."""
         return self._multiscale() and not self._two_scale_fused(x)
@@ -173,7 +172,7 @@ class DyNCA(nn.Module):
         if self._composed(x):
             out = self._step_multiscale(x.float(), cond, update_rate, self._draw_one(x))
         elif self._multiscale():
-            out = self._nsteps_two_scale(x, cond, 1, update_rate)[0]
+            out, _ = dynca_nsteps_autograd(self, x, cond, 1, update_rate, two_scale=True)
         else:
             out, _ = dynca_nsteps_autograd(self, x, cond, 1, update_rate)
         if return_perception:
@@ -199,22 +198,8 @@ class DyNCA(nn.Module):
         sd = torch.rand(1, c, size_y, size_x) - 0.5
         return sd.repeat(n, 1, 1, 1).to(self.device)
 
-    def _nsteps_two_scale(self, x, cond, step_n, update_rate, want_states=False):
-        """step_n fused two-scale steps (no autograd: _two_scale_fused checked that none is needed)."""
-        w = ops.DyncaWeights(self.w1.weight, self.w1.bias, self.w2.weight, self.w2.bias, x)
-        us = self._draw(x, step_n)
-        out, states = ops.dynca_nsteps(x.contiguous(), step_n, cond, us, w, self.padding_mode, float(update_rate), self.mask_seed,
-                                       self._mask_step, keep_history=want_states, two_scale=True)
-        self._mask_step += step_n
-        return out, states
-
     def forward_nsteps(self, input_state, step_n, update_rate=0.5, return_middle_feature=False, cond_img=None):
         cond = self._cond(input_state, cond_img)
-        if self._multiscale() and not self._composed(input_state):
-            out, states = self._nsteps_two_scale(input_state, cond, step_n, update_rate, want_states=return_middle_feature)
-            if return_middle_feature:
-                return out, self.to_rgb(out), [self.to_rgb(states[t]) for t in range(1, step_n + 1)]
-            return out, self.to_rgb(out)
         if self._composed(input_state):
             x, mids = input_state.float(), []
             for _ in range(step_n):
@@ -223,7 +208,7 @@ class DyNCA(nn.Module):
                     mids.append(self.to_rgb(x))
             return (x, self.to_rgb(x), mids) if return_middle_feature else (x, self.to_rgb(x))
         out, states = dynca_nsteps_autograd(self, input_state, cond, step_n, update_rate,
-                                            want_states=return_middle_feature)
+                                            want_states=return_middle_feature, two_scale=self._multiscale())
         feature = self.to_rgb(out)
         if return_middle_feature:
             return out, feature, [self.to_rgb(states[t]) for t in range(1, step_n + 1)]

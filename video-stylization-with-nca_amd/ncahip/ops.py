@@ -330,7 +330,7 @@ def _gram_fits(ma: int, nb: int) -> bool:
 
 def dynca_nsteps_backward(states: torch.Tensor, cond: Optional[torch.Tensor], us: Optional[torch.Tensor], w: DyncaWeights,
                           g_final: torch.Tensor, g_states: Optional[torch.Tensor], T: int, pad_mode: str = "replicate",
-                          update_rate: float = 0.5, seed: int = 0, step0: int = 0):
+                          update_rate: float = 0.5, seed: int = 0, step0: int = 0, two_scale: bool = False):
     """Backward of dynca_nsteps (states = the keep_history=True buffer [T+1,B,C,H,W]): ONE call into the C driver
     ncahip_dynca_nsteps_bwd_f32, which enqueues the whole T-step loop (perception, fused MLP-backward kernel per 128-wide
     slice of the hidden layer, weight-gradient products with the cell axis as K, stencil adjoint) on the current stream with
@@ -353,10 +353,11 @@ def dynca_nsteps_backward(states: torch.Tensor, cond: Optional[torch.Tensor], us
     out = {"x0": torch.empty(B, C, H, W, device=dev, dtype=f32), "w1": torch.empty(fc, k1, device=dev, dtype=f32),
            "b1": torch.empty(fc, device=dev, dtype=f32), "w2": torch.empty(C, fc, device=dev, dtype=f32),
            "b2": torch.empty(C, device=dev, dtype=f32)}
-    nbytes = lib().ncahip_dynca_nsteps_bwd_workspace(B, C, H, W, fc, c_cond)
+    sfx = "_ms" if two_scale else ""       # two_scale: backward through ncahip_dynca_nsteps_fwd_ms_f32's steps
+    nbytes = getattr(lib(), f"ncahip_dynca_nsteps_bwd{sfx}_workspace")(B, C, H, W, fc, c_cond)
     ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-    check(lib().ncahip_dynca_nsteps_bwd_f32(_p(states), T, _p(cond), _p(us), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C, H, W, fc,
+    check(getattr(lib(), f"ncahip_dynca_nsteps_bwd{sfx}_f32")(_p(states), T, _p(cond), _p(us), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C, H, W, fc,
                                             c_cond, PAD_MODES[pad_mode], update_rate, seed, step0, _p(g), _p(g_states), _p(out["x0"]),
                                             _p(out["w1"]), _p(out["b1"]), _p(out["w2"]), _p(out["b2"]), _p(ws), nbytes, _stream()),
-          "dynca_nsteps_bwd")
+          "dynca_nsteps_bwd" + sfx)
     return out
