@@ -7,6 +7,7 @@ HIP events on the launch stream).  `python tools/bench_paths.py [names...]`; wit
   dynca_fwd       DyNCA forward steps: C=16/fc=128, C=12/fc=96, C=32/fc=128 and C=32/fc=256 at 2x512^2 (configs[4])
   dynca_train     DyNCA forward with history + backward (the C driver): C=16/fc=128, C=12/fc=96, C=32/fc=256 at 2x512^2
   big             working sets beyond the 256 MiB Infinity Cache: perception stencil and fused fp32 step at B=64
+  video           B = 1 inference at 256^2 with the shipped video models' shapes, single- and two-scale
   loss            the default objective (VGG16 features + batched OT + content + overflow) at 32 x 3 x 256^2, fp32 / bf16 features
 """
 import json
@@ -154,6 +155,21 @@ def loss_leg():
         emit(path="cfg3_loss", features=name, B=32, ms_fwd_bwd=ms, min_ms=mn, objective="overflow + OT appearance (batched) + content, VGG16 random weights")
 
 
+def video_leg():
+    """B = 1 inference as the video loop issues it (utils/misc/video_utils.py:66-83: forward_nsteps(h, step_n, cond_img=frame) per
+    frame) with the shipped video models' shapes (C = 12 / fc = 96 and C = 16 / fc = 128, pos_emb, two-scale perception), 256^2."""
+    for C, fc in ((12, 96), (16, 128)):
+        for two in (False, True):
+            gen = torch.Generator().manual_seed(0)
+            w = dyn_weights(C, fc, 2, gen)
+            x = (torch.rand(1, C, 256, 256, generator=gen) - 0.5).to(DEV)
+            cond = (torch.rand(1, 2, 256, 256, generator=gen) * 2 - 1).to(DEV)
+            T = 32
+            (ms,), (mn,) = timed([lambda: ops.dynca_nsteps(x, T, cond, None, w, "circular", 0.5, seed=1, two_scale=two)], iters=20)
+            emit(path="video_B1", C=C, fc=fc, two_scale=two, HW=[256, 256], us_per_step=ms / T * 1e3, min_us_per_step=mn / T * 1e3,
+                 frames_per_s_at_32_steps=1e3 / ms)
+
+
 def main(names):
     allp = not names
     if allp or "cond_train" in names:
@@ -175,6 +191,8 @@ def main(names):
         big()
     if allp or "loss" in names:
         loss_leg()
+    if allp or "video" in names:
+        video_leg()
 
 
 if __name__ == "__main__":
