@@ -322,12 +322,17 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
                     if (l5 < 18) A1[(2 * k + hl) * RS + l5 + 3] = aok[k] ? ST::cv1(av[k]) : NCA_NEG_INF;
             }
             // z_t interior out (kernel B needs it for the perception-weight gradient)
+            // (BFM: the two scratch tensors kernel B streams, z_t and dL/dperception, are stored as bf16: half the bytes)
             float* const zo = ba.zbuf + (size_t)t.b * C * plane + off;
+            uint16_t* const zo16 = reinterpret_cast<uint16_t*>(ba.zbuf) + (size_t)t.b * C * plane + off;
 #pragma unroll
             for (int k = 0; k < CP / 4; ++k) {
                 const int ch = 4 * k + g;
                 const f32x4 zv = ld4(Z + ch * CS + (row + 1) * RS + 4 + 4 * ff);
-                if (ok && ch < C) st4(zo + (unsigned)ch * plane, zv);
+                if (ok && ch < C) {
+                    if constexpr (BFM) *reinterpret_cast<u32x2*>(zo16 + (unsigned)ch * plane) = u32x2{pk_bf16(zv[0], zv[1]), pk_bf16(zv[2], zv[3])};
+                    else st4(zo + (unsigned)ch * plane, zv);
+                }
             }
             wave_sync();
 #pragma unroll
@@ -778,11 +783,15 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
                 const int gy = ty0 + n0 + rr, gx = tx0 + 4 * ff;
                 const bool ok = gy < H && gx + 3 < W;
                 float* const po = ba.dP + (size_t)t.b * 3 * C * plane + (ok ? (unsigned)(gy * W + gx) : 0u);
+                uint16_t* const po16 = reinterpret_cast<uint16_t*>(ba.dP) + (size_t)t.b * 3 * C * plane + (ok ? (unsigned)(gy * W + gx) : 0u);
 #pragma unroll
                 for (int k = 0; k < 2 * K::MJ; ++k) {
                     const int j = 8 * k + jl;
                     const f32x4 v = ld4(TB + j * 36 + rr * 16 + 4 * ff);
-                    if (ok && j < K1) st4(po + (unsigned)j * plane, v);
+                    if (ok && j < K1) {
+                        if constexpr (BFM) *reinterpret_cast<u32x2*>(po16 + (unsigned)j * plane) = u32x2{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3])};
+                        else st4(po + (unsigned)j * plane, v);
+                    }
                 }
             }
             NCA_BPHASE(9);   // dP out
@@ -907,6 +916,21 @@ __device__ __forceinline__ RawRow issue_row6(const float* __restrict__ plane, in
     if (!has_r && x0 + 4 < W) r.er = row[x0 + 4];
     return r;
 }
+// bf16 scratch (the BFM backward): 8-byte group + 2-byte edges, widened on arrival (the widening touches the loaded value, so a
+// row issued two rows ahead pays no wait here either: the compiler places the wait at the first shift)
+__device__ __forceinline__ RawRow issue_row6(const uint16_t* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r) {
+    RawRow r;
+    r.in = y >= 0 && y < H;
+    const uint16_t* const row = plane + (size_t)(r.in ? y : 0) * W;
+    const u32x2 c = *reinterpret_cast<const u32x2*>(row + x0);
+    unsigned el = 0u, er = 0u;
+    if (!has_l && x0 > 0) el = row[x0 - 1];
+    if (!has_r && x0 + 4 < W) er = row[x0 + 4];
+    r.c = make_float4(__uint_as_float(c[0] << 16), __uint_as_float(c[0] & 0xffff0000u), __uint_as_float(c[1] << 16), __uint_as_float(c[1] & 0xffff0000u));
+    r.el = __uint_as_float(el << 16);
+    r.er = __uint_as_float(er << 16);
+    return r;
+}
 __device__ __forceinline__ Row6 finish_row6(const RawRow& q, bool has_l, bool has_r) {
     Row6 r;
     const float z = q.in ? 1.0f : 0.0f;   // rows outside the image read row 0 and are zeroed here
@@ -916,10 +940,13 @@ __device__ __forceinline__ Row6 finish_row6(const RawRow& q, bool has_l, bool ha
     r.v[0] = l * z; r.v[1] = q.c.x * z; r.v[2] = q.c.y * z; r.v[3] = q.c.z * z; r.v[4] = q.c.w * z; r.v[5] = rr * z;
     return r;
 }
-__device__ __forceinline__ Row6 load_row6(const float* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r) {
+template <typename ET>
+__device__ __forceinline__ Row6 load_row6(const ET* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r) {
     return finish_row6(issue_row6(plane, H, W, y, x0, has_l, has_r), has_l, has_r);
 }
 
+// ET = element type of the two scratch tensors kernel A wrote (z_t, dL/dperception): float, or uint16_t (bf16) behind the BFM kernel A
+template <typename ET>
 __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCondBwdArgs ba) {
     const NcaCondArgs& a = ba.f;
     const int C = a.C, H = a.H, W = a.W;
@@ -936,8 +963,8 @@ __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCon
     float wl[27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) wl[i] = a.wp[(size_t)c * 27 + i];
-    const float* const zb = ba.zbuf + ((size_t)b * C + c) * plane;
-    const float* const p0 = ba.dP + ((size_t)b * 3 * C + 3 * c) * plane;
+    const ET* const zb = reinterpret_cast<const ET*>(ba.zbuf) + ((size_t)b * C + c) * plane;
+    const ET* const p0 = reinterpret_cast<const ET*>(ba.dP) + ((size_t)b * 3 * C + 3 * c) * plane;
     float wsum[27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) wsum[i] = 0.f;
@@ -1081,7 +1108,8 @@ hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
 #endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cond_step_bwd_stencil_kernel, dim3(ba.nblk), dim3(256), 0, st, ba);
+    if (BFM) hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<uint16_t>, dim3(ba.nblk), dim3(256), 0, st, ba);
+    else hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<float>, dim3(ba.nblk), dim3(256), 0, st, ba);
     return hipGetLastError();
 }
 
