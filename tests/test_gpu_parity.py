@@ -714,8 +714,9 @@ def test_dynca_backward_shape_fuzz(ops):
     stencil adjoint all see odd sizes here."""
     rng = np.random.RandomState(int(os.environ.get("NCAHIP_FUZZ_SEED", "888")))
     pads = ["replicate", "circular", "reflect", "constant"]
-    for case in range(int(os.environ.get("NCAHIP_FUZZ_CASES", "8"))):
-        C, fc = [(12, 96), (16, 128), (8, 64), (16, 96), (5, 40)][int(rng.randint(0, 5))]
+    for case in range(int(os.environ.get("NCAHIP_FUZZ_CASES", "14"))):
+        # (round 2: C up to 32 and hidden layers beyond 128 -- 128-wide slices -- through the C driver as well)
+        C, fc = [(12, 96), (16, 128), (8, 64), (16, 96), (5, 40), (32, 256), (20, 100), (24, 192), (16, 320), (32, 128)][int(rng.randint(0, 10))]
         cc = int(rng.choice([0, 2, 3]))
         B = int(rng.randint(1, 3)); H = int(rng.randint(2, 30)); W = int(rng.randint(2, 45))
         if rng.rand() < 0.5:

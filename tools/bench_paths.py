@@ -140,10 +140,10 @@ def loss_leg():
     from ncahip.loss import Loss
     dev = torch.device(DEV)
     style = (np.random.RandomState(0).rand(256, 256, 3) * 255).astype(np.uint8)
-    for name, dt in (("float32", torch.float32), ("bfloat16", torch.bfloat16)):
+    for name, dt, cl in (("float32", torch.float32, False), ("bfloat16", torch.bfloat16, False), ("bfloat16 NHWC", torch.bfloat16, True)):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            L = Loss(dev, target_style_image=style, feature_dtype=dt)
+            L = Loss(dev, target_style_image=style, feature_dtype=dt, channels_last=cl)
         gen = torch.rand(32, 3, 256, 256, device=dev, requires_grad=True)
         d = {"generated_images": gen, "nca_state": torch.rand(32, 16, 256, 256, device=dev) * 3 - 1.5,
              "target_images": torch.rand(32, 3, 256, 256, device=dev)}

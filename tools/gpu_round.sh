@@ -42,3 +42,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/${tag}_trainprof -o s
 stats $out/${tag}_trainprof $out/${tag}_train_kernel_stats.txt 10
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/${tag}_dyprof -o stats --output-format csv -- python tools/bench_paths.py dynca_train > $out/${tag}_dyprof.log 2>&1 || { tail -20 $out/${tag}_dyprof.log; exit 1; }
 stats $out/${tag}_dyprof $out/${tag}_dynca_train_kernel_stats.txt 14
+if [ -f video-stylization-with-nca_amd/libncahip_stamps.so ]; then   # diagnostic build (make stamps): cycles per phase of backward kernel A
+  timeout -k 10 200 python tools/stamp_bwd.py > $out/${tag}_bwd_phases.txt 2>&1 || { tail -20 $out/${tag}_bwd_phases.txt; exit 1; }
+  timeout -k 10 200 python tools/stamp_bwd.py bf16 > $out/${tag}_bwd_phases_bf16.txt 2>&1 || { tail -20 $out/${tag}_bwd_phases_bf16.txt; exit 1; }
+  cat $out/${tag}_bwd_phases_bf16.txt
+fi

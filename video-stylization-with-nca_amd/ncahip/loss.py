@@ -60,6 +60,8 @@ class VGG16Features(nn.Module):
         x = (x - self.mean) / self.std
         dt = self.features[0].weight.dtype          # bf16 when the module was cast (.to(torch.bfloat16)): convs on bf16 MFMA
         x = x.to(dt)
+        if self.features[0].weight.is_contiguous(memory_format=torch.channels_last) and not self.features[0].weight.is_contiguous():
+            x = x.contiguous(memory_format=torch.channels_last)     # NHWC convolutions (Loss(channels_last=True))
         out, last = {}, max(layers)
         for i, m in enumerate(self.features):
             x = m(x)
@@ -178,7 +180,7 @@ def ot_loss_batched(target_feats, gen_feats, n_samples=1000):
 
 class Loss(nn.Module):
     def __init__(self, device, content_loss_weight=1.0, overflow_loss_weight=1.0, appearance_loss_weight=1.0,
-                 appearance_loss_type="OT", target_style_image=None, feature_dtype=torch.float32):
+                 appearance_loss_type="OT", target_style_image=None, feature_dtype=torch.float32, channels_last=False):
         super().__init__()
         self.device = device
         self.appearance_loss_type = appearance_loss_type
@@ -198,6 +200,8 @@ class Loss(nn.Module):
         self.vgg = VGG16Features().to(device) if (appearance_loss_weight != 0 or content_loss_weight != 0) else None
         if self.vgg is not None and feature_dtype != torch.float32:
             self.vgg.features.to(feature_dtype)
+        if self.vgg is not None and channels_last:
+            self.vgg.features.to(memory_format=torch.channels_last)
         if appearance_loss_weight != 0:
             self.target_style_tensor = _to_nchw(target_style_image).to(device)
             with torch.no_grad():
