@@ -8,12 +8,14 @@
 // operands stream through LDS once, coalesced along the cell axis, and every wave keeps its share of the out tiles in
 // accumulator registers for the whole launch (per-workgroup partials, summed in fixed order afterwards: deterministic).
 // The B rows may come from two tensors (the perception [B,4C,HW] and the conditioning map [B,c_cond,HW]): no concatenation.
+#include <cstdlib>
+
 #include "nca_common.h"
 #include "nca_kernels.h"
 
 namespace {
 
-constexpr int kGramThreads = 256, kGramChunk = 64, kGramLS = 68;   // 64 cells per chunk; LDS row stride 68 (68 % 32 == 4)
+constexpr int kGramThreads = 256, kGramChunk = 64, kGramLS = 66;   // 64 cells per chunk; LDS row stride 66: operand reads A[row ci][k = g] hit bank (2 ci + g) % 32 -- conflict-free per 32-lane half (68 was 2-way)
 
 struct GramArgs {
     const float* a;    // [B, ma, HW]
@@ -35,9 +37,8 @@ __global__ __launch_bounds__(kGramThreads, 2) void gram_rows_kernel(const GramAr
     const int nb = a.nb1 + a.nb2, HW = a.HW;
     const int cpb = (HW + kGramChunk - 1) / kGramChunk, total = a.B * cpb;
 
-    // Row sums of A (the bias gradient): as ONE MORE B COLUMN of ones when the column tiles have room for it (nb < 16 * NB_T:
-    // the dW1-like shapes) -- it then rides on the MFMAs; a vector add inside an exact-f32 MFMA stream drains the matrix pipe
-    // (~25 cycles each), and there were 2 per k-step.  Full column tiles (dW2-like, nb = 128) keep the adds.
+    // Row sums of A (the bias gradient): either vector adds beside the MFMAs, or ONE MORE B COLUMN of ones riding on the MFMAs
+    // (needs nb < 16 * NB_T).  Which is faster depends on the shape (see launch_gram).
     constexpr bool ones_col = ONES;      // the launcher picks ONES = (nb < 16 * NB_T)
     f32x4 acc[RT][CT];
     float rs[RT];
@@ -169,7 +170,11 @@ hipError_t launch_gram_o(const GramArgs& a, int grid, hipStream_t st) {
 template <int RT, int CT, bool ROWSPLIT>
 hipError_t launch_gram(const GramArgs& a, int grid, hipStream_t st) {
     constexpr int NB_T = ROWSPLIT ? CT : 4 * CT;
-    return (a.nb1 + a.nb2 < 16 * NB_T) ? launch_gram_o<RT, CT, ROWSPLIT, true>(a, grid, st) : launch_gram_o<RT, CT, ROWSPLIT, false>(a, grid, st);
+    // Measured in one process, interleaved (tools/ab_gram.py): the ones column wins at 9 column tiles (ma = 128, nb = 131: 270 -> 230 us)
+    // and loses at 5 (nb = 67: 142 -> 150 us; nb = 51: 125 -> 134 us), so it is the default only for the wide shape.
+    const char* const e = getenv("NCAHIP_GRAM_ONES");      // A/B hook: 0 / 1 force a form
+    const bool want = e ? e[0] == '1' : CT >= 9;
+    return (want && a.nb1 + a.nb2 < 16 * NB_T) ? launch_gram_o<RT, CT, ROWSPLIT, true>(a, grid, st) : launch_gram_o<RT, CT, ROWSPLIT, false>(a, grid, st);
 }
 
 }  // namespace
