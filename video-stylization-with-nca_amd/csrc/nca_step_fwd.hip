@@ -58,6 +58,29 @@ __device__ __forceinline__ void fill_image(float* __restrict__ dst, const float*
     }
 }
 
+// Two-phase form of the same gather: fill_issue requests EVERY element of an image (one register each), fill_commit writes
+// them to LDS.  Issuing all images before committing any makes the workgroup's cold start ONE memory round trip instead of one
+// per batch of 8 (at B = 1 -- the video loop -- a launch is one tile per workgroup and the prologue is most of it).
+template <int N>
+struct FillV { float v[(N + kThreads - 1) / kThreads]; };
+template <int N, typename MapT>
+__device__ __forceinline__ void fill_issue(FillV<N>& r, const float* __restrict__ src, int tid, MapT map) {
+#pragma unroll
+    for (int u = 0; u < (N + kThreads - 1) / kThreads; ++u) {
+        const int idx = tid + kThreads * u;
+        const long o = idx < N ? map(idx) : -1;
+        r.v[u] = src[o >= 0 ? o : 0];
+    }
+}
+template <int N, typename MapT>
+__device__ __forceinline__ void fill_commit(const FillV<N>& r, float* __restrict__ dst, int tid, MapT map) {
+#pragma unroll
+    for (int u = 0; u < (N + kThreads - 1) / kThreads; ++u) {
+        const int idx = tid + kThreads * u;
+        if (idx < N) dst[idx] = map(idx) >= 0 ? r.v[u] : 0.0f;
+    }
+}
+
 // ---- halo-1 tile staging -------------------------------------------------------------------
 // LDS tile Z[ch][r][zq]: r = 0..TH+1 (image row ty0-1+r), zq = q+3 where q = 0..TW+1 is the halo-1
 // column (image col tx0-1+q), so the interior starts 16-byte aligned at zq = 4.  Row stride TW+8.
@@ -232,7 +255,7 @@ __global__ __launch_bounds__(kThreads, ((BWD && CP > 16) || MS) ? 1 : 2) void dy
     const int K1 = 4 * C + CC;
 
     // ---- A-operand weight images, once per workgroup -------------------------------------
-    fill_image<K::M1T * K::K1S * 64>(W1L, a.w1, tid, [&](int idx) -> long {
+    auto map_w1 = [&](int idx) -> long {
         const int l = idx & 63, s = (idx >> 6) % K::K1S, m = (idx >> 6) / K::K1S;
         const int gg = l >> 4, o = 16 * m + (l & 15);
         if (o >= fc) return -1;
@@ -241,15 +264,29 @@ __global__ __launch_bounds__(kThreads, ((BWD && CP > 16) || MS) ? 1 : 2) void dy
             return ch < C ? (long)o * K1 + (s & 3) * C + ch : -1;  // blocked [x|Sx|Sy|L], dynca.py:92-95
         }
         return gg < CC ? (long)o * K1 + 4 * C + gg : -1;  // conditioning k-step
-    });
-    fill_image<K::M2T * K::K2S * 64>(W2L, a.w2, tid, [&](int idx) -> long {
+    };
+    auto map_w2 = [&](int idx) -> long {
         const int l = idx & 63, s = (idx >> 6) % K::K2S, m = (idx >> 6) / K::K2S;
         const int gg = l >> 4, o = 16 * m + (l & 15);
         const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
         return (o < C && k < fc) ? (long)o * (a.w2_ld ? a.w2_ld : fc) + k : -1;
-    });
-    fill_image<FC>(B1L, a.b1, tid, [&](int idx) -> long { return idx < fc ? idx : -1; });
-    fill_image<K::M2T * 16>(B2L, a.b2, tid, [&](int idx) -> long { return (idx < C && !ACC) ? idx : -1; });
+    };
+    auto map_b1 = [&](int idx) -> long { return idx < fc ? idx : -1; };
+    auto map_b2 = [&](int idx) -> long { return (idx < C && !ACC) ? idx : -1; };
+    {
+        FillV<K::M1T * K::K1S * 64> f1;
+        FillV<K::M2T * K::K2S * 64> f2;
+        FillV<FC> f3;
+        FillV<K::M2T * 16> f4;
+        fill_issue(f1, a.w1, tid, map_w1);
+        fill_issue(f2, a.w2, tid, map_w2);
+        fill_issue(f3, a.b1, tid, map_b1);
+        fill_issue(f4, a.b2, tid, map_b2);
+        fill_commit(f1, W1L, tid, map_w1);
+        fill_commit(f2, W2L, tid, map_w2);
+        fill_commit(f3, B1L, tid, map_b1);
+        fill_commit(f4, B2L, tid, map_b2);
+    }
     // Transposed operands of the backward, read from the forward images with ONE 16-byte LDS read each (the 64 lanes of a read
     // cover 1 KiB contiguously: conflict-free):
     //   W2^T, k-steps s = 0..3 of (m, m2):  W2[ch = 16 m2 + 4g + s][h = 16 m + ci]  = W2L[(m2*K2S + 4m + (ci&3))*64 + (ci>>2)*16 + 4g + s]
