@@ -93,6 +93,23 @@ def test_argument_validation_without_gpu():
     rc = L.ncahip_dynca_step_bwd_f32(one, None, None, one, one, one, one, 1, 16, 8, 8, 256, 0, 1, 0.5, 0, 0,
                                      one, two, one, one, one, None)
     assert rc == -2
+    # two-scale entry points: odd sizes and C > 16 are refused (the Python layer then composes)
+    rc = L.ncahip_dynca_step_fwd_ms_f32(one, two, None, None, one, one, one, one, 1, 12, 9, 8, 96, 0, 1, 0.5, 0, 0, one, None)
+    assert rc == -2 and b"even" in L.ncahip_last_error()
+    rc = L.ncahip_dynca_step_fwd_ms_f32(one, two, None, None, one, one, one, one, 1, 24, 8, 8, 96, 0, 1, 0.5, 0, 0, one, None)
+    assert rc == -2
+    need = L.ncahip_dynca_nsteps_bwd_ms_workspace(1, 12, 8, 8, 96, 2)
+    rc = L.ncahip_dynca_nsteps_bwd_ms_f32(one, 1, two, None, one, one, one, one, 1, 12, 8, 7, 96, 2, 1, 0.5, 0, 0, one, None,
+                                          two, one, one, one, one, ctypes.c_void_p(0x4000), need, None)
+    assert rc == -2
+    # bf16-history backward: 8-byte aligned states / goal, W % 4
+    rc = L.ncahip_cond_grow_bwd_bf16(ctypes.c_void_p(0x1004), one, 1, None, 0, None, one, one, one, one, one, one, 1, 16, 8, 8, 64, 3, 0.1,
+                                     0.5, -10.0, 10.0, 0, 0, two, ctypes.c_void_p(0x3000), None, one, one, one, one, one, one,
+                                     ctypes.c_void_p(0x4000), 1 << 30, None)
+    assert rc == -2 and b"aligned" in L.ncahip_last_error()
+    # conditioning front ends
+    assert L.ncahip_image_encoder_front_f32(one, one, one, two, 1, 9, 8, 8, None) == -2
+    assert L.ncahip_edge_extractor_f32(one, one, one, 1, 8, 8, 1, None) == -1      # aliased in/out
     # error-word entry points exist and fail soft without a device (no GPU in the build container: nothing to map)
     assert L.ncahip_debug_inject_error(1) in (0, -1)
     assert isinstance(L.ncahip_check_errors(None, 1), int)
