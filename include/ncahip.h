@@ -201,6 +201,18 @@ int ncahip_dynca_nsteps_bwd_f32(const float *states, int T, const float *cond, c
                                 float *g_x0, float *g_w1, float *g_b1, float *g_w2, float *g_b2,
                                 void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
 
+/* The same backward over a bf16 history (the [T+1 slots] ncahip_dynca_nsteps_fwd_bf16 kept with ring = T+1): storage format only, as in
+ * the forward -- x_t is widened exactly into scratch and the step's backward runs in fp32; every gradient is fp32.
+ * B*C*H*W % 4 == 0, states 8-byte aligned; fc <= 128 (the bf16 forward's limit).                                           */
+size_t ncahip_dynca_nsteps_bwd_bf16_workspace(int B, int C, int H, int W, int fc, int c_cond);
+int ncahip_dynca_nsteps_bwd_bf16(const uint16_t *states, int T, const float *cond, const float *u,
+                                 const float *w1, const float *b1, const float *w2, const float *b2,
+                                 int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                                 float update_rate, uint64_t seed, uint64_t step0,
+                                 const float *g_final, const float *g_states,
+                                 float *g_x0, float *g_w1, float *g_b1, float *g_w2, float *g_b2,
+                                 void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
+
 /* The same backward through the TWO-SCALE steps of ncahip_dynca_nsteps_fwd_ms_f32 (training with perception_scales = [0, 1]:
  * ExtraChannels/fit_video_motion.py:129-130 defaults to it).  dL/dy splits evenly over the two levels: the fine level goes
  * through the stencil adjoint as before; the coarse level through the adjoint of the bilinear x2 up-sampling, the stencil

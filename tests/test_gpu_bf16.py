@@ -259,8 +259,39 @@ def test_dynca_module_bf16(ops):
         yf, _ = m.forward_nsteps(x.float(), 4, cond_img=img)
     assert yb.dtype == torch.bfloat16 and rgb.shape == (2, 3, 32, 32)
     assert float((yb.float() - yf).abs().mean()) < 1e-2
-    with pytest.raises(NotImplementedError):
-        m.forward_nsteps(x, 2, cond_img=img)
+    # autograd over the bf16 history (ncahip_dynca_nsteps_bwd_bf16): storage format only, so the gradients equal the fp32
+    # backward fed the widened history bit for bit, and match oracle autograd through straight-through bf16 stores
+    from oracle import nca_oracle as O2
+    prm = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if k.startswith(("w1", "w2"))}
+    us = torch.rand(3, 2, 1, 32, 32, device=DEV)
+    it = iter(us)
+    m._draw = lambda x_, steps: torch.stack([next(it) for _ in range(steps)])
+    xg = x.clone().requires_grad_(True)
+    cot = torch.randn(2, 12, 32, 32, device=DEV)
+    out, _ = m.forward_nsteps(xg, 3, cond_img=img)
+    assert out.dtype == torch.bfloat16
+    (out.float() * cot).sum().backward()
+    assert xg.grad.dtype == torch.bfloat16
+    w = ops.DyncaWeights(m.w1.weight, m.w1.bias, m.w2.weight, m.w2.bias, x)
+    cond = m._cond(x, img)
+    _, st16 = ops.dynca_nsteps(x, 3, cond, us, w, "circular", 0.5, keep_history=True)
+    g16 = ops.dynca_nsteps_backward(st16, cond, us, w, cot, None, 3, "circular", 0.5)
+    g32 = ops.dynca_nsteps_backward(st16.float(), cond, us, w, cot, None, 3, "circular", 0.5)
+    for k in g16:
+        assert torch.equal(g16[k], g32[k]), k
+    gmod = ops.dynca_nsteps_backward(st16, cond, us, w, cot.bfloat16().float(), None, 3, "circular", 0.5)   # autograd hands the bf16 output a bf16 cotangent
+    assert torch.equal(m.w1.weight.grad[:, :, 0, 0], gmod["w1"]) and torch.equal(m.w2.bias.grad, gmod["b2"])
+    # oracle: x <- bf16(x + dx * m) with a straight-through store
+    xr = x.float().cpu().clone().requires_grad_(True)
+    p = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+    cur, cnd = xr, cond.cpu()
+    for t in range(3):
+        nxt = O2.dynca_step(cur, cnd, us[t].cpu(), p, "circular", 0.5)
+        cur = nxt + (nxt.to(torch.bfloat16).float() - nxt).detach()
+    (cur * cot.cpu()).sum().backward()
+    rel2 = lambda a, b: float((a.double().cpu().reshape(-1) - b.double().reshape(-1)).norm() / b.double().norm().clamp_min(1e-12))
+    assert rel2(g16["x0"], xr.grad) < 1e-2 and rel2(g16["w1"], p["w1.weight"].grad[:, :, 0, 0]) < 1e-2
+    assert rel2(g16["w2"], p["w2.weight"].grad[:, :, 0, 0]) < 1e-2
 
 
 # ------------------------------------------------------------------------------------------------ opt-in bf16x3 products

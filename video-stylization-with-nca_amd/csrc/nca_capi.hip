@@ -444,10 +444,10 @@ int ncahip_dynca_step_bwd_w2_f32(const float* x_t, const float* cond, const floa
 namespace {
 struct DyncaBwdPlan {
     int nsl, fs;                 // hidden-layer slices of at most 128 units (fs = width of the full slices)
-    size_t n, off_g[2], off_y, off_dy, off_dh, off_ws2, off_wsg, off_acc1, off_acc2, off_pc, off_dpc, off_dxc, total;
+    size_t n, off_g[2], off_y, off_dy, off_dh, off_ws2, off_wsg, off_acc1, off_acc2, off_pc, off_dpc, off_dxc, off_x32, total;
     int grid2, gridg, K1;
 };
-DyncaBwdPlan dynca_bwd_plan(int B, int C, int H, int W, int fc, int c_cond, bool two_scale = false) {
+DyncaBwdPlan dynca_bwd_plan(int B, int C, int H, int W, int fc, int c_cond, bool two_scale = false, bool bf16 = false) {
     DyncaBwdPlan p{};
     p.nsl = (fc + 127) / 128;
     p.fs = fc < 128 ? fc : 128;
@@ -471,6 +471,7 @@ DyncaBwdPlan dynca_bwd_plan(int B, int C, int H, int W, int fc, int c_cond, bool
         p.off_dpc = take(p.n);
         p.off_dxc = take(p.n / 4);
     }
+    if (bf16) p.off_x32 = take(p.n);   // x_t widened to fp32
     p.total = o;
     return p;
 }
@@ -485,20 +486,24 @@ size_t ncahip_dynca_nsteps_bwd_ms_workspace(int B, int C, int H, int W, int fc, 
     return dynca_bwd_plan(B, C, H, W, fc, c_cond, true).total;
 }
 
-static int dynca_nsteps_bwd_impl(bool two_scale, const float* states, int T, const float* cond, const float* u, const float* w1, const float* b1,
+static int dynca_nsteps_bwd_impl(bool two_scale, const void* states_v, int sb, int T, const float* cond, const float* u, const float* w1, const float* b1,
                                 const float* w2, const float* b2, int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
                                 float update_rate, uint64_t seed, uint64_t step0, const float* g_final, const float* g_states,
                                 float* g_x0, float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* workspace,
                                 size_t workspace_bytes, ncahip_stream_t stream) {
+    const char* const states = (const char*)states_v;
+    const bool bf16 = sb == 2;
     if (T < 1 || !states || !g_final || !g_x0 || !g_w1 || !g_b1 || !g_w2 || !g_b2 || !workspace)
         return fail(NCAHIP_EINVAL, "dynca nsteps bwd: null pointer or T < 1");
     if (int rc = check_dynca(states, g_x0, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, kMaxFcFwd)) return rc;
+    if (bf16 && ((((size_t)B * C * H * W) & 3) != 0 || ((uintptr_t)states & 7) != 0))
+        return fail(NCAHIP_ERANGE, "dynca nsteps bwd (bf16): B*C*H*W %% 4 == 0 and 8-byte aligned states required");
     if ((size_t)(128 > 4 * C ? 128 : 4 * C) * H * W * sizeof(float) >= ((size_t)1 << 32))
         return fail(NCAHIP_ERANGE, "dynca nsteps bwd: 4C*H*W*4 must stay below 4 GiB (32-bit store offsets inside a batch item)");
     if (two_scale) {
         if (int rc = check_ms(C, H, W, fc, workspace)) return rc;
     }
-    const DyncaBwdPlan p = dynca_bwd_plan(B, C, H, W, fc, c_cond, two_scale);
+    const DyncaBwdPlan p = dynca_bwd_plan(B, C, H, W, fc, c_cond, two_scale, bf16);
     if (workspace_bytes < p.total) return fail(NCAHIP_EINVAL, "dynca nsteps bwd: workspace too small");
     if (((uintptr_t)workspace & 15) != 0) return fail(NCAHIP_ERANGE, "dynca nsteps bwd: workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -521,7 +526,12 @@ static int dynca_nsteps_bwd_impl(bool two_scale, const float* states, int T, con
     const size_t slot = p.n, uslot = (size_t)B * H * W;
     const float* gcur = g_final;
     for (int t = T - 1; t >= 0; --t) {
-        const float* const x_t = states + (size_t)t * slot;
+        const float* x_t = reinterpret_cast<const float*>(states + (size_t)t * slot * sb);
+        if (bf16) {   // bf16 history (storage format only: the DyNCA step computes in fp32 on the widened state)
+            float* const x32 = (float*)(ws + p.off_x32);
+            if (int rc = hip_result(nca_launch_widen_bf16(reinterpret_cast<const uint16_t*>(x_t), x32, slot, st), "dynca nsteps bwd widen")) return rc;
+            x_t = x32;
+        }
         float* const g_out = t == 0 ? g_x0 : gbuf[t & 1];
         if (int rc = hip_result(nca_launch_dynca_perceive(x_t, y, B, C, H, W, pad_mode, st), "dynca nsteps bwd perceive")) return rc;
         if (two_scale) {   // y <- two-scale perception of x_t (the B rows of the layer-1 weight-gradient product)
@@ -577,7 +587,7 @@ int ncahip_dynca_nsteps_bwd_f32(const float* states, int T, const float* cond, c
                                 float update_rate, uint64_t seed, uint64_t step0, const float* g_final, const float* g_states,
                                 float* g_x0, float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* workspace,
                                 size_t workspace_bytes, ncahip_stream_t stream) {
-    return dynca_nsteps_bwd_impl(false, states, T, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step0, g_final,
+    return dynca_nsteps_bwd_impl(false, states, 4, T, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step0, g_final,
                                  g_states, g_x0, g_w1, g_b1, g_w2, g_b2, workspace, workspace_bytes, stream);
 }
 int ncahip_dynca_nsteps_bwd_ms_f32(const float* states, int T, const float* cond, const float* u, const float* w1, const float* b1,
@@ -585,7 +595,20 @@ int ncahip_dynca_nsteps_bwd_ms_f32(const float* states, int T, const float* cond
                                    float update_rate, uint64_t seed, uint64_t step0, const float* g_final, const float* g_states,
                                    float* g_x0, float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* workspace,
                                    size_t workspace_bytes, ncahip_stream_t stream) {
-    return dynca_nsteps_bwd_impl(true, states, T, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step0, g_final,
+    return dynca_nsteps_bwd_impl(true, states, 4, T, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step0, g_final,
+                                 g_states, g_x0, g_w1, g_b1, g_w2, g_b2, workspace, workspace_bytes, stream);
+}
+
+size_t ncahip_dynca_nsteps_bwd_bf16_workspace(int B, int C, int H, int W, int fc, int c_cond) {
+    if (!dims_ok(B, C, H, W) || fc <= 0 || c_cond < 0) return 0;
+    return dynca_bwd_plan(B, C, H, W, fc, c_cond, false, true).total;
+}
+int ncahip_dynca_nsteps_bwd_bf16(const uint16_t* states, int T, const float* cond, const float* u, const float* w1, const float* b1,
+                                 const float* w2, const float* b2, int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                                 float update_rate, uint64_t seed, uint64_t step0, const float* g_final, const float* g_states,
+                                 float* g_x0, float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* workspace,
+                                 size_t workspace_bytes, ncahip_stream_t stream) {
+    return dynca_nsteps_bwd_impl(false, states, 2, T, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step0, g_final,
                                  g_states, g_x0, g_w1, g_b1, g_w2, g_b2, workspace, workspace_bytes, stream);
 }
 

@@ -141,6 +141,7 @@ hipError_t nca_launch_dynca_perceive(const float* x, float* y, int B, int C, int
 hipError_t nca_launch_image_encoder_front(const float* img, const float* k3, const float* k5, float* feat, int B, int ch, int H, int W,
                                           hipStream_t st);
 hipError_t nca_launch_edge_extractor(const float* img, const float* k3, float* out, int B, int H, int W, int do_tanh, hipStream_t st);
+hipError_t nca_launch_widen_bf16(const uint16_t* in, float* out, size_t n, hipStream_t st);
 hipError_t nca_launch_dynca_ms_combine(float* y, const float* pc, int B, int C, int H, int W, hipStream_t st);   // y <- (y + up2(pc)) / 2
 hipError_t nca_launch_dynca_ms_upT(const float* dy, float* dpc, int B, int C, int H, int W, hipStream_t st);    // dpc = 0.5 * up2^T(dy)
 int nca_dynca_bwd_ms_grid(int B, int H, int W);

@@ -128,6 +128,15 @@ __global__ __launch_bounds__(256) void dynca_coarse_perceive_kernel(const float*
     o[(size_t)3 * C * cp] = nca_laplacian(a);
 }
 
+// bf16 -> f32 (exact), 4 elements per thread: the DyNCA backward over a bf16 history widens x_t into scratch and then runs fp32
+__global__ __launch_bounds__(256) void widen_bf16_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, size_t n4) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n4) return;
+    const uint2 v = reinterpret_cast<const uint2*>(in)[id];
+    reinterpret_cast<float4*>(out)[id] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                                                     __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
+
 // Two-scale perception, pieces of the backward pass (forward: dynca_coarse_perceive_kernel + the fused step).
 // bilinear x2 up-sampling weights of fine index y (align_corners = False, even sizes): rows (r0, r1) with lambdas (1 - l1, l1)
 __device__ __forceinline__ void nca_up2_taps(int y, int nc, int& r0, int& r1, float& l1) {
@@ -400,6 +409,10 @@ hipError_t nca_launch_edge_extractor(const float* img, const float* k3, float* o
     return hipGetLastError();
 }
 
+hipError_t nca_launch_widen_bf16(const uint16_t* in, float* out, size_t n, hipStream_t st) {   // n % 4 == 0, 8-byte aligned input
+    hipLaunchKernelGGL(widen_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, in, out, n / 4);
+    return hipGetLastError();
+}
 hipError_t nca_launch_dynca_ms_combine(float* y, const float* pc, int B, int C, int H, int W, hipStream_t st) {
     const size_t n = (size_t)B * 4 * C * H * W;
     hipLaunchKernelGGL(dynca_ms_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, pc, B, 4 * C, H, W);

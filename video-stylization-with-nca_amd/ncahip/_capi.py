@@ -51,6 +51,9 @@ SIGNATURES = {
     "ncahip_dynca_nsteps_bwd_workspace": [_I, _I, _I, _I, _I, _I],
     "ncahip_dynca_nsteps_bwd_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P, _P, _P, _P, _P, _P, _P,
                                     _P, ctypes.c_size_t, _P],
+    "ncahip_dynca_nsteps_bwd_bf16_workspace": [_I, _I, _I, _I, _I, _I],
+    "ncahip_dynca_nsteps_bwd_bf16": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P, _P, _P, _P, _P, _P, _P,
+                                     _P, ctypes.c_size_t, _P],
     "ncahip_dynca_nsteps_bwd_ms_workspace": [_I, _I, _I, _I, _I, _I],
     "ncahip_dynca_nsteps_bwd_ms_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P, _P, _P, _P, _P, _P, _P,
                                        _P, ctypes.c_size_t, _P],
@@ -64,7 +67,8 @@ SIGNATURES = {
 }
 _RESTYPES = {"ncahip_last_error": c_char_p, "ncahip_cond_grow_bwd_workspace": ctypes.c_size_t,
              "ncahip_gram_rows_workspace": ctypes.c_size_t, "ncahip_dynca_step_bwd_w2_workspace": ctypes.c_size_t,
-             "ncahip_dynca_nsteps_bwd_workspace": ctypes.c_size_t, "ncahip_dynca_nsteps_bwd_ms_workspace": ctypes.c_size_t}
+             "ncahip_dynca_nsteps_bwd_workspace": ctypes.c_size_t, "ncahip_dynca_nsteps_bwd_ms_workspace": ctypes.c_size_t,
+             "ncahip_dynca_nsteps_bwd_bf16_workspace": ctypes.c_size_t}
 
 _lib = None
 

@@ -123,19 +123,16 @@ class _DyncaNSteps(torch.autograd.Function):
         gfin = g_out.contiguous()
         if g_states is not None:                       # cotangents of intermediate states (return_middle_feature)
             gfin = gfin + g_states[cfg["T"]]
-        g = ops.dynca_nsteps_backward(states, cond if cond.numel() else None, cfg["us"], ctx.w, gfin,
+        g = ops.dynca_nsteps_backward(states, cond if cond.numel() else None, cfg["us"], ctx.w, gfin.float(),
                                       g_states, cfg["T"], cfg["pad"], cfg["rate"], cfg["seed"], cfg["step0"],
                                       two_scale=cfg.get("two_scale", False))
-        return g["x0"], None, g["w1"][:, :, None, None], g["b1"], g["w2"][:, :, None, None], g["b2"], None  # no grad to cond (dynca.py:123)
+        return g["x0"].to(states.dtype), None, g["w1"][:, :, None, None], g["b1"], g["w2"][:, :, None, None], g["b2"], None  # no grad to cond (dynca.py:123)
 
 
 def dynca_nsteps_autograd(model, x, cond, T, update_rate, want_states=False, two_scale=False):
-    bf16 = x.dtype == torch.bfloat16      # bf16 pool: bf16-storage entry points, inference only
+    bf16 = x.dtype == torch.bfloat16      # bf16 pool: bf16-storage entry points (storage format only), forward and backward
     x = x.contiguous() if bf16 else x.float().contiguous()
     params = (model.w1.weight, model.w1.bias, model.w2.weight, model.w2.bias)
-    if bf16 and _needs_grad(x, *params):
-        raise NotImplementedError("ncahip: the bf16-storage DyNCA steps are forward-only; train with float32 states or call "
-                                  "them under torch.no_grad()")
     us = model._draw(x, T)
     cfg = dict(T=T, us=us, pad=model.padding_mode, rate=float(update_rate), seed=model.mask_seed, step0=model._mask_step,
                want_states=want_states, two_scale=two_scale)

@@ -337,7 +337,8 @@ def dynca_nsteps_backward(states: torch.Tensor, cond: Optional[torch.Tensor], us
     one caller-owned workspace.  g_final must already include any cotangent of x_T itself; g_states (optional, [T+1,...])
     adds dL/dx_t cotangents of the intermediate states t < T (forward_nsteps' return_middle_feature).
     Returns dict x0, w1 [fc,4C+cc], b1, w2 [C,fc], b2."""
-    states, g = _dev(states, "states"), _dev(g_final.float(), "g_final")
+    dt, dsfx = _state_dtype(states)      # bfloat16 history: ncahip_dynca_nsteps_bwd_bf16 (storage format only, fp32 gradients)
+    states, g = _dev(states, "states", dt), _dev(g_final.float(), "g_final")
     _, B, C, H, W = states.shape
     assert states.shape[0] == T + 1
     c_cond = 0 if cond is None else cond.shape[1]
@@ -348,15 +349,20 @@ def dynca_nsteps_backward(states: torch.Tensor, cond: Optional[torch.Tensor], us
     if g_states is not None:
         g_states = _dev(g_states.float(), "g_states")
         assert g_states.shape == states.shape
+    if dsfx == "bf16" and w.fc > 128:
+        raise _capi.NcaHipError("ncahip: the bf16-storage DyNCA steps cover fc <= 128")
     dev, f32 = states.device, torch.float32
     fc, k1 = w.fc, 4 * C + c_cond
     out = {"x0": torch.empty(B, C, H, W, device=dev, dtype=f32), "w1": torch.empty(fc, k1, device=dev, dtype=f32),
            "b1": torch.empty(fc, device=dev, dtype=f32), "w2": torch.empty(C, fc, device=dev, dtype=f32),
            "b2": torch.empty(C, device=dev, dtype=f32)}
     sfx = "_ms" if two_scale else ""       # two_scale: backward through ncahip_dynca_nsteps_fwd_ms_f32's steps
-    nbytes = getattr(lib(), f"ncahip_dynca_nsteps_bwd{sfx}_workspace")(B, C, H, W, fc, c_cond)
+    assert not (two_scale and dsfx == "bf16"), "the two-scale step is an fp32 kernel"
+    fn = "ncahip_dynca_nsteps_bwd_bf16" if dsfx == "bf16" else f"ncahip_dynca_nsteps_bwd{sfx}_f32"
+    wsfn = "ncahip_dynca_nsteps_bwd_bf16_workspace" if dsfx == "bf16" else f"ncahip_dynca_nsteps_bwd{sfx}_workspace"
+    nbytes = getattr(lib(), wsfn)(B, C, H, W, fc, c_cond)
     ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-    check(getattr(lib(), f"ncahip_dynca_nsteps_bwd{sfx}_f32")(_p(states), T, _p(cond), _p(us), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C, H, W, fc,
+    check(getattr(lib(), fn)(_p(states), T, _p(cond), _p(us), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C, H, W, fc,
                                             c_cond, PAD_MODES[pad_mode], update_rate, seed, step0, _p(g), _p(g_states), _p(out["x0"]),
                                             _p(out["w1"]), _p(out["b1"]), _p(out["w2"]), _p(out["b2"]), _p(ws), nbytes, _stream()),
           "dynca_nsteps_bwd" + sfx)
