@@ -1,40 +1,52 @@
-// nca_cond_bwd.hip -- backward of one ConditionedNCA step (EncoderConditioning/nca.py:181-195 under
-// autograd, conditioned_trainer.py:125-132), gfx950, fp32.
+// nca_cond_bwd2.hip -- backward kernel A of one ConditionedNCA step with TWO waves per SIMD (EncoderConditioning/nca.py:181-195
+// under autograd, conditioned_trainer.py:125-132), gfx950.
 //
-// Recomputation design: only the pending states x'_t and the 1-byte pre masks are kept by
-// the forward pass.  Per step, two launches:
-//   A  cond_step_bwd_kernel   wave-private 4x16 tiles, same staging as the forward kernel (resolve s_t, pre_t,
-//      z_t in LDS).  The forward MLP is recomputed on MFMA with h1/h2 kept in registers; the incoming gradient
-//      is gated by life_t and the clamp pass-band (closed interval, as torch.clamp) -> dL/dx'_t; the data path
-//      runs back through W3^T, W2^T, W1^T on MFMA (accumulator tile == next B operand, as in the forward);
-//      weight gradients are MFMA products with the CELL axis as K: each 16-cell tile's activations are
-//      transposed through an 18-float-stride LDS buffer (conflict-free operand reads) and accumulated in 128
-//      persistent accumulator registers, flushed once per launch into this wave's slab (deterministic).
-//      Outputs dL/dperception [B,3C,H,W], dL/dx'_t and z_t.
-//   B  cond_step_bwd_stencil_kernel   HBM-bound: dL/ds_t = dL/dx'_t + depthwise-stencil^T(dL/dperception),
-//      dL/dgoal += dz * pre_t, per-block partials of the perception-weight gradient.
-// One wave per SIMD (the persistent accumulators need the registers); 4 waves / workgroup / CU.
+// nca_cond_bwd.hip's kernel A keeps the forward recomputation, the data path AND the 128 persistent weight-gradient
+// accumulators in one wave: 456 registers, one wave per SIMD, and nothing covers its staging / LDS / memory latencies (a
+// third of the kernel).  Here a workgroup is 8 waves = 4 pairs; the two waves of a pair share a SIMD and a tile stream:
+//   data-path wave   staging, forward recomputation, W3^T / W2^T / W1^T, dL/dperception and dL/dx' outputs (no accumulators);
+//                    per 16-cell tile and layer it writes the two factors of the weight-gradient product into the pair's
+//                    cell-major transposition buffer and posts;
+//   gradient wave    reads the factors into registers (operands of all four k-steps), hands the buffer back, and runs the
+//                    products D += A B^T (cell axis as K) into its 128 accumulators while the data wave is already in its
+//                    next section; flushes them into the pair's partial slab at the end.
+// Both fit 256 registers.  Same arithmetic per product and the same per-pair summation order as the one-wave kernel, so the
+// weight gradients are bitwise those of nca_cond_bwd.hip (the f32 bias sums are taken from the operand rows by the gradient
+// wave: a different, equally fixed order).  Kernel B (stencil adjoint) is unchanged.
 #include <cstdlib>
 
 #include "nca_cond_bwd_common.h"
 
 namespace {
 
-template <int CP, typename ST = StF32, bool BFM = false>
-__global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const NcaCondBwdArgs ba) {
+constexpr int kB2Waves = 8, kB2Threads = 512, kB2Pairs = 4;
+template <int CP>
+struct B2Cfg {
     using K = BCfg<CP>;
+    static constexpr int PW_FLAG = K::PW;     // two hand-off counters
+    static constexpr int PW = K::PW + 4;
+    static constexpr int LDS_FLOATS = K::SHARED + kB2Pairs * PW;
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+};
+
+template <int CP, typename ST = StF32, bool BFM = false>
+__global__ __launch_bounds__(kB2Threads, 1) void cond_step_bwd2_kernel(const NcaCondBwdArgs ba) {
+    using K = BCfg<CP>;
+    using K2 = B2Cfg<CP>;
     using FK = WCfg<CP>;
     constexpr int NT = 2;
     const NcaCondArgs& a = ba.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, lane_w = lane;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave & (kB2Pairs - 1);   // waves p and p + 4 sit on the same SIMD
+    const bool grad = wave >= kB2Pairs;       // role: weight-gradient wave (else data-path wave)
     const int C = a.C, H = a.H, W = a.W, hid = a.hidden, K1 = 3 * C;
     const unsigned plane = (unsigned)(H * W);
     const int g = lane >> 4, ci = lane & 15;
 
 #if defined(NCA_STAMPS)
-    unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_last, ph_real0, ph_t0;
+    unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_last, ph_real0, ph_t0;   // data-path waves only
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_real0)::"memory");
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_last)::"memory");
     ph_t0 = ph_last;
@@ -42,13 +54,13 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
     // ---- forward A-operand images (identical to the forward kernel) + transposed images --------------------
     // Two-phase: all gathers are requested before the first is waited for (one cold round trip instead of ten).
     {
-        FillRegs<4 * FK::K1S * 64, kBwdThreads> fr0;
-        FillRegs<4 * 16 * 64, kBwdThreads> fr1;
-        FillRegs<FK::HID, kBwdThreads> fr2;
-        FillRegs<FK::HID, kBwdThreads> fr3;
-        FillRegs<CP * FK::WPS, kBwdThreads> fr4;
-        FillRegs<4 * 4 * 64, kBwdThreads> fr5;
-        FillRegs<K::MJ * 16 * 64, kBwdThreads> fr6;
+        FillRegs<4 * FK::K1S * 64, kB2Threads> fr0;
+        FillRegs<4 * 16 * 64, kB2Threads> fr1;
+        FillRegs<FK::HID, kB2Threads> fr2;
+        FillRegs<FK::HID, kB2Threads> fr3;
+        FillRegs<CP * FK::WPS, kB2Threads> fr4;
+        FillRegs<4 * 4 * 64, kB2Threads> fr5;
+        FillRegs<K::MJ * 16 * 64, kB2Threads> fr6;
         fill_load(fr0, a.w1, tid, [&](int idx) -> long {
             const int l = idx & 63, s = (idx >> 6) % FK::K1S, m = (idx >> 6) / FK::K1S;
             const int gg = l >> 4, o = 16 * m + (l & 15);
@@ -95,7 +107,8 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
     const float* const B2L = smem + FK::OFF_B2;
     const float* const W3T = smem + K::OFF_W3T;
     const float* const W1T = smem + K::OFF_W1T;
-    float* const PWR = smem + K::SHARED + wave * K::PW;
+    float* const PWR = smem + K::SHARED + pair * K2::PW;
+    int* const flags = reinterpret_cast<int*>(PWR + K2::PW_FLAG);   // [0] hand-offs posted by the data wave, [1] consumed by the gradient wave
     float* const Z = PWR + FK::PW_Z;
     float* const XR = PWR + FK::PW_XR;
     float* const PN = PWR + FK::PW_A3;
@@ -111,7 +124,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
     static_assert(OP_N * 64 * 2 <= FK::OFF_B1, "bf16 operand image fits over the f32 W1 | W2 | W3 images");
     const bf_s16x4* const BW = reinterpret_cast<const bf_s16x4*>(smem) + lane;      // operand o of this lane: BW[o * 64]
     if constexpr (BFM) {
-        bf_s16x4 img[(OP_N + kBwdWaves - 1) / kBwdWaves];    // this wave's share of the operands (round robin)
+        bf_s16x4 img[(OP_N + kB2Waves - 1) / kB2Waves];    // this wave's share of the operands (round robin)
         const int w2t_lane0 = (ci & 3) * 64 + (ci >> 2) * 16 + 4 * g;
         auto build = [&](int o) -> bf_s16x4 {
             float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -139,40 +152,239 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             return pack4(v[0], v[1], v[2], v[3]);
         };
 #pragma unroll
-        for (int k = 0; k < (OP_N + kBwdWaves - 1) / kBwdWaves; ++k) {
-            const int o = k * kBwdWaves + wave;
+        for (int k = 0; k < (OP_N + kB2Waves - 1) / kB2Waves; ++k) {
+            const int o = k * kB2Waves + wave;
             img[k] = o < OP_N ? build(o) : bf_s16x4{0, 0, 0, 0};
         }
         __syncthreads();                               // every wave has read what it needs of the f32 images
 #pragma unroll
-        for (int k = 0; k < (OP_N + kBwdWaves - 1) / kBwdWaves; ++k) {
-            const int o = k * kBwdWaves + wave;
+        for (int k = 0; k < (OP_N + kB2Waves - 1) / kB2Waves; ++k) {
+            const int o = k * kB2Waves + wave;
             if (o < OP_N) *(reinterpret_cast<bf_s16x4*>(smem) + o * 64 + lane) = img[k];
         }
         __syncthreads();
     }
-    // persistent weight-gradient accumulators (D = A * B^T with the cell axis as K)
-    f32x4 aW1[4][K::MJ], aW2[4][4], aW3[4];
-    float db1[4][4], db2[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        aW3[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { aW2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; db1[i][j] = 0.f; db2[i][j] = 0.f; }
-#pragma unroll
-        for (int j = 0; j < K::MJ; ++j) aW1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    // ---- hand-off between the two waves of a pair: the data-path wave writes one 16-cell tile's factors of one layer into the
+    //      pair's transposition buffer TB and posts; the gradient wave reads them into registers, posts back (TB is free
+    //      again) and runs the weight-gradient MFMAs.  Two monotonic counters in LDS; LDS operations of one wave execute in
+    //      order, so "data, then counter" / "counter, then data" is all the ordering needed.  Polls are bounded: a broken
+    //      hand-off never hangs the device, it sets the sticky error word (as the forward kernel's await).
+    if (!grad && lane == 0) { flags[0] = 0; flags[1] = 0; }
+    __syncthreads();
+    auto post = [&](int idx, int round) {
+        wave_sync();
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS traffic for the round is done
+        if (lane == 0) __hip_atomic_store(flags + idx, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto await = [&](int idx, int round) {
+        int spins = 0;
+        while (__hip_atomic_load(flags + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < round && ++spins < (1 << 20))
+            __builtin_amdgcn_s_sleep(1);
+        if (spins >= (1 << 20) && lane == 0 && a.err) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        wave_sync();
+    };
+    int posted = 0;   // hand-offs posted (data wave) / consumed (gradient wave)
 
-    NCA_BPHASE(10);  // start-up: weight images, accumulators
+    NCA_BPHASE(10);  // start-up: weight images
     // ---- tile walk: super-tiles of 16 x 16 (4 waves stacked vertically) ------------------------------------
     constexpr int BSTH = 16, BSTW = 16;
     const int st_x = (W + BSTW - 1) / BSTW, st_y = (H + BSTH - 1) / BSTH;
     const int halo = a.alive_ch >= 0 ? 3 : 1;
     const bool use_alive = a.alive_ch >= 0;
+    const int sf = slab_floats(C, hid);
+    static_assert(kB2Pairs * (64 * 3 * CP + 64 * 64 + CP * 64 + 128) <= K2::LDS_FLOATS, "slab staging fits the LDS carve");
+    float* const sw = smem + pair * sf;   // this pair's partial slab (written after the tile loops, over the dead images)
+    if (grad) {
+    // ================= weight-gradient wave: D = A * B^T with the CELL axis as K, 128 persistent accumulators =================
+    f32x4 aW1[4][K::MJ], aW2[4][4], aW3[4];
+    float sb1[4] = {0.f, 0.f, 0.f, 0.f}, sb2[4] = {0.f, 0.f, 0.f, 0.f};   // f32 form: bias sums from the operand rows (lane (g,ci): row 16m + ci, cells = g mod 4)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        aW3[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aW2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < K::MJ; ++j) aW1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (NcaTileWalk tw = nca_tile_walk(a.B * st_x * st_y); tw.t < tw.end; tw.t += tw.stride) {
+        if (((tw.t / st_x) % st_y) * BSTH + pair * WTH >= H || (tw.t % st_x) * BSTW >= W) continue;   // as the data wave
+#pragma unroll 1
+        for (int pass = 0; pass < WTH / NT; ++pass) {
+            if constexpr (BFM) {
+                const short* const tb16 = reinterpret_cast<const short*>(TB);
+                // layer 3: dW3 += dO x h2
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    await(0, ++posted);
+                    const bf_s16x4 ta = tb_tr_read(tb16, 0, lane);
+                    bf_s16x4 tbv[4];
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) tbv[nb] = tb_tr_read(tb16, 1 + nb, lane);
+                    post(1, posted);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) aW3[nb] = mfma_bf16(ta, tbv[nb], aW3[nb]);
+                }
+                // layer 2: dW2 += d2 x h1
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    await(0, ++posted);
+                    bf_s16x4 ta[4], tbv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { ta[k] = tb_tr_read(tb16, k, lane); tbv[k] = tb_tr_read(tb16, 4 + k, lane); }
+                    post(1, posted);
+#pragma unroll
+                    for (int ma = 0; ma < 4; ++ma)
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) aW2[ma][nb] = mfma_bf16(ta[ma], tbv[nb], aW2[ma][nb]);
+                }
+                // layer 1: dW1 += d1 x P (P columns in slot order, un-permuted at the slab flush)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    await(0, ++posted);
+                    bf_s16x4 ta[4], tbv[K::MJ];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ta[k] = tb_tr_read(tb16, k, lane);
+#pragma unroll
+                    for (int nb = 0; nb < K::MJ; ++nb) tbv[nb] = tb_tr_read(tb16, 4 + nb, lane);
+                    post(1, posted);
+#pragma unroll
+                    for (int ma = 0; ma < 4; ++ma)
+#pragma unroll
+                        for (int nb = 0; nb < K::MJ; ++nb) aW1[ma][nb] = mfma_bf16(ta[ma], tbv[nb], aW1[ma][nb]);
+                }
+            } else {
+                const float* const tr_ = TB + g * TBS + ci;   // operand reads: cell 4s+g -> + 4*s*TBS; rows 0.. = factor A, 16.. / 64.. = factor B
+                // layer 3: dW3 = dO (rows 0..15) x h2 (rows 16..79)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    await(0, ++posted);
+                    OpN<5> o[4];
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) {
+                        o[s_].v[0] = tr_[4 * s_ * TBS];
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) o[s_].v[1 + nb] = tr_[4 * s_ * TBS + 16 + 16 * nb];
+                    }
+                    post(1, posted);
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) aW3[nb] = nca_mfma(o[s_].v[0], o[s_].v[1 + nb], aW3[nb]);
+                }
+                // layer 2: dW2 = d2 (rows 0..63) x h1 (rows 64..127);  db2 = row sums of d2
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    await(0, ++posted);
+                    OpN<8> o[4];
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            o[s_].v[k] = tr_[4 * s_ * TBS + 16 * k];
+                            o[s_].v[4 + k] = tr_[4 * s_ * TBS + 64 + 16 * k];
+                        }
+                    post(1, posted);
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) sb2[k] += o[s_].v[k];
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int ma = 0; ma < 4; ++ma)
+#pragma unroll
+                            for (int nb = 0; nb < 4; ++nb) aW2[ma][nb] = nca_mfma(o[s_].v[ma], o[s_].v[4 + nb], aW2[ma][nb]);
+                }
+                // layer 1: dW1 = d1 (rows 0..63) x P (rows 64.., natural perception index j = 3c+f);  db1 = row sums of d1
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    await(0, ++posted);
+                    OpN<4 + K::MJ> o[4];
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[s_].v[k] = tr_[4 * s_ * TBS + 16 * k];
+#pragma unroll
+                        for (int nb = 0; nb < K::MJ; ++nb) o[s_].v[4 + nb] = tr_[4 * s_ * TBS + 64 + 16 * nb];
+                    }
+                    post(1, posted);
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) sb1[k] += o[s_].v[k];
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int ma = 0; ma < 4; ++ma)
+#pragma unroll
+                            for (int nb = 0; nb < K::MJ; ++nb) aW1[ma][nb] = nca_mfma(o[s_].v[ma], o[s_].v[4 + nb], aW1[ma][nb]);
+                }
+            }
+        }
+    }
+    __syncthreads();   // (the data waves' barrier after their tile loop)
+#pragma unroll
+    for (int ma = 0; ma < 4; ++ma)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = 16 * ma + 4 * g + r;
+            if (o < hid) {
+#pragma unroll
+                for (int nb = 0; nb < K::MJ; ++nb) {
+                    if constexpr (BFM) {   // column 16nb + ci = 12 g' + q, q = 3 c4 + f: channel 4 c4 + g', filter f
+                        const int col = 16 * nb + ci, gp = col / 12, q = col - 12 * gp, j = 3 * (4 * (q / 3) + gp) + q % 3;
+                        if (gp < 4 && q < K::K1S && j < K1) sw[o * K1 + j] = aW1[ma][nb][r];
+                    } else if (16 * nb + ci < K1) sw[o * K1 + 16 * nb + ci] = aW1[ma][nb][r];
+                }
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    if (16 * nb + ci < hid) sw[slab_off_w2(C, hid) + o * hid + 16 * nb + ci] = aW2[ma][nb][r];
+            }
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ch = 4 * g + r;
+        if (ch < C) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                if (16 * nb + ci < hid) sw[slab_off_w3(C, hid) + ch * hid + 16 * nb + ci] = aW3[nb][r];
+        }
+    }
+    if constexpr (!BFM) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float s1 = sb1[m], s2 = sb2[m];
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            const int o = 16 * m + ci;
+            if (g == 0 && o < hid) {
+                sw[slab_off_b1(C, hid) + o] = s1;
+                sw[slab_off_b2(C, hid) + o] = s2;
+            }
+        }
+    }
+    } else {
+    float db1[4][4], db2[4][4];   // bias-gradient sums (BFM: taken before the bf16 rounding, so they stay with the data path)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { db1[i][j] = 0.f; db2[i][j] = 0.f; }
+    switch (ba.prio & 3) {   // (the instruction takes an immediate)
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+    }
+    for (NcaTileWalk tw = nca_tile_walk(a.B * st_x * st_y); tw.t < tw.end; tw.t += tw.stride) {
+        // The lane id is opaque per tile: everything derived from it (LDS and global lane offsets, ~35 registers' worth) is
+        // then recomputed where it is used instead of being hoisted out of the tile loop -- with 256 registers the hoisted
+        // values were spilled, and a spill reload inside the loop waits for every load and store in flight.
+        int lane = lane_w;
+        asm volatile("" : "+v"(lane));
+        const int g = (lane >> 4) & 3, ci = lane & 15;
         WTile t;
         t.b = tw.t / (st_x * st_y);
-        t.ty0 = ((tw.t / st_x) % st_y) * BSTH + wave * WTH;
+        t.ty0 = ((tw.t / st_x) % st_y) * BSTH + pair * WTH;
         t.tx0 = (tw.t % st_x) * BSTW;
         if (t.ty0 >= H || t.tx0 >= W) continue;
         t.valid = true;
@@ -180,10 +392,20 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
         const int ty0 = t.ty0, tx0 = t.tx0;
 
         NCA_BPHASE(0);   // loop overhead / previous tile's tail
-        // ---- all global loads of the tile are requested up front (one HBM round trip per tile instead of two: with one
-        //      wave per SIMD nothing else hides it): forward operands, pending x'_t (alpha halo 1 + interior), incoming gradient
+        // ---- forward operands: requested and staged first.  (The one-wave kernel also requests the pending state and the
+        //      incoming gradient here, one memory round trip per tile; with 256 registers those 35 extra landing registers
+        //      spill, and a spill reload waits for every load and store in flight.  The partner wave covers the second trip.)
         TileRegs<CP, ST> R;
-        issue_loads<CP, true, true, -1, false, ST>(a, t, lane, R);
+        const TileLds L = wave_private_lds<CP>(PWR);
+        if (t.inner) {
+            issue_loads<CP, true, true, 0, false, ST>(a, t, lane, R);
+            stage_tile<CP, false, false, ST>(a, t, L, lane, R, 0);
+        } else {
+            issue_loads<CP, true, true, 1, false, ST>(a, t, lane, R);
+            stage_tile<CP, true, false, ST>(a, t, L, lane, R, 0);
+        }
+        NCA_BPHASE(1);   // forward staging
+        // ---- pending x'_t (alpha halo 1 + interior) and the incoming gradient
         const char* const xn = reinterpret_cast<const char*>(ba.x_next) + (size_t)t.b * C * plane * ST::BYTES;
         const float* const gn = ba.g_next + (size_t)t.b * C * plane;
         const int hl = (lane >> 5) & 1, l5 = lane & 31;
@@ -208,19 +430,8 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             xv[k] = ST::gld4(xn, ch * plane + off);
             gv[k] = ld4(gn + ch * plane + off);
         }
-        // ---- forward staging: s_t (XR), pre_t (PN), z_t (Z), fire mask (MK) -------------------------------
-        const TileLds L = wave_private_lds<CP>(PWR);
-        if (t.inner) stage_tile<CP, false, false, ST>(a, t, L, lane, R, 0);
-        else stage_tile<CP, true, false, ST>(a, t, L, lane, R, 0);
-        NCA_BPHASE(1);   // forward staging
-
-        // ---- pending x'_t: alpha halo 1 -> A1 (post mask), interior -> XR; incoming gradient -> TB --------
+        // ---- z_t out while those are in flight; then alpha halo 1 -> A1 (post mask), interior -> XR; incoming gradient -> TB
         {
-            if (use_alive) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if (l5 < 18) A1[(2 * k + hl) * RS + l5 + 3] = aok[k] ? ST::cv1(av[k]) : NCA_NEG_INF;
-            }
             // z_t interior out (kernel B needs it for the perception-weight gradient)
             // (BFM: the two scratch tensors kernel B streams, z_t and dL/dperception, are stored as bf16: half the bytes)
             float* const zo = ba.zbuf + (size_t)t.b * C * plane + off;
@@ -233,6 +444,11 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
                     if constexpr (BFM) *reinterpret_cast<u32x2*>(zo16 + (unsigned)ch * plane) = u32x2{pk_bf16(zv[0], zv[1]), pk_bf16(zv[2], zv[3])};
                     else st4(zo + (unsigned)ch * plane, zv);
                 }
+            }
+            if (use_alive) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if (l5 < 18) A1[(2 * k + hl) * RS + l5 + 3] = aok[k] ? ST::cv1(av[k]) : NCA_NEG_INF;
             }
             wave_sync();
 #pragma unroll
@@ -375,14 +591,11 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
                 // ---- layer 3: dW3 += dO x h2 (cells as K);  d2 = (W3^T dO) * 1[h2 > 0] ---------------------------------------
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    wave_sync();
+                    await(1, posted);
                     tb_write(tb16, 0, lane, dOb[n]);
 #pragma unroll
                     for (int m = 0; m < 4; ++m) tb_write(tb16, 1 + m, lane, h2b[m][n]);
-                    wave_sync();
-                    const bf_s16x4 ta = tb_tr_read(tb16, 0, lane);
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) aW3[nb] = mfma_bf16(ta, tb_tr_read(tb16, 1 + nb, lane), aW3[nb]);
+                    post(0, ++posted);
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
@@ -397,19 +610,10 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
                 // ---- layer 2: dW2 += d2 x h1;  d1 = (W2^T d2) * 1[h1 > 0] ----------------------------------------------------
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    wave_sync();
+                    await(1, posted);
 #pragma unroll
                     for (int m = 0; m < 4; ++m) { tb_write(tb16, m, lane, d2b[m][n]); tb_write(tb16, 4 + m, lane, h1b[m][n]); }
-                    wave_sync();
-                    bf_s16x4 tbv[4];
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) tbv[nb] = tb_tr_read(tb16, 4 + nb, lane);
-#pragma unroll
-                    for (int ma = 0; ma < 4; ++ma) {
-                        const bf_s16x4 ta = tb_tr_read(tb16, ma, lane);
-#pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) aW2[ma][nb] = mfma_bf16(ta, tbv[nb], aW2[ma][nb]);
-                    }
+                    post(0, ++posted);
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
@@ -426,21 +630,12 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
                 // ---- layer 1: dW1 += d1 x P (P columns in slot order: column 12 g' + q, un-permuted at the slab flush);  dp = W1^T d1
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    wave_sync();
+                    await(1, posted);
 #pragma unroll
                     for (int m = 0; m < 4; ++m) tb_write(tb16, m, lane, d1b[m][n]);
 #pragma unroll
                     for (int s_ = 0; s_ < KS1; ++s_) tb_write_chunk(tb16, 16 + 3 * g + s_, lane, pb[n][s_]);   // columns 12g + 4s .. of tiles 4..6
-                    wave_sync();
-                    bf_s16x4 tbv[K::MJ];
-#pragma unroll
-                    for (int nb = 0; nb < K::MJ; ++nb) tbv[nb] = tb_tr_read(tb16, 4 + nb, lane);
-#pragma unroll
-                    for (int ma = 0; ma < 4; ++ma) {
-                        const bf_s16x4 ta = tb_tr_read(tb16, ma, lane);
-#pragma unroll
-                        for (int nb = 0; nb < K::MJ; ++nb) aW1[ma][nb] = mfma_bf16(ta, tbv[nb], aW1[ma][nb]);
-                    }
+                    post(0, ++posted);
                 }
 #pragma unroll
                 for (int mj = 0; mj < K::MJ; ++mj)
@@ -521,28 +716,15 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             // accumulator rows of a tile with ONE 16-byte store; operand fragments A[i][k=g] = TB[4s+g][rowA+i],
             // B[k=g][j] = TB[4s+g][rowB+j] are 16 consecutive floats per lane group.
             float* const tw_ = TB + ci * TBS + 4 * g;            // this lane's cell row, accumulator-row offset
-            const float* const tr_ = TB + g * TBS + ci;           // operand reads: cell 4s+g -> + 4*s*TBS
             f32x4 d2[4][NT], d1[4][NT];
             // ---- layer 3: dW3 = dO (rows 0..15) x h2 (rows 16..79);  d2 = (W3^T dO) * 1[h2 > 0] ---------------------------
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                wave_sync();  // TB free (gradient tile consumed above / previous products done)
+                await(1, posted);  // TB free: the gradient wave has everything posted so far in registers
                 st4(tw_, f32x4{dO[n][0], dO[n][1], dO[n][2], dO[n][3]});
 #pragma unroll
                 for (int m = 0; m < 4; ++m) st4(tw_ + 16 + 16 * m, h2[m][n]);
-                wave_sync();
-                piped<4>(
-                    [&](int s_) {
-                        OpN<5> o;
-                        o.v[0] = tr_[4 * s_ * TBS];
-#pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) o.v[1 + nb] = tr_[4 * s_ * TBS + 16 + 16 * nb];
-                        return o;
-                    },
-                    [&](int, const OpN<5>& o) {
-#pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) aW3[nb] = nca_mfma(o.v[0], o.v[1 + nb], aW3[nb]);
-                    });
+                post(0, ++posted);
             }
             piped<4>(
                 [&](int m) {
@@ -567,29 +749,13 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             // ---- layer 2: dW2 = d2 (rows 0..63) x h1 (rows 64..127);  d1 = (W2^T d2) * 1[h1 > 0] ---------------------------
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                wave_sync();
+                await(1, posted);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     st4(tw_ + 16 * m, d2[m][n]);
                     st4(tw_ + 64 + 16 * m, h1[m][n]);
                 }
-                wave_sync();
-                piped<4>(
-                    [&](int s_) {
-                        OpN<8> o;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            o.v[k] = tr_[4 * s_ * TBS + 16 * k];
-                            o.v[4 + k] = tr_[4 * s_ * TBS + 64 + 16 * k];
-                        }
-                        return o;
-                    },
-                    [&](int, const OpN<8>& o) {
-#pragma unroll
-                        for (int ma = 0; ma < 4; ++ma)
-#pragma unroll
-                            for (int nb = 0; nb < 4; ++nb) aW2[ma][nb] = nca_mfma(o.v[ma], o.v[4 + nb], aW2[ma][nb]);
-                    });
+                post(0, ++posted);
             }
             const int w2t_lane = (ci & 3) * 64 + (ci >> 2) * 16 + 4 * g;  // transposed read of the forward W2 image
             piped<16>(
@@ -614,39 +780,18 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
                             for (int r = 0; r < 4; ++r) d1[m][n][r] = gate_pos(h1[m][n][r], d1[m][n][r]);
                     }
                 });
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) { db1[m][r] += d1[m][n][r]; db2[m][r] += d2[m][n][r]; }
-            NCA_BPHASE(7);   // layer 2
+            NCA_BPHASE(7);   // layer 2 (the bias sums are taken by the gradient wave from the operands it reads)
             // ---- layer 1: dW1 = d1 (rows 0..63) x P (rows 64.., natural perception index j = 3c+f);  dp = W1^T d1 ---------
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                wave_sync();
+                await(1, posted);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) st4(tw_ + 16 * m, d1[m][n]);
 #pragma unroll
                 for (int c4 = 0; c4 < CP / 4; ++c4)
 #pragma unroll
                     for (int f = 0; f < 3; ++f) TB[ci * TBS + 64 + 3 * (4 * c4 + g) + f] = P[n][3 * c4 + f];
-                wave_sync();
-                piped<4>(
-                    [&](int s_) {
-                        OpN<4 + K::MJ> o;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) o.v[k] = tr_[4 * s_ * TBS + 16 * k];
-#pragma unroll
-                        for (int nb = 0; nb < K::MJ; ++nb) o.v[4 + nb] = tr_[4 * s_ * TBS + 64 + 16 * nb];
-                        return o;
-                    },
-                    [&](int, const OpN<4 + K::MJ>& o) {
-#pragma unroll
-                        for (int ma = 0; ma < 4; ++ma)
-#pragma unroll
-                            for (int nb = 0; nb < K::MJ; ++nb) aW1[ma][nb] = nca_mfma(o.v[ma], o.v[4 + nb], aW1[ma][nb]);
-                    });
+                post(0, ++posted);
             }
             piped<4 * K::MJ>(
                 [&](int i) {
@@ -669,8 +814,8 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
                 });
             NCA_BPHASE(8);   // layer 1
             }
-            // ---- dL/dperception out: [j][2 rows][16] via TB, 16-byte stores -----------------------------------
-            wave_sync();
+            // ---- dL/dperception out: [j][2 rows][16] via TB (free once the gradient wave has read the last hand-off), 16-byte stores
+            await(1, posted);
 #pragma unroll
             for (int mj = 0; mj < K::MJ; ++mj)
 #pragma unroll
@@ -716,347 +861,85 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
 
 #if defined(NCA_STAMPS)
     if (a.dbg && lane == 0) {
-        for (int i = 0; i < 12; ++i) a.dbg[(size_t)(blockIdx.x * kBwdWaves + wave) * 16 + i] = ph_acc[i];
+        for (int i = 0; i < 12; ++i) a.dbg[(size_t)(blockIdx.x * kB2Pairs + pair) * 16 + i] = ph_acc[i];
         unsigned long long r1;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1)::"memory");
-        a.dbg[(size_t)(blockIdx.x * kBwdWaves + wave) * 16 + 12] = r1 - ph_real0;    // 100 MHz ticks
-        a.dbg[(size_t)(blockIdx.x * kBwdWaves + wave) * 16 + 13] = ph_last - ph_t0;  // shader-clock ticks over the same span
+        a.dbg[(size_t)(blockIdx.x * kB2Pairs + pair) * 16 + 12] = r1 - ph_real0;    // 100 MHz ticks
+        a.dbg[(size_t)(blockIdx.x * kB2Pairs + pair) * 16 + 13] = ph_last - ph_t0;  // shader-clock ticks over the same span
     }
 #endif
-    // ---- weight-gradient partials: the four waves' accumulators are summed through LDS (tiles and weight images are dead
-    //      by now) and added to the WORKGROUP's slab with coalesced accesses; fixed summation order (deterministic).
-    const int sf = slab_floats(C, hid);
-    static_assert(kBwdWaves * (64 * 3 * CP + 64 * 64 + CP * 64 + 128) <= K::LDS_FLOATS, "slab staging fits the LDS carve");
-    __syncthreads();
-    float* const sw = smem + wave * sf;
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();   // tiles and weight images are dead: the pairs' partial slabs go over them
+    if constexpr (BFM) {
 #pragma unroll
-    for (int ma = 0; ma < 4; ++ma)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = 16 * ma + 4 * g + r;
-            if (o < hid) {
+            for (int r = 0; r < 4; ++r) {
+                float s1 = db1[m][r], s2 = db2[m][r];
 #pragma unroll
-                for (int nb = 0; nb < K::MJ; ++nb) {
-                    if constexpr (BFM) {   // column 16nb + ci = 12 g' + q, q = 3 c4 + f: channel 4 c4 + g', filter f
-                        const int col = 16 * nb + ci, gp = col / 12, q = col - 12 * gp, j = 3 * (4 * (q / 3) + gp) + q % 3;
-                        if (gp < 4 && q < K::K1S && j < K1) sw[o * K1 + j] = aW1[ma][nb][r];
-                    } else if (16 * nb + ci < K1) sw[o * K1 + 16 * nb + ci] = aW1[ma][nb][r];
+                for (int d = 1; d < 16; d <<= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
+                const int o = 16 * m + 4 * g + r;
+                if (ci == 0 && o < hid) {
+                    sw[slab_off_b1(C, hid) + o] = s1;
+                    sw[slab_off_b2(C, hid) + o] = s2;
                 }
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-                    if (16 * nb + ci < hid) sw[slab_off_w2(C, hid) + o * hid + 16 * nb + ci] = aW2[ma][nb][r];
             }
-        }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int ch = 4 * g + r;
-        if (ch < C) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-                if (16 * nb + ci < hid) sw[slab_off_w3(C, hid) + ch * hid + 16 * nb + ci] = aW3[nb][r];
-        }
     }
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float s1 = db1[m][r], s2 = db2[m][r];
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
-            const int o = 16 * m + 4 * g + r;
-            if (ci == 0 && o < hid) {
-                sw[slab_off_b1(C, hid) + o] = s1;
-                sw[slab_off_b2(C, hid) + o] = s2;
-            }
-        }
+    }   // role
+    // ---- weight-gradient partials: the four pairs' sums meet in LDS and are added to the WORKGROUP's slab with coalesced
+    //      accesses; fixed summation order (deterministic).
     __syncthreads();
     float* const slab = ba.slabs + (size_t)blockIdx.x * sf;
-    constexpr int PER = (64 * 3 * CP + 64 * 64 + CP * 64 + 128 + kBwdThreads - 1) / kBwdThreads;
+    constexpr int PER = (64 * 3 * CP + 64 * 64 + CP * 64 + 128 + kB2Threads - 1) / kB2Threads;
     float cur[PER];   // all reads of the read-modify-write in flight at once (one round trip, not PER)
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int i = tid + kBwdThreads * k;
+        const int i = tid + kB2Threads * k;
         cur[k] = i < sf ? slab[i] : 0.0f;
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int i = tid + kBwdThreads * k;
+        const int i = tid + kB2Threads * k;
         if (i < sf) slab[i] = cur[k] + ((smem[i] + smem[sf + i]) + (smem[2 * sf + i] + smem[3 * sf + i]));
     }
 #if defined(NCA_STAMPS)
-    NCA_BPHASE(11);  // slab flush
-    if (a.dbg && lane == 0) a.dbg[(size_t)(blockIdx.x * kBwdWaves + wave) * 16 + 11] = ph_acc[11];
+    if (!grad) {
+        NCA_BPHASE(11);  // slab flush
+        if (a.dbg && lane == 0) a.dbg[(size_t)(blockIdx.x * kB2Pairs + pair) * 16 + 11] = ph_acc[11];
+    }
 #endif
 }
 
-// Kernel B: dL/ds_t = dL/dx'_t + stencil^T(dL/dP);  dL/dgoal += dz * pre_t;  perception-weight partials.
-// One thread = 4 W-contiguous cells x a strip of SROWS rows of one (b, c) plane, walked top to bottom with a
-// three-row sliding window held in registers: every row of z / dL/dP is loaded once per thread (16-byte loads,
-// left/right neighbours by wavefront shuffle with a scalar fallback at row/wave edges), and the 27 perception-weight
-// sums are reduced across the block once per strip.  A block never spans two channels.
-constexpr int SROWS = 16;
-struct Row6 { float v[6]; };   // columns x0-1 .. x0+4
+}  // namespace
 
-// Two-stage row fetch: issue (raw 16-byte group + the two edge cells that have no neighbour lane) and finish (shuffle the
-// neighbours' edge values in).  Anything that touches the loaded value belongs to finish -- a shuffle at issue time waits
-// for the load and defeats the prefetch.
-struct RawRow {
-    float4 c;
-    float el, er;
-    bool in;
-};
-__device__ __forceinline__ RawRow issue_row6(const float* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r) {
-    RawRow r;
-    r.in = y >= 0 && y < H;
-    const float* const row = plane + (size_t)(r.in ? y : 0) * W;
-    r.c = *reinterpret_cast<const float4*>(row + x0);
-    r.el = 0.0f;
-    r.er = 0.0f;
-    if (!has_l && x0 > 0) r.el = row[x0 - 1];
-    if (!has_r && x0 + 4 < W) r.er = row[x0 + 4];
-    return r;
-}
-// bf16 scratch (the BFM backward): 8-byte group + 2-byte edges, widened on arrival (the widening touches the loaded value, so a
-// row issued two rows ahead pays no wait here either: the compiler places the wait at the first shift)
-__device__ __forceinline__ RawRow issue_row6(const uint16_t* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r) {
-    RawRow r;
-    r.in = y >= 0 && y < H;
-    const uint16_t* const row = plane + (size_t)(r.in ? y : 0) * W;
-    const u32x2 c = *reinterpret_cast<const u32x2*>(row + x0);
-    unsigned el = 0u, er = 0u;
-    if (!has_l && x0 > 0) el = row[x0 - 1];
-    if (!has_r && x0 + 4 < W) er = row[x0 + 4];
-    r.c = make_float4(__uint_as_float(c[0] << 16), __uint_as_float(c[0] & 0xffff0000u), __uint_as_float(c[1] << 16), __uint_as_float(c[1] & 0xffff0000u));
-    r.el = __uint_as_float(el << 16);
-    r.er = __uint_as_float(er << 16);
-    return r;
-}
-__device__ __forceinline__ Row6 finish_row6(const RawRow& q, bool has_l, bool has_r) {
-    Row6 r;
-    const float z = q.in ? 1.0f : 0.0f;   // rows outside the image read row 0 and are zeroed here
-    float l = __shfl_up(q.c.w, 1), rr = __shfl_down(q.c.x, 1);
-    if (!has_l) l = q.el;
-    if (!has_r) rr = q.er;
-    r.v[0] = l * z; r.v[1] = q.c.x * z; r.v[2] = q.c.y * z; r.v[3] = q.c.z * z; r.v[4] = q.c.w * z; r.v[5] = rr * z;
-    return r;
-}
-template <typename ET>
-__device__ __forceinline__ Row6 load_row6(const ET* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r) {
-    return finish_row6(issue_row6(plane, H, W, y, x0, has_l, has_r), has_l, has_r);
-}
-
-// ET = element type of the two scratch tensors kernel A wrote (z_t, dL/dperception): float, or uint16_t (bf16) behind the BFM kernel A
-template <typename ET>
-__global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCondBwdArgs ba) {
-    const NcaCondArgs& a = ba.f;
-    const int C = a.C, H = a.H, W = a.W;
-    const size_t plane = (size_t)H * W;
-    const int W4 = W / 4, strips = (H + SROWS - 1) / SROWS;
-    const int per_plane = strips * W4, blocks_per_plane = (per_plane + 255) / 256;
-    const int bc = blockIdx.x / blocks_per_plane, b = bc / C, c = bc % C;
-    const int id = (blockIdx.x % blocks_per_plane) * 256 + threadIdx.x;
-    const bool active = id < per_plane;
-    const int ida = active ? id : per_plane - 1;      // inactive lanes shadow the last item (they still shuffle)
-    const int x0 = (ida % W4) * 4, y0 = (ida / W4) * SROWS;
-    const int lane = threadIdx.x & 63;
-    const bool has_l = x0 > 0 && lane > 0, has_r = x0 + 4 < W && lane < 63 && id + 1 < per_plane;
-    float wl[27];
-#pragma unroll
-    for (int i = 0; i < 27; ++i) wl[i] = a.wp[(size_t)c * 27 + i];
-    const ET* const zb = reinterpret_cast<const ET*>(ba.zbuf) + ((size_t)b * C + c) * plane;
-    const ET* const p0 = reinterpret_cast<const ET*>(ba.dP) + ((size_t)b * 3 * C + 3 * c) * plane;
-    float wsum[27];
-#pragma unroll
-    for (int i = 0; i < 27; ++i) wsum[i] = 0.f;
-    const int gch0 = C - a.goal_ch;
-    // window rows: index 0 = y-1, 1 = y, 2 = y+1; row y+2 (zn / pn) is loaded while row y is computed, so no load
-    // is consumed in the iteration that issues it
-    Row6 zw[3], pw[3][3];
-    RawRow zn, pn[3];
-    zw[0] = load_row6(zb, H, W, y0 - 1, x0, has_l, has_r);
-    zw[1] = load_row6(zb, H, W, y0, x0, has_l, has_r);
-    zw[2] = load_row6(zb, H, W, y0 + 1, x0, has_l, has_r);
-#pragma unroll
-    for (int f = 0; f < 3; ++f) {
-        pw[f][0] = load_row6(p0 + (size_t)f * plane, H, W, y0 - 1, x0, has_l, has_r);
-        pw[f][1] = load_row6(p0 + (size_t)f * plane, H, W, y0, x0, has_l, has_r);
-        pw[f][2] = load_row6(p0 + (size_t)f * plane, H, W, y0 + 1, x0, has_l, has_r);
-    }
-    // the row's own read-modify-write operands (dL/dx', dL/dgoal, pre mask) are requested one row ahead as well
-    const bool goal_ch = c >= gch0, use_pre = goal_ch && a.alive_ch >= 0;
-    const float* const gxp = ba.gx + ((size_t)b * C + c) * plane + x0;
-    float* const gop = ba.g_out + ((size_t)b * C + c) * plane + x0;
-    float* const dgp = goal_ch ? ba.dgoal + ((size_t)b * a.goal_ch + (c - gch0)) * plane + x0 : nullptr;
-    const uint8_t* const prp = use_pre ? ba.pre_t + (size_t)b * plane + x0 : nullptr;
-    float4 gxn = make_float4(0.f, 0.f, 0.f, 0.f), dgn = gxn;
-    uchar4 pbn = make_uchar4(1, 1, 1, 1);
-    auto issue_rmw = [&](int y) {
-        const size_t ro = (size_t)min(y, H - 1) * W;
-        gxn = *reinterpret_cast<const float4*>(gxp + ro);
-        if (goal_ch) dgn = *reinterpret_cast<const float4*>(dgp + ro);
-        if (use_pre) pbn = *reinterpret_cast<const uchar4*>(prp + ro);
-    };
-    issue_rmw(y0);
-#pragma unroll 1
-    for (int k = 0; k < SROWS; ++k) {
-        const int y = y0 + k;
-        zn = issue_row6(zb, H, W, y + 2, x0, has_l, has_r);
-#pragma unroll
-        for (int f = 0; f < 3; ++f) pn[f] = issue_row6(p0 + (size_t)f * plane, H, W, y + 2, x0, has_l, has_r);
-        const float4 gx = gxn, dgc = dgn;
-        const uchar4 pb = pbn;
-        issue_rmw(y + 1);
-        if (active && y < H) {
-            // dz[x] = sum_f sum_{ty,tx} Wp[f][ty][tx] * dP[f][y-(ty-1)][x-(tx-1)]      (transpose of the zero-padded correlation)
-            float dz[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int f = 0; f < 3; ++f)
-#pragma unroll
-                for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-                    for (int tx = 0; tx < 3; ++tx)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            dz[j] = fmaf(wl[9 * f + 3 * ty + tx], pw[f][2 - ty].v[j + 2 - tx], dz[j]);
-            // dWp[f][ty][tx] += dP[f][y][x] * z[y+ty-1][x+tx-1]
-#pragma unroll
-            for (int f = 0; f < 3; ++f)
-#pragma unroll
-                for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-                    for (int tx = 0; tx < 3; ++tx)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            wsum[9 * f + 3 * ty + tx] = fmaf(pw[f][1].v[j + 1], zw[ty].v[j + tx], wsum[9 * f + 3 * ty + tx]);
-            const size_t ro = (size_t)y * W;
-            *reinterpret_cast<float4*>(gop + ro) = make_float4(gx.x + dz[0], gx.y + dz[1], gx.z + dz[2], gx.w + dz[3]);
-            if (goal_ch) {
-                float4 o = dgc;
-                o.x += dz[0] * (float)pb.x; o.y += dz[1] * (float)pb.y; o.z += dz[2] * (float)pb.z; o.w += dz[3] * (float)pb.w;
-                *reinterpret_cast<float4*>(dgp + ro) = o;
-            }
-        }
-        zw[0] = zw[1]; zw[1] = zw[2]; zw[2] = finish_row6(zn, has_l, has_r);
-#pragma unroll
-        for (int f = 0; f < 3; ++f) { pw[f][0] = pw[f][1]; pw[f][1] = pw[f][2]; pw[f][2] = finish_row6(pn[f], has_l, has_r); }
-    }
-    // block reduction of the 27 partial sums, fixed order (deterministic)
-    __shared__ float red[4][27];
-#pragma unroll
-    for (int i = 0; i < 27; ++i) {
-        float v = active ? wsum[i] : 0.0f;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
-        if (lane == 0) red[threadIdx.x >> 6][i] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 27)
-        ba.wp_partials[(size_t)blockIdx.x * 27 + threadIdx.x] +=
-            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
-
-// dst[j] = sum_i src[i*m + j] (fixed order -> deterministic)
-// dst[j] = sum_i src[i][j]: a block owns 16 columns, its 16 row groups take every sixteenth row each, partial sums combined
-// in a fixed order (deterministic)
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int m, int accumulate) {
-    __shared__ float part[16][17];
-    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4, j = blockIdx.x * 16 + c;
-    float acc0 = 0.0f, acc1 = 0.0f;
-    if (j < m) {
-        int i = rg;
-        for (; i + 16 < n; i += 32) {
-            acc0 += src[(size_t)i * m + j];
-            acc1 += src[(size_t)(i + 16) * m + j];
-        }
-        if (i < n) acc0 += src[(size_t)i * m + j];
-    }
-    part[rg][c] = acc0 + acc1;
-    __syncthreads();
-    if (rg == 0 && j < m) {
-        float v = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v += part[k][c];
-        dst[j] = accumulate ? dst[j] + v : v;
-    }
-}
-// perception-weight partials [B*C*bpp][27] -> grad [C][27]
-__global__ __launch_bounds__(64) void reduce_wp_kernel(const float* __restrict__ part, float* __restrict__ dst, int B, int C, int bpp) {
-    const int c = blockIdx.x, i = threadIdx.x;
-    if (i >= 27) return;
-    float acc = 0.0f;
-    for (int b = 0; b < B; ++b)
-        for (int k = 0; k < bpp; ++k) acc += part[((size_t)(b * C + c) * bpp + k) * 27 + i];
-    dst[c * 27 + i] = acc;
-}
-
-int g_bwd_variant = [] { const char* e = getenv("NCAHIP_BWD_VARIANT"); return e ? atoi(e) : 0; }();
-int g_bwd2_prio = [] { const char* e = getenv("NCAHIP_BWD2_PRIO"); return e ? atoi(e) : 0; }();
-
-template <int CP, typename ST, bool BFM = false>
-hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
-    if (g_bwd_variant == 0) {   // default: kernel A with a data-path wave and a weight-gradient wave per SIMD
-        NcaCondBwdArgs b2 = ba;
-        b2.prio = g_bwd2_prio;
-        if (hipError_t e = nca_launch_cond_step_bwd_a2(b2, st, BFM ? 2 : (ST::BYTES == 2 ? 1 : 0)); e != hipSuccess) return e;
-        if (BFM) hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<uint16_t>, dim3(ba.nblk), dim3(256), 0, st, ba);
-        else hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<float>, dim3(ba.nblk), dim3(256), 0, st, ba);
-        return hipGetLastError();
-    }
-    using K = BCfg<CP>;
-    auto kern = cond_step_bwd_kernel<CP, ST, BFM>;
-    const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
+template <int CP, typename ST, bool BFM>
+static hipError_t launch_a2(const NcaCondBwdArgs& ba, hipStream_t st) {
+    using K2 = B2Cfg<CP>;
+    auto kern = cond_step_bwd2_kernel<CP, ST, BFM>;
+    const size_t lds = (size_t)K2::LDS_FLOATS * sizeof(float);
     static NcaLdsAttr attr;   // per instantiation; keyed by device inside
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
     const NcaCondArgs& a = ba.f;
     const int nst = a.B * ((a.W + 15) / 16) * ((a.H + 15) / 16);
     const int grid = nst < ba.nslab ? nst : ba.nslab;   // one slab per workgroup
-#if defined(NCA_STAMPS)
     NcaCondBwdArgs bd = ba;
+    bd.f.err = nca_error_word_device();
+#if defined(NCA_STAMPS)
     bd.f.dbg = nca_debug_stamp_ptr();
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), lds, st, bd);
-#else
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), lds, st, ba);
 #endif
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (BFM) hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<uint16_t>, dim3(ba.nblk), dim3(256), 0, st, ba);
-    else hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<float>, dim3(ba.nblk), dim3(256), 0, st, ba);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kB2Threads), lds, st, bd);
     return hipGetLastError();
 }
 
-}  // namespace
-
-int nca_cond_bwd_slab_floats(int C, int hidden) { return slab_floats(C, hidden); }
-int nca_cond_bwd_nslab() { return nca_cu_count(); }   // one persistent workgroup (and one slab) per CU
-int nca_cond_bwd_nblk(int B, int C, int H, int W) { return B * C * ((((H + SROWS - 1) / SROWS) * (W / 4) + 255) / 256); }
-
-static bool g_bwd_bf16_exact = getenv("NCAHIP_BWD_BF16_EXACT") != nullptr;
-void nca_set_bwd_bf16_exact(bool on) { g_bwd_bf16_exact = on; }
-void nca_set_bwd_variant(int v) { g_bwd_variant = v; }
-
-// W % 4 == 0 and 16-byte aligned tensors required (checked by the C ABI).
-hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st, bool bf16) {
-    if (bf16) {   // history (f.x_in, x_next) and goal hold bf16; gradients and scratch stay f32
-        if (g_bwd_bf16_exact) {   // test hook: exact-f32 recomputation from the widened history
-            if (ba.f.C <= 12) return launch_bwd<12, StBF16>(ba, st);
-            if (ba.f.C <= 16) return launch_bwd<16, StBF16>(ba, st);
-            return hipErrorInvalidValue;
-        }
-        if (ba.f.C <= 12) return launch_bwd<12, StBF16, true>(ba, st);
-        if (ba.f.C <= 16) return launch_bwd<16, StBF16, true>(ba, st);
-        return hipErrorInvalidValue;
+// kernel A, two-waves-per-SIMD form (kernel B is launched by the caller).  bf16: 0 = f32 history, 1 = bf16 history with
+// exact-f32 products, 2 = bf16 history with the products on bf16 MFMA.
+hipError_t nca_launch_cond_step_bwd_a2(const NcaCondBwdArgs& ba, hipStream_t st, int mode) {
+    const bool c12 = ba.f.C <= 12;
+    if (ba.f.C > 16) return hipErrorInvalidValue;
+    switch (mode) {
+        case 0: return c12 ? launch_a2<12, StF32, false>(ba, st) : launch_a2<16, StF32, false>(ba, st);
+        case 1: return c12 ? launch_a2<12, StBF16, false>(ba, st) : launch_a2<16, StBF16, false>(ba, st);
+        case 2: return c12 ? launch_a2<12, StBF16, true>(ba, st) : launch_a2<16, StBF16, true>(ba, st);
     }
-    if (ba.f.C <= 12) return launch_bwd<12, StF32>(ba, st);
-    if (ba.f.C <= 16) return launch_bwd<16, StF32>(ba, st);
     return hipErrorInvalidValue;
-}
-
-hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st, bool accumulate) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((m + 15) / 16), dim3(256), 0, st, src, dst, n, m, accumulate ? 1 : 0);
-    return hipGetLastError();
-}
-hipError_t nca_launch_reduce_wp(const float* part, float* dst, int B, int C, int H, int W, hipStream_t st) {
-    const int bpp = (((H + SROWS - 1) / SROWS) * (W / 4) + 255) / 256;
-    hipLaunchKernelGGL(reduce_wp_kernel, dim3(C), dim3(64), 0, st, part, dst, B, C, bpp);
-    return hipGetLastError();
 }
