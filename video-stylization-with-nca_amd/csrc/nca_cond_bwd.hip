@@ -27,7 +27,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
     constexpr int NT = 2;
     const NcaCondArgs& a = ba.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, lane_w = lane;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C = a.C, H = a.H, W = a.W, hid = a.hidden, K1 = 3 * C;
     const unsigned plane = (unsigned)(H * W);
@@ -170,6 +170,9 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
     const int halo = a.alive_ch >= 0 ? 3 : 1;
     const bool use_alive = a.alive_ch >= 0;
     for (NcaTileWalk tw = nca_tile_walk(a.B * st_x * st_y); tw.t < tw.end; tw.t += tw.stride) {
+        int lane = lane_w;   // opaque per tile: lane-derived offsets are recomputed where used, not hoisted out of the tile loop and spilled
+        asm volatile("" : "+v"(lane));
+        const int g = (lane >> 4) & 3, ci = lane & 15;
         WTile t;
         t.b = tw.t / (st_x * st_y);
         t.ty0 = ((tw.t / st_x) % st_y) * BSTH + wave * WTH;
@@ -994,7 +997,7 @@ int g_bwd2_prio = [] { const char* e = getenv("NCAHIP_BWD2_PRIO"); return e ? at
 
 template <int CP, typename ST, bool BFM = false>
 hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
-    if (g_bwd_variant == 0) {   // default: kernel A with a data-path wave and a weight-gradient wave per SIMD
+    if (g_bwd_variant == 1) {   // cross-check form: kernel A with a data-path wave and a weight-gradient wave per SIMD (nca_cond_bwd2.hip; measured slower)
         NcaCondBwdArgs b2 = ba;
         b2.prio = g_bwd2_prio;
         if (hipError_t e = nca_launch_cond_step_bwd_a2(b2, st, BFM ? 2 : (ST::BYTES == 2 ? 1 : 0)); e != hipSuccess) return e;
