@@ -324,3 +324,40 @@ def test_bf16x3_precision_mode(ops, C, shape, gch):
     assert ee < 5e-6 and es > ee                 # and it is NOT the exact path
     with pytest.raises(Exception):
         ops.set_cond_precision(7)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,shape,gch,Tn", [(16, (2, 80, 112), 12, 3), (12, (1, 36, 52), 8, 2)])
+def test_cond_backward_two_wave_form_equals_one_wave(ops, dtype, C, shape, gch, Tn):
+    """Backward kernel A exists in two forms (csrc/nca_cond_bwd.hip: one wave per SIMD, every product in one wave;
+    csrc/nca_cond_bwd2.hip: a data-path wave and a weight-gradient wave per SIMD, hand-offs through LDS).  They issue the same
+    products in the same per-wave order, so everything but the fp32 bias sums (taken from the operand rows in the two-wave
+    form: another fixed order) must agree BIT FOR BIT -- on evolving life masks, image borders (ragged sizes) included.  Both
+    forms are checked against the oracle by the kernel-family fixture of test_gpu_parity.py; this pins them to each other."""
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(7 * C + Tn)
+    from test_gpu_parity import rand_cond_prm
+    prm = rand_cond_prm(C, seed=C + 5, out_scale=1.0)
+    x0 = bfr(torch.rand(B, C, H, W, generator=gen))
+    x0[0, :, : H // 3] = 0.0
+    goal = bfr(torch.randn(B, gch, H, W, generator=gen) * 0.5)
+    us = torch.rand(Tn, B, 1, H, W, generator=gen)
+    cot = torch.randn(B, C, H, W, generator=gen)
+    xd, gd, ud, cd = x0.to(DEV).to(dtype), goal.to(DEV).to(dtype), us.to(DEV), cot.to(DEV)
+    w = weights(ops, prm, xd)
+    _, states, pre = ops.cond_grow(xd, Tn, gd, ud, w, 3, keep_history=True)
+    res = []
+    try:
+        for form in (0, 8):
+            ops.force_generic(form)
+            res.append(ops.cond_grow_backward(states, pre, gd, ud, w, cd, Tn, 3))
+            ops.check_errors()
+    finally:
+        ops.force_generic(0)
+    one, two = res
+    for k in one:
+        if k in ("b1", "b2") and dtype == torch.float32:
+            d = float((one[k] - two[k]).abs().max()) / max(1e-12, float(one[k].abs().max()))
+            assert d <= 2e-6, (k, d)
+        else:
+            assert torch.equal(one[k], two[k]), k

@@ -1243,18 +1243,19 @@ __global__ __launch_bounds__(256) void dynca_step_bwd_stencil_kernel(const NcaDy
 // W % 4 == 0, 16-byte aligned planes: one thread per 4 W-contiguous cells.  Away from the image border the padding plays no
 // part and the adjoint is the correlation with the flipped filters (Sobel flips sign, the Laplacian is symmetric): three
 // rows of three planes, 16-byte loads plus the two edge cells (L1 hits: the neighbouring lanes fetch those lines).
-// The border band (two rows top and bottom, four columns left and right) is left to the kernel below: a few lanes of every
-// wave running the per-cell routine would hold the whole wave for its ~2000 instructions.
-__global__ __launch_bounds__(256) void dynca_step_bwd_stencil_vec_kernel(const NcaDyncaArgs a) {
+// The border band (two rows top and bottom, four columns left and right) is left to separate WORKGROUPS of the same launch
+// (dynca_bwd_border_block below): a few lanes of every wave running the per-cell routine would hold the whole wave for its
+// ~2000 instructions.
+__device__ __forceinline__ void dynca_bwd_vec_block(const NcaDyncaArgs& a, unsigned blk) {
     const int C = a.C, H = a.H, W = a.W, W4 = W >> 2;
     const size_t plane = (size_t)H * W;
-    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t id = (size_t)blk * blockDim.x + threadIdx.x;
     if (id >= (size_t)a.B * C * H * W4) return;
     const int x0 = (int)(id % W4) * 4, py = (int)((id / W4) % H), c = (int)((id / ((size_t)W4 * H)) % C),
               b = (int)(id / ((size_t)W4 * H * C));
     float* const out = a.g_out + ((size_t)b * C + c) * plane + (size_t)py * W + x0;
     // border band of two cells: with 'reflect' a border cell's out-of-range taps land one cell INSIDE the image
-    if (py < 2 || py > H - 3 || x0 < 4 || x0 + 8 > W) return;   // the border band belongs to dynca_step_bwd_stencil_border_kernel
+    if (py < 2 || py > H - 3 || x0 < 4 || x0 + 8 > W) return;   // the border band belongs to dynca_bwd_border_block
     const float* const dy = a.dybuf + (size_t)b * 4 * C * plane + (size_t)py * W + x0;
     float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.g_next) gv = *reinterpret_cast<const float4*>(a.g_next + ((size_t)b * C + c) * plane + (size_t)py * W + x0);
@@ -1359,10 +1360,10 @@ hipError_t nca_launch_dynca_step_fwd(const NcaDyncaArgs& a, hipStream_t st) {
 // bf16 state storage: x_in / x_out point at bf16 data (cond, uniforms, weights stay f32); same kernel, exact f32 compute,
 // round-to-nearest-even on store.  The 8-byte vector path needs W % 4 == 0 and 8-byte aligned planes.
 // the border band of every (b, c) plane, one thread per cell: 4 full rows + 8 columns of the H - 4 rows between them
-__global__ __launch_bounds__(256) void dynca_step_bwd_stencil_border_kernel(const NcaDyncaArgs a) {
+__device__ __forceinline__ void dynca_bwd_border_block(const NcaDyncaArgs& a, unsigned blk) {
     const int C = a.C, H = a.H, W = a.W;
     const int per_plane = 4 * W + 8 * (H - 4);
-    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t id = (size_t)blk * blockDim.x + threadIdx.x;
     if (id >= (size_t)a.B * C * per_plane) return;
     const int k = (int)(id % per_plane), c = (int)((id / per_plane) % C), b = (int)(id / ((size_t)per_plane * C));
     int py, px;
@@ -1376,6 +1377,13 @@ __global__ __launch_bounds__(256) void dynca_step_bwd_stencil_border_kernel(cons
         px = j < 4 ? j : W - 8 + j;
     }
     a.g_out[((size_t)b * C + c) * (size_t)H * W + (size_t)py * W + px] = dynca_bwd_cell(a, b, c, py, px);
+}
+// One launch for both: the first nborder workgroups take the border band (their threads are the slow ones: dispatched first,
+// they run under the interior's memory traffic instead of after it -- as a launch of their own they were 19 us behind a 50 us
+// interior pass), the rest the interior.
+__global__ __launch_bounds__(256) void dynca_step_bwd_stencil_vec_kernel(const NcaDyncaArgs a, unsigned nborder) {
+    if (blockIdx.x < nborder) dynca_bwd_border_block(a, blockIdx.x);
+    else dynca_bwd_vec_block(a, blockIdx.x - nborder);
 }
 
 template <int CP, int FC, bool HAS_COND>
@@ -1448,9 +1456,9 @@ hipError_t nca_launch_dynca_step_bwd_stencil(const NcaDyncaArgs& a, hipStream_t 
                      aligned16(a.dybuf) && (a.g_extra == nullptr || aligned16(a.g_extra)) &&
                      (a.coarse_add == nullptr || (((uintptr_t)a.coarse_add & 7u) == 0 && a.H % 2 == 0));
     if (vec && a.H >= 5) {
-        hipLaunchKernelGGL(dynca_step_bwd_stencil_vec_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, a);
         const size_t nb = (size_t)a.B * a.C * (4 * a.W + 8 * (a.H - 4));
-        hipLaunchKernelGGL(dynca_step_bwd_stencil_border_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, a);
+        const unsigned nborder = (unsigned)((nb + 255) / 256), nvec = (unsigned)((n / 4 + 255) / 256);
+        hipLaunchKernelGGL(dynca_step_bwd_stencil_vec_kernel, dim3(nborder + nvec), dim3(256), 0, st, a, nborder);
     } else {
         hipLaunchKernelGGL(dynca_step_bwd_stencil_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     }
