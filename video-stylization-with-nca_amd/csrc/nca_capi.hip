@@ -638,7 +638,8 @@ size_t ncahip_cond_grow_bwd_workspace(int B, int C, int H, int W, int hidden) {
     const size_t n = (size_t)B * C * H * W * sizeof(float);
     return 4 * align256(n) + align256(3 * n) +
            align256((size_t)(nca_cond_bwd_nslab() + 1) * nca_cond_bwd_slab_floats(C, hidden) * sizeof(float)) +
-           align256((size_t)nca_cond_bwd_nblk(B, C, H, W) * 27 * sizeof(float));
+           align256((size_t)nca_cond_bwd_nblk(B, C, H, W) * 27 * sizeof(float)) +
+           align256(nca_cond_bwd_fm_pscr_bytes(B, H, W)) + align256(nca_cond_bwd_fm_doscr_bytes(B, H, W));
 }
 
 // states / goal: fp32 or bf16 (sb = bytes per element); everything else fp32
@@ -676,7 +677,9 @@ static int cond_grow_bwd_impl(const void* states_v, int sb, const uint8_t* pre, 
     float* slabs = (float*)p;
     float* red = slabs + (size_t)nslab * sf;  // one extra slab: the reduced gradients
     p += align256((size_t)(nslab + 1) * sf * sizeof(float));
-    float* wpp = (float*)p;
+    float* wpp = (float*)p; p += align256((size_t)nblk * 27 * sizeof(float));
+    void* pscr = p; p += align256(nca_cond_bwd_fm_pscr_bytes(B, H, W));   // front kernel -> matrix kernel scratch (operand order)
+    void* doscr = p;
     hipError_t e = hipMemsetAsync(slabs, 0, (size_t)nslab * sf * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(wpp, 0, (size_t)nblk * 27 * sizeof(float), st);
     if (e == hipSuccess && goal_ch > 0) e = hipMemsetAsync(g_goal, 0, (size_t)B * goal_ch * H * W * sizeof(float), st);
@@ -694,6 +697,7 @@ static int cond_grow_bwd_impl(const void* states_v, int sb, const uint8_t* pre, 
         ba.g_out = t == 0 ? g_x0 : gbuf[t & 1];
         ba.gx = gx; ba.dP = dP; ba.zbuf = zbuf; ba.dgoal = g_goal; ba.slabs = slabs; ba.wp_partials = wpp;
         ba.nslab = nslab; ba.nblk = nblk;
+        ba.pscr = pscr; ba.doscr = doscr;
         if (int rc = hip_result(nca_launch_cond_step_bwd(ba, st, bf16), "cond_grow_bwd step")) return rc;
         gcur = ba.g_out;
     }

@@ -1,28 +1,233 @@
-// nca_cond_bwd.hip -- backward of one ConditionedNCA step (EncoderConditioning/nca.py:181-195 under
-// autograd, conditioned_trainer.py:125-132), gfx950, fp32.
+// nca_cond_bwd_fm.hip -- backward kernel A of one ConditionedNCA step split by WORK instead of by wave (EncoderConditioning/
+// nca.py:181-195 under autograd, conditioned_trainer.py:125-132), gfx950.
 //
-// Recomputation design: only the pending states x'_t and the 1-byte pre masks are kept by
-// the forward pass.  Per step, two launches:
-//   A  cond_step_bwd_kernel   wave-private 4x16 tiles, same staging as the forward kernel (resolve s_t, pre_t,
-//      z_t in LDS).  The forward MLP is recomputed on MFMA with h1/h2 kept in registers; the incoming gradient
-//      is gated by life_t and the clamp pass-band (closed interval, as torch.clamp) -> dL/dx'_t; the data path
-//      runs back through W3^T, W2^T, W1^T on MFMA (accumulator tile == next B operand, as in the forward);
-//      weight gradients are MFMA products with the CELL axis as K: each 16-cell tile's activations are
-//      transposed through an 18-float-stride LDS buffer (conflict-free operand reads) and accumulated in 128
-//      persistent accumulator registers, flushed once per launch into this wave's slab (deterministic).
-//      Outputs dL/dperception [B,3C,H,W], dL/dx'_t and z_t.
-//   B  cond_step_bwd_stencil_kernel   HBM-bound: dL/ds_t = dL/dx'_t + depthwise-stencil^T(dL/dperception),
-//      dL/dgoal += dz * pre_t, per-block partials of the perception-weight gradient.
-// One wave per SIMD (the persistent accumulators need the registers); 4 waves / workgroup / CU.
+// nca_cond_bwd.hip's kernel A does everything for a tile in one wave at one wave per SIMD (the 128 weight-gradient
+// accumulators pin it there): a third of its time is the FRONT of the tile -- 45 loads, the pending-mask chain, gate,
+// perception -- an instruction- and latency-bound stream that nothing overlaps.  Here the front is its own launch:
+//   F  cond_step_bwd_front_kernel   no accumulators, ~130 registers, several waves per SIMD: stages the tile exactly as the
+//      forward does (s_t, pre_t, z_t, fire mask), writes z_t and dL/dx'_t = G * gate for kernel B, and leaves the two things the
+//      matrix part needs in a scratch laid out in MFMA-operand order: the perception vector P (lane-major: the 16-byte value
+//      a lane stores is the B operand it will load) and dO = dL/dx'_t * fire mask ([row tile][channel][cell]).
+//   M  cond_step_bwd_mlp_kernel     the matrix part (forward recomputation from P, W3^T/W2^T/W1^T, the three weight-gradient
+//      products, dL/dperception out): per-cell work with no halo, no masks, no Philox; its only loads are 4 coalesced
+//      16-byte reads per 16-cell row.  Same products in the same per-wave order as the one-launch kernel: bitwise the same
+//      weight gradients.
+// Cost: P and dO cross HBM once (256 B/cell fp32, 128 B/cell bf16).  Kernel B (stencil adjoint) is unchanged.
 #include <cstdlib>
 
 #include "nca_cond_bwd_common.h"
 
 namespace {
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// F: front kernel.  One workgroup = one 16 x 16 super-tile, 4 waves, wave-private 4 x 16 tiles; 2-3 workgroups per CU.
+constexpr int kFrontWaves = 4, kFrontThreads = 256;
+#ifndef FM_OCC
+#define FM_OCC 2
+#endif
+template <int CP>
+struct FrontCfg {
+    using F = WCfg<CP>;
+    static constexpr int PW_Z = 0;                              // z halo 1: [CP][6][RS]
+    static constexpr int PW_A3 = CP * CS;                       // alpha' halo 3 (10 rows); later rows 0-5 = PN, rows 6-9 = fire mask
+    static constexpr int PW_LIFE = PW_A3 + (WTH + 6) * RS;
+    static constexpr int PW_A2 = PW_LIFE + (WTH + 4) * RS;
+    static constexpr int PW_A1 = PW_A2 + (WTH + 4) * RS;        // alpha of the pending x'_t, halo 1
+    static constexpr int PW = PW_A1 + ZROWS * RS;
+    static constexpr int OFF_WP = kFrontWaves * PW;             // behind the tiles: perceive_tile addresses it as WS + F::OFF_WP
+    static_assert(OFF_WP >= F::OFF_WP, "WS = smem + OFF_WP - F::OFF_WP stays inside the allocation");
+    static constexpr int LDS_FLOATS = OFF_WP + CP * F::WPS;
+    static_assert(PW % 4 == 0 && PW_A3 % 4 == 0, "16-byte carve");
+};
+
+template <int CP, typename ST, bool BFM>
+__global__ __launch_bounds__(kFrontThreads, FM_OCC) void cond_step_bwd_front_kernel(const NcaCondBwdArgs ba) {
+    using K = FrontCfg<CP>;
+    using FK = WCfg<CP>;
+    const NcaCondArgs& a = ba.f;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = a.C, H = a.H, W = a.W;
+    const unsigned plane = (unsigned)(H * W);
+    {
+        FillRegs<CP * FK::WPS, kFrontThreads> fr;
+        fill_load(fr, a.wp, tid, [&](int idx) -> long {
+            const int ch = idx / FK::WPS, j = idx % FK::WPS;
+            return (ch < C && j < 27) ? (long)ch * 27 + j : -1;
+        });
+        fill_store(fr, smem + K::OFF_WP, tid);
+    }
+    __syncthreads();
+    const float* const WS = smem + K::OFF_WP - FK::OFF_WP;
+    float* const PWR = smem + wave * K::PW;
+    float* const Z = PWR + K::PW_Z;
+    float* const PN = PWR + K::PW_A3;
+    const float* const MK = PWR + K::PW_A3 + ZROWS * RS;
+    float* const A1 = PWR + K::PW_A1;
+    const TileLds L{Z, nullptr, PWR + K::PW_A3, PWR + K::PW_A3, PWR + K::PW_LIFE, PWR + K::PW_A2, PWR + K::PW_A3 + ZROWS * RS};
+
+    // super-tile of this workgroup: consecutive super-tiles go to the same XCD (workgroups are dealt round-robin over 8 XCDs)
+    const int st_x = (W + 15) / 16, st_y = (H + 15) / 16, nst = a.B * st_x * st_y;
+    const int chunk = (nst + 7) / 8, sidx = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || sidx >= nst) return;
+    const int halo = a.alive_ch >= 0 ? 3 : 1;
+    const bool use_alive = a.alive_ch >= 0;
+    WTile t;
+    t.b = sidx / (st_x * st_y);
+    t.ty0 = ((sidx / st_x) % st_y) * 16 + wave * WTH;
+    t.tx0 = (sidx % st_x) * 16;
+    if (t.ty0 >= H || t.tx0 >= W) return;
+    t.valid = true;
+    t.inner = t.ty0 >= halo && t.ty0 + WTH + halo <= H && t.tx0 >= halo && t.tx0 + WTW + halo <= W;
+    const int ty0 = t.ty0, tx0 = t.tx0;
+    const size_t rid0 = ((size_t)sidx * kFrontWaves + wave) * WTH;   // scratch row tiles of this wave (as kernel M computes them)
+
+    // ---- every global load of the tile up front: pending x'_t (alpha halo 1 + interior), incoming gradient, forward operands
+    const char* const xn = reinterpret_cast<const char*>(ba.x_next) + (size_t)t.b * C * plane * ST::BYTES;
+    const float* const gn = ba.g_next + (size_t)t.b * C * plane;
+    const int g = lane >> 4, hl = (lane >> 5) & 1, l5 = lane & 31;
+    const int row = (lane >> 2) & 3, ff = lane & 3;
+    const bool ok = ty0 + row < H && tx0 + 4 * ff + 3 < W;
+    const unsigned off = ok ? (unsigned)((ty0 + row) * W + tx0 + 4 * ff) : 0u;
+    typename ST::raw1 av[3];
+    bool aok[3];
+    if (use_alive) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int gy = ty0 - 1 + 2 * k + hl, gx = tx0 - 1 + l5;
+            aok[k] = l5 < 18 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            av[k] = ST::gld1(xn, (unsigned)a.alive_ch * plane + (aok[k] ? (unsigned)(gy * W + gx) : 0u));
+        }
+    }
+    typename ST::raw4 xv[CP / 4];
+    f32x4 gv[CP / 4];
+#pragma unroll
+    for (int k = 0; k < CP / 4; ++k) {
+        const unsigned ch = (unsigned)min(4 * k + g, C - 1);
+        xv[k] = ST::gld4(xn, ch * plane + off);
+        gv[k] = ld4(gn + ch * plane + off);
+    }
+    // ---- forward staging: pre_t (PN), z_t (Z), fire mask (MK); the resolved-state copy is not needed here
+    {
+        TileRegs<CP, ST> R;
+        if (t.inner) {
+            issue_loads<CP, true, true, 0, false, ST>(a, t, lane, R);
+            stage_tile<CP, false, false, ST, false>(a, t, L, lane, R, 0);
+        } else {
+            issue_loads<CP, true, true, 1, false, ST>(a, t, lane, R);
+            stage_tile<CP, true, false, ST, false>(a, t, L, lane, R, 0);
+        }
+    }
+    // ---- alpha of the pending state -> A1 (post mask of this step);  z_t interior out (kernel B's perception-weight gradient)
+    if (use_alive) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (l5 < 18) A1[(2 * k + hl) * RS + l5 + 3] = aok[k] ? ST::cv1(av[k]) : NCA_NEG_INF;
+    }
+    {
+        float* const zo = ba.zbuf + (size_t)t.b * C * plane + off;
+        uint16_t* const zo16 = reinterpret_cast<uint16_t*>(ba.zbuf) + (size_t)t.b * C * plane + off;
+#pragma unroll
+        for (int k = 0; k < CP / 4; ++k) {
+            const int ch = 4 * k + g;
+            const f32x4 zv = ld4(Z + ch * CS + (row + 1) * RS + 4 + 4 * ff);
+            if (ok && ch < C) {
+                if constexpr (BFM) *reinterpret_cast<u32x2*>(zo16 + (unsigned)ch * plane) = u32x2{pk_bf16(zv[0], zv[1]), pk_bf16(zv[2], zv[3])};
+                else st4(zo + (unsigned)ch * plane, zv);
+            }
+        }
+    }
+    wave_sync();
+    // ---- gate, in the layout the loads arrived in (lane = channel 4k+g, row, cells 4ff..4ff+3):
+    //      dL/dx'_t = G * 1[lo <= x'*life <= hi] * life (nca.py:191-194) -> gx;  dO = . * fire mask -> scratch
+    {
+        const f32x4 pnv = ld4(PN + (row + 1) * RS + 4 + 4 * ff);
+        const f32x4 mk = ld4(MK + row * WTW + 4 * ff);
+        float lf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float life = pnv[j];
+            if (use_alive) life = (life != 0.0f && max3x3(A1 + (row + 1) * RS + 4 * ff + j + 4) > a.thr) ? 1.0f : 0.0f;
+            lf[j] = life;
+        }
+        float* const go = ba.gx + (size_t)t.b * C * plane + off;
+        float* const dso = reinterpret_cast<float*>(ba.doscr) + (rid0 + row) * 256 + 4 * ff;
+        uint16_t* const dso16 = reinterpret_cast<uint16_t*>(ba.doscr) + (rid0 + row) * 256 + 4 * ff;
+#pragma unroll
+        for (int k = 0; k < CP / 4; ++k) {
+            const int ch = 4 * k + g;
+            const bool live = ok && ch < C;
+            const f32x4 x = ST::cv4(xv[k]);
+            f32x4 gxv, dov;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y = x[j] * lf[j];
+                gxv[j] = (live && y >= a.lo && y <= a.hi) ? gv[k][j] * lf[j] : 0.0f;
+                dov[j] = gxv[j] * mk[j];
+            }
+            if (live) st4(go + (unsigned)ch * plane, gxv);
+            if constexpr (BFM) *reinterpret_cast<u32x2*>(dso16 + ch * 16) = u32x2{pk_bf16(dov[0], dov[1]), pk_bf16(dov[2], dov[3])};
+            else st4(dso + ch * 16, dov);
+        }
+    }
+    // ---- perception of the four rows, stored as the B operands kernel M will load
+#pragma unroll 1
+    for (int n0 = 0; n0 < WTH; n0 += 2) {
+        float P[2][FK::K1S];
+#if defined(FM_NO_PERCEIVE)
+        for (int n = 0; n < 2; ++n) for (int s_ = 0; s_ < FK::K1S; ++s_) P[n][s_] = Z[lane + n + s_];
+#else
+        perceive_tile<CP, 2>(WS, Z, lane, n0, P);
+#endif
+#if defined(FM_NO_PSTORE)
+        if (P[0][0] + P[1][1] == 123.456f)
+#endif
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            if constexpr (BFM) {
+                bf_s16x4* const ps = reinterpret_cast<bf_s16x4*>(ba.pscr) + (rid0 + n0 + n) * 192 + lane;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = 4 * q + r < FK::K1S ? P[n][4 * q + r] : 0.0f;
+                    ps[q * 64] = pack4(v[0], v[1], v[2], v[3]);
+                }
+            } else {
+                f32x4* const ps = reinterpret_cast<f32x4*>(ba.pscr) + (rid0 + n0 + n) * 192 + lane;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = 4 * q + r < FK::K1S ? P[n][4 * q + r] : 0.0f;
+                    ps[q * 64] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// M: the matrix part.  4 waves / workgroup / CU (one wave per SIMD: 128 persistent accumulators), persistent over the tiles.
+template <int CP>
+struct MCfg {
+    using F = WCfg<CP>;
+    static constexpr int K1S = F::K1S;
+    static constexpr int MJ = (3 * CP + 15) / 16;
+    static constexpr int OFF_W3T = F::SHARED;               // [4 m][4 s][64]
+    static constexpr int OFF_W1T = OFF_W3T + 4 * 4 * 64;    // [MJ][16 s][64]
+    static constexpr int SHARED = OFF_W1T + MJ * 16 * 64;
+    static constexpr int PW = 16 * TBS;                     // transposition buffer, 16 cells x 148 rows
+    static constexpr int SLABS = kBwdWaves * (64 * 3 * CP + 64 * 64 + CP * 64 + 128);   // the flush stages four partial slabs
+    static constexpr int LDS_FLOATS = (SHARED + kBwdWaves * PW) > SLABS ? (SHARED + kBwdWaves * PW) : SLABS;
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+    static_assert(CP <= 16, "one 16-row output tile (M3T == 1)");
+};
+
 template <int CP, typename ST = StF32, bool BFM = false>
-__global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const NcaCondBwdArgs ba) {
-    using K = BCfg<CP>;
+__global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_mlp_kernel(const NcaCondBwdArgs ba) {
+    using K = MCfg<CP>;
     using FK = WCfg<CP>;
     constexpr int NT = 2;
     const NcaCondArgs& a = ba.f;
@@ -95,13 +300,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
     const float* const B2L = smem + FK::OFF_B2;
     const float* const W3T = smem + K::OFF_W3T;
     const float* const W1T = smem + K::OFF_W1T;
-    float* const PWR = smem + K::SHARED + wave * K::PW;
-    float* const Z = PWR + FK::PW_Z;
-    float* const XR = PWR + FK::PW_XR;
-    float* const PN = PWR + FK::PW_A3;
-    const float* const MK = PWR + FK::PW_A3 + ZROWS * RS;
-    float* const TB = PWR + K::PW_TB;
-    float* const A1 = PWR + K::PW_A1;
+    float* const TB = smem + K::SHARED + wave * K::PW;   // this wave's transposition buffer (the only per-wave LDS left)
 
     // BFM: bf16 A operands of every product, built once per launch from the f32 LDS images (same k orders as the f32 path) and
     // kept as ONE packed image in LDS, [operand][lane] x 8 bytes, over the (then dead) f32 images: 120 operand registers per
@@ -178,155 +377,44 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
         t.ty0 = ((tw.t / st_x) % st_y) * BSTH + wave * WTH;
         t.tx0 = (tw.t % st_x) * BSTW;
         if (t.ty0 >= H || t.tx0 >= W) continue;
-        t.valid = true;
-        t.inner = t.ty0 >= halo && t.ty0 + WTH + halo <= H && t.tx0 >= halo && t.tx0 + WTW + halo <= W;
         const int ty0 = t.ty0, tx0 = t.tx0;
-
         NCA_BPHASE(0);   // loop overhead / previous tile's tail
-        // ---- all global loads of the tile are requested up front (one HBM round trip per tile instead of two: with one
-        //      wave per SIMD nothing else hides it): forward operands, pending x'_t (alpha halo 1 + interior), incoming gradient
-        TileRegs<CP, ST> R;
-        issue_loads<CP, true, true, -1, false, ST>(a, t, lane, R);
-        const char* const xn = reinterpret_cast<const char*>(ba.x_next) + (size_t)t.b * C * plane * ST::BYTES;
-        const float* const gn = ba.g_next + (size_t)t.b * C * plane;
-        const int hl = (lane >> 5) & 1, l5 = lane & 31;
-        const int row = (lane >> 2) & 3, ff = lane & 3;
-        const bool ok = ty0 + row < H && tx0 + 4 * ff + 3 < W;
-        const unsigned off = ok ? (unsigned)((ty0 + row) * W + tx0 + 4 * ff) : 0u;
-        typename ST::raw1 av[3];
-        bool aok[3];
-        if (use_alive) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int gy = ty0 - 1 + 2 * k + hl, gx = tx0 - 1 + l5;
-                aok[k] = l5 < 18 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-                av[k] = ST::gld1(xn, (unsigned)a.alive_ch * plane + (aok[k] ? (unsigned)(gy * W + gx) : 0u));
-            }
-        }
-        typename ST::raw4 xv[CP / 4];
-        f32x4 gv[CP / 4];
-#pragma unroll
-        for (int k = 0; k < CP / 4; ++k) {
-            const unsigned ch = (unsigned)min(4 * k + g, C - 1);
-            xv[k] = ST::gld4(xn, ch * plane + off);
-            gv[k] = ld4(gn + ch * plane + off);
-        }
-        // ---- forward staging: s_t (XR), pre_t (PN), z_t (Z), fire mask (MK) -------------------------------
-        const TileLds L = wave_private_lds<CP>(PWR);
-        if (t.inner) stage_tile<CP, false, false, ST>(a, t, L, lane, R, 0);
-        else stage_tile<CP, true, false, ST>(a, t, L, lane, R, 0);
-        NCA_BPHASE(1);   // forward staging
-
-        // ---- pending x'_t: alpha halo 1 -> A1 (post mask), interior -> XR; incoming gradient -> TB --------
-        {
-            if (use_alive) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if (l5 < 18) A1[(2 * k + hl) * RS + l5 + 3] = aok[k] ? ST::cv1(av[k]) : NCA_NEG_INF;
-            }
-            // z_t interior out (kernel B needs it for the perception-weight gradient)
-            // (BFM: the two scratch tensors kernel B streams, z_t and dL/dperception, are stored as bf16: half the bytes)
-            float* const zo = ba.zbuf + (size_t)t.b * C * plane + off;
-            uint16_t* const zo16 = reinterpret_cast<uint16_t*>(ba.zbuf) + (size_t)t.b * C * plane + off;
-#pragma unroll
-            for (int k = 0; k < CP / 4; ++k) {
-                const int ch = 4 * k + g;
-                const f32x4 zv = ld4(Z + ch * CS + (row + 1) * RS + 4 + 4 * ff);
-                if (ok && ch < C) {
-                    if constexpr (BFM) *reinterpret_cast<u32x2*>(zo16 + (unsigned)ch * plane) = u32x2{pk_bf16(zv[0], zv[1]), pk_bf16(zv[2], zv[3])};
-                    else st4(zo + (unsigned)ch * plane, zv);
-                }
-            }
-            wave_sync();
-#pragma unroll
-            for (int k = 0; k < CP / 4; ++k) {
-                const int ch = 4 * k + g;
-                const bool live = ok && ch < C;
-                st4(XR + ch * XRS + row * WTW + 4 * ff, live ? ST::cv4(xv[k]) : f32x4{0.f, 0.f, 0.f, 0.f});
-                st4(TB + ch * XRS + row * WTW + 4 * ff, live ? gv[k] : f32x4{0.f, 0.f, 0.f, 0.f});
-            }
-            wave_sync();
-        }
-
-        // ---- warm the L2 for the NEXT tile: one 4-byte read per row segment it will load (state and goal rows with halo 1,
-        //      pending state and gradient rows).  There are no registers to hold the real loads a tile ahead (one wave per SIMD,
-        //      256 + 200 in use), but these need only a handful of landing registers: they are issued here, return during the
-        //      pass loop, and the tile's real requests then meet the L2 instead of HBM.  They are ordinary loads the compiler
-        //      tracks (issue pinned by the scheduling fence, values "consumed" by an empty asm after the pass loop): an
-        //      inline-asm load into a register the allocator may copy or re-use while the load is in flight is a race.
-        constexpr int NW1 = (8 * 2 * CP + 63) / 64, NW2 = (8 * CP + 63) / 64;
-        float warm[NW1 + NW2];
-#pragma unroll
-        for (int k = 0; k < NW1 + NW2; ++k) warm[k] = 0.0f;
-        if (tw.t + tw.stride < tw.end) {
-            const int tnx = tw.t + tw.stride, gch = a.goal_ch;
-            const int nb = tnx / (st_x * st_y), ny0 = ((tnx / st_x) % st_y) * BSTH + wave * WTH, nx0 = (tnx % st_x) * BSTW;
-            constexpr unsigned SB = ST::BYTES;      // state-type tensors are addressed in bytes; a 4-byte read of a bf16 row
-            // covers two elements (even column: aligned), which is fine: the value is never used
-            const char* const bx = reinterpret_cast<const char*>(a.x_in) + (size_t)nb * C * plane * SB;
-            const char* const bg = gch ? reinterpret_cast<const char*>(a.goal) + (size_t)nb * gch * plane * SB : bx;
-            const char* const bn = reinterpret_cast<const char*>(ba.x_next) + (size_t)nb * C * plane * SB;
-            const float* const bq = ba.g_next + (size_t)nb * C * plane;
-            const unsigned col = (unsigned)min(nx0, W - 1) & ~1u;
-            // state + goal planes: 8 rows each (ty0-1 ..; two more than needed keeps the index arithmetic to shifts)
-#pragma unroll
-            for (int k = 0; k < NW1; ++k) {
-                const int i = min(64 * k + lane, 8 * (C + gch) - 1), pl = i >> 3;
-                const unsigned rowo = (unsigned)min(max(ny0 + (i & 7) - 1, 0), H - 1) * (unsigned)W + col;
-                const char* const p = (pl < C ? bx + (size_t)((unsigned)pl * plane + rowo) * SB : bg + (size_t)((unsigned)(pl - C) * plane + rowo) * SB);
-                warm[k] = *reinterpret_cast<const float*>(p);
-            }
-            // pending state + incoming gradient: 4 rows each
-#pragma unroll
-            for (int k = 0; k < NW2; ++k) {
-                const int i = min(64 * k + lane, 8 * C - 1), pl = i >> 2;
-                const unsigned rowo = (unsigned)min(ny0 + (i & 3), H - 1) * (unsigned)W + col;
-                const void* const p = pl < C ? (const void*)(bn + (size_t)((unsigned)pl * plane + rowo) * SB)
-                                             : (const void*)(bq + (unsigned)(pl - C) * plane + rowo);
-                warm[NW1 + k] = *reinterpret_cast<const float*>(p);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // the requests stay HERE (not sunk to their "use" after the pass loop)
-        NCA_BPHASE(2);   // x'/g loads, z out
-        // ---- dL/dx'_t = G * 1[lo <= x'*life <= hi] * life (nca.py:191-194);  d out = . * fire mask.  All four
-        //      rows now: TB (the staged incoming gradient) is reused for the transposes inside the pass loop.
-        float dOall[WTH][4];
-        {
-            // reads of all four rows first, then the arithmetic and the XR write-back: with the write-back inside the row loop
-            // every row's reads waited behind the previous row's stores (possible aliases) -- four exposed LDS round trips
-            float lifev[WTH], mkv[WTH], xr[WTH][4], gr[WTH][4];
-#pragma unroll
-            for (int row = 0; row < WTH; ++row) {
-                float life = PN[(row + 1) * RS + ci + 4];
-                if (use_alive) life = (life != 0.0f && max3x3(A1 + (row + 1) * RS + ci + 4) > a.thr) ? 1.0f : 0.0f;
-                lifev[row] = life;
-                mkv[row] = MK[row * WTW + ci];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ch = 4 * g + r;
-                    xr[row][r] = ch < CP ? XR[ch * XRS + row * WTW + ci] : 0.0f;   // XR / TB hold CP channel planes
-                    gr[row][r] = ch < CP ? TB[ch * XRS + row * WTW + ci] : 0.0f;
-                }
-            }
-#pragma unroll
-            for (int row = 0; row < WTH; ++row)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ch = 4 * g + r;
-                    const float y = xr[row][r] * lifev[row];
-                    const float gxv = (ch < C && y >= a.lo && y <= a.hi) ? gr[row][r] * lifev[row] : 0.0f;
-                    if (ch < CP) XR[ch * XRS + row * WTW + ci] = gxv;  // XR now carries dL/dx'_t for the 16-byte store pass
-                    dOall[row][r] = gxv * mkv[row];
-                }
-        }
-        NCA_BPHASE(3);   // gate
+        const size_t rid0 = ((size_t)tw.t * kBwdWaves + wave) * WTH;   // 16-cell row tiles of the front kernel's scratch
 #pragma unroll 1
         for (int pass = 0; pass < WTH / NT; ++pass) {
             const int n0 = pass * NT;
             // ---- forward recompute: P, h1, h2 kept in registers ------------------------------------------
-            float P[NT][K::K1S];
-            perceive_tile<CP, NT>(smem, Z, lane, n0, P);
-            NCA_BPHASE(4);   // perception
+            // ---- this pass's two 16-cell rows from the front kernel's scratch: the perception vector in B-operand order
+            //      ([row tile][4-slot group][lane] x 16 B, or x 8 B of bf16) and the gated gradient dO = dL/dx' * fire mask
+            //      ([row tile][channel][cell]) -------------------------------------------------------------------------
+            float P[NT][12];
+            float dOin[NT][4];
+            bf_s16x4 pbin[NT][3];
+            if constexpr (BFM) {
+                const bf_s16x4* const ps = reinterpret_cast<const bf_s16x4*>(ba.pscr) + (rid0 + n0) * 192 + lane;
+                const uint16_t* const ds = reinterpret_cast<const uint16_t*>(ba.doscr) + (rid0 + n0) * 256 + 64 * g + ci;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) pbin[n][q] = ps[n * 192 + q * 64];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dOin[n][r] = 4 * g + r < CP ? __uint_as_float((unsigned)ds[n * 256 + 16 * r] << 16) : 0.0f;
+                }
+            } else {
+                const f32x4* const ps = reinterpret_cast<const f32x4*>(ba.pscr) + (rid0 + n0) * 192 + lane;
+                const float* const ds = reinterpret_cast<const float*>(ba.doscr) + (rid0 + n0) * 256 + 64 * g + ci;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const f32x4 v = ps[n * 192 + q * 64];
+                        P[n][4 * q] = v[0]; P[n][4 * q + 1] = v[1]; P[n][4 * q + 2] = v[2]; P[n][4 * q + 3] = v[3];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dOin[n][r] = 4 * g + r < CP ? ds[n * 256 + 16 * r] : 0.0f;
+                }
+            }
+            NCA_BPHASE(4);   // scratch loads
             f32x4 dp[K::MJ][NT];
             if constexpr (BFM) {
                 short* const tb16 = reinterpret_cast<short*>(TB);
@@ -335,12 +423,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
-                    for (int s_ = 0; s_ < KS1; ++s_) {
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = 4 * s_ + r < K::K1S ? P[n][4 * s_ + r] : 0.0f;
-                        pb[n][s_] = pack4(v[0], v[1], v[2], v[3]);
-                    }
+                    for (int s_ = 0; s_ < KS1; ++s_) pb[n][s_] = pbin[n][s_];
                 f32x4 h1f[4][NT], h2f[4][NT];              // pre-ReLU accumulators (gates), f32
                 bf_s16x4 h1b[4][NT], h2b[4][NT];           // ReLU'd, bf16: operands of layer 2 / 3 and of the weight gradients
 #pragma unroll
@@ -370,10 +453,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
                 NCA_BPHASE(5);   // forward recompute
                 bf_s16x4 dOb[NT];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int rw = pass ? NT + n : n;
-                    dOb[n] = pack4(dOall[rw][0], dOall[rw][1], dOall[rw][2], dOall[rw][3]);
-                }
+                for (int n = 0; n < NT; ++n) dOb[n] = pack4(dOin[n][0], dOin[n][1], dOin[n][2], dOin[n][3]);   // (bf16 values: exact)
                 bf_s16x4 d2b[4][NT], d1b[4][NT];
                 // ---- layer 3: dW3 += dO x h2 (cells as K);  d2 = (W3^T dO) * 1[h2 > 0] ---------------------------------------
 #pragma unroll
@@ -516,7 +596,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dO[n][r] = pass ? dOall[NT + n][r] : dOall[n][r];
+                for (int r = 0; r < 4; ++r) dO[n][r] = dOin[n][r];
             // Backward data path and weight gradients, layer by layer from the output: each layer's weight-gradient product
             // is issued as soon as its two factors exist, so h2 dies after layer 3, d2 and h1 after layer 2, P and d1 after
             // layer 1 (all five tiles alive at once through a separate weight-gradient phase cost 36 spilled registers).
@@ -699,21 +779,6 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             }
             NCA_BPHASE(9);   // dP out
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < NW1 + NW2; ++k) asm volatile("" ::"v"(warm[k]));   // the warm-up reads have long returned
-        // ---- dL/dx'_t out (XR), 16-byte stores ---------------------------------------------------------------
-        wave_sync();
-        {
-            const int row = (lane >> 2) & 3, ff = lane & 3, gy = ty0 + row, gx = tx0 + 4 * ff;
-            const bool ok = gy < H && gx + 3 < W;
-            float* const go = ba.gx + (size_t)t.b * C * plane + (ok ? (unsigned)(gy * W + gx) : 0u);
-#pragma unroll
-            for (int k = 0; k < CP / 4; ++k) {
-                const int ch = 4 * k + g;
-                if (ok && ch < C) st4(go + (unsigned)ch * plane, ld4(XR + ch * XRS + row * WTW + 4 * ff));
-            }
-        }
         wave_sync();
     }
 
@@ -792,280 +857,50 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
 #endif
 }
 
-// Kernel B: dL/ds_t = dL/dx'_t + stencil^T(dL/dP);  dL/dgoal += dz * pre_t;  perception-weight partials.
-// One thread = 4 W-contiguous cells x a strip of SROWS rows of one (b, c) plane, walked top to bottom with a
-// three-row sliding window held in registers: every row of z / dL/dP is loaded once per thread (16-byte loads,
-// left/right neighbours by wavefront shuffle with a scalar fallback at row/wave edges), and the 27 perception-weight
-// sums are reduced across the block once per strip.  A block never spans two channels.
-constexpr int SROWS = 16;
-struct Row6 { float v[6]; };   // columns x0-1 .. x0+4
 
-// Two-stage row fetch: issue (raw 16-byte group + the two edge cells that have no neighbour lane) and finish (shuffle the
-// neighbours' edge values in).  Anything that touches the loaded value belongs to finish -- a shuffle at issue time waits
-// for the load and defeats the prefetch.
-struct RawRow {
-    float4 c;
-    float el, er;
-    bool in;
-};
-__device__ __forceinline__ RawRow issue_row6(const float* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r) {
-    RawRow r;
-    r.in = y >= 0 && y < H;
-    const float* const row = plane + (size_t)(r.in ? y : 0) * W;
-    r.c = *reinterpret_cast<const float4*>(row + x0);
-    r.el = 0.0f;
-    r.er = 0.0f;
-    if (!has_l && x0 > 0) r.el = row[x0 - 1];
-    if (!has_r && x0 + 4 < W) r.er = row[x0 + 4];
-    return r;
-}
-// bf16 scratch (the BFM backward): 8-byte group + 2-byte edges, widened on arrival (the widening touches the loaded value, so a
-// row issued two rows ahead pays no wait here either: the compiler places the wait at the first shift)
-__device__ __forceinline__ RawRow issue_row6(const uint16_t* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r) {
-    RawRow r;
-    r.in = y >= 0 && y < H;
-    const uint16_t* const row = plane + (size_t)(r.in ? y : 0) * W;
-    const u32x2 c = *reinterpret_cast<const u32x2*>(row + x0);
-    unsigned el = 0u, er = 0u;
-    if (!has_l && x0 > 0) el = row[x0 - 1];
-    if (!has_r && x0 + 4 < W) er = row[x0 + 4];
-    r.c = make_float4(__uint_as_float(c[0] << 16), __uint_as_float(c[0] & 0xffff0000u), __uint_as_float(c[1] << 16), __uint_as_float(c[1] & 0xffff0000u));
-    r.el = __uint_as_float(el << 16);
-    r.er = __uint_as_float(er << 16);
-    return r;
-}
-__device__ __forceinline__ Row6 finish_row6(const RawRow& q, bool has_l, bool has_r) {
-    Row6 r;
-    const float z = q.in ? 1.0f : 0.0f;   // rows outside the image read row 0 and are zeroed here
-    float l = __shfl_up(q.c.w, 1), rr = __shfl_down(q.c.x, 1);
-    if (!has_l) l = q.el;
-    if (!has_r) rr = q.er;
-    r.v[0] = l * z; r.v[1] = q.c.x * z; r.v[2] = q.c.y * z; r.v[3] = q.c.z * z; r.v[4] = q.c.w * z; r.v[5] = rr * z;
-    return r;
-}
-template <typename ET>
-__device__ __forceinline__ Row6 load_row6(const ET* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r) {
-    return finish_row6(issue_row6(plane, H, W, y, x0, has_l, has_r), has_l, has_r);
-}
-
-// ET = element type of the two scratch tensors kernel A wrote (z_t, dL/dperception): float, or uint16_t (bf16) behind the BFM kernel A
-template <typename ET>
-__global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCondBwdArgs ba) {
-    const NcaCondArgs& a = ba.f;
-    const int C = a.C, H = a.H, W = a.W;
-    const size_t plane = (size_t)H * W;
-    const int W4 = W / 4, strips = (H + SROWS - 1) / SROWS;
-    const int per_plane = strips * W4, blocks_per_plane = (per_plane + 255) / 256;
-    const int bc = blockIdx.x / blocks_per_plane, b = bc / C, c = bc % C;
-    const int id = (blockIdx.x % blocks_per_plane) * 256 + threadIdx.x;
-    const bool active = id < per_plane;
-    const int ida = active ? id : per_plane - 1;      // inactive lanes shadow the last item (they still shuffle)
-    const int x0 = (ida % W4) * 4, y0 = (ida / W4) * SROWS;
-    const int lane = threadIdx.x & 63;
-    const bool has_l = x0 > 0 && lane > 0, has_r = x0 + 4 < W && lane < 63 && id + 1 < per_plane;
-    float wl[27];
-#pragma unroll
-    for (int i = 0; i < 27; ++i) wl[i] = a.wp[(size_t)c * 27 + i];
-    const ET* const zb = reinterpret_cast<const ET*>(ba.zbuf) + ((size_t)b * C + c) * plane;
-    const ET* const p0 = reinterpret_cast<const ET*>(ba.dP) + ((size_t)b * 3 * C + 3 * c) * plane;
-    float wsum[27];
-#pragma unroll
-    for (int i = 0; i < 27; ++i) wsum[i] = 0.f;
-    const int gch0 = C - a.goal_ch;
-    // window rows: index 0 = y-1, 1 = y, 2 = y+1; row y+2 (zn / pn) is loaded while row y is computed, so no load
-    // is consumed in the iteration that issues it
-    Row6 zw[3], pw[3][3];
-    RawRow zn, pn[3];
-    zw[0] = load_row6(zb, H, W, y0 - 1, x0, has_l, has_r);
-    zw[1] = load_row6(zb, H, W, y0, x0, has_l, has_r);
-    zw[2] = load_row6(zb, H, W, y0 + 1, x0, has_l, has_r);
-#pragma unroll
-    for (int f = 0; f < 3; ++f) {
-        pw[f][0] = load_row6(p0 + (size_t)f * plane, H, W, y0 - 1, x0, has_l, has_r);
-        pw[f][1] = load_row6(p0 + (size_t)f * plane, H, W, y0, x0, has_l, has_r);
-        pw[f][2] = load_row6(p0 + (size_t)f * plane, H, W, y0 + 1, x0, has_l, has_r);
-    }
-    // the row's own read-modify-write operands (dL/dx', dL/dgoal, pre mask) are requested one row ahead as well
-    const bool goal_ch = c >= gch0, use_pre = goal_ch && a.alive_ch >= 0;
-    const float* const gxp = ba.gx + ((size_t)b * C + c) * plane + x0;
-    float* const gop = ba.g_out + ((size_t)b * C + c) * plane + x0;
-    float* const dgp = goal_ch ? ba.dgoal + ((size_t)b * a.goal_ch + (c - gch0)) * plane + x0 : nullptr;
-    const uint8_t* const prp = use_pre ? ba.pre_t + (size_t)b * plane + x0 : nullptr;
-    float4 gxn = make_float4(0.f, 0.f, 0.f, 0.f), dgn = gxn;
-    uchar4 pbn = make_uchar4(1, 1, 1, 1);
-    auto issue_rmw = [&](int y) {
-        const size_t ro = (size_t)min(y, H - 1) * W;
-        gxn = *reinterpret_cast<const float4*>(gxp + ro);
-        if (goal_ch) dgn = *reinterpret_cast<const float4*>(dgp + ro);
-        if (use_pre) pbn = *reinterpret_cast<const uchar4*>(prp + ro);
-    };
-    issue_rmw(y0);
-#pragma unroll 1
-    for (int k = 0; k < SROWS; ++k) {
-        const int y = y0 + k;
-        zn = issue_row6(zb, H, W, y + 2, x0, has_l, has_r);
-#pragma unroll
-        for (int f = 0; f < 3; ++f) pn[f] = issue_row6(p0 + (size_t)f * plane, H, W, y + 2, x0, has_l, has_r);
-        const float4 gx = gxn, dgc = dgn;
-        const uchar4 pb = pbn;
-        issue_rmw(y + 1);
-        if (active && y < H) {
-            // dz[x] = sum_f sum_{ty,tx} Wp[f][ty][tx] * dP[f][y-(ty-1)][x-(tx-1)]      (transpose of the zero-padded correlation)
-            float dz[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int f = 0; f < 3; ++f)
-#pragma unroll
-                for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-                    for (int tx = 0; tx < 3; ++tx)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            dz[j] = fmaf(wl[9 * f + 3 * ty + tx], pw[f][2 - ty].v[j + 2 - tx], dz[j]);
-            // dWp[f][ty][tx] += dP[f][y][x] * z[y+ty-1][x+tx-1]
-#pragma unroll
-            for (int f = 0; f < 3; ++f)
-#pragma unroll
-                for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-                    for (int tx = 0; tx < 3; ++tx)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            wsum[9 * f + 3 * ty + tx] = fmaf(pw[f][1].v[j + 1], zw[ty].v[j + tx], wsum[9 * f + 3 * ty + tx]);
-            const size_t ro = (size_t)y * W;
-            *reinterpret_cast<float4*>(gop + ro) = make_float4(gx.x + dz[0], gx.y + dz[1], gx.z + dz[2], gx.w + dz[3]);
-            if (goal_ch) {
-                float4 o = dgc;
-                o.x += dz[0] * (float)pb.x; o.y += dz[1] * (float)pb.y; o.z += dz[2] * (float)pb.z; o.w += dz[3] * (float)pb.w;
-                *reinterpret_cast<float4*>(dgp + ro) = o;
-            }
-        }
-        zw[0] = zw[1]; zw[1] = zw[2]; zw[2] = finish_row6(zn, has_l, has_r);
-#pragma unroll
-        for (int f = 0; f < 3; ++f) { pw[f][0] = pw[f][1]; pw[f][1] = pw[f][2]; pw[f][2] = finish_row6(pn[f], has_l, has_r); }
-    }
-    // block reduction of the 27 partial sums, fixed order (deterministic)
-    __shared__ float red[4][27];
-#pragma unroll
-    for (int i = 0; i < 27; ++i) {
-        float v = active ? wsum[i] : 0.0f;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
-        if (lane == 0) red[threadIdx.x >> 6][i] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 27)
-        ba.wp_partials[(size_t)blockIdx.x * 27 + threadIdx.x] +=
-            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
-
-// dst[j] = sum_i src[i*m + j] (fixed order -> deterministic)
-// dst[j] = sum_i src[i][j]: a block owns 16 columns, its 16 row groups take every sixteenth row each, partial sums combined
-// in a fixed order (deterministic)
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int m, int accumulate) {
-    __shared__ float part[16][17];
-    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4, j = blockIdx.x * 16 + c;
-    float acc0 = 0.0f, acc1 = 0.0f;
-    if (j < m) {
-        int i = rg;
-        for (; i + 16 < n; i += 32) {
-            acc0 += src[(size_t)i * m + j];
-            acc1 += src[(size_t)(i + 16) * m + j];
-        }
-        if (i < n) acc0 += src[(size_t)i * m + j];
-    }
-    part[rg][c] = acc0 + acc1;
-    __syncthreads();
-    if (rg == 0 && j < m) {
-        float v = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v += part[k][c];
-        dst[j] = accumulate ? dst[j] + v : v;
-    }
-}
-// perception-weight partials [B*C*bpp][27] -> grad [C][27]
-__global__ __launch_bounds__(64) void reduce_wp_kernel(const float* __restrict__ part, float* __restrict__ dst, int B, int C, int bpp) {
-    const int c = blockIdx.x, i = threadIdx.x;
-    if (i >= 27) return;
-    float acc = 0.0f;
-    for (int b = 0; b < B; ++b)
-        for (int k = 0; k < bpp; ++k) acc += part[((size_t)(b * C + c) * bpp + k) * 27 + i];
-    dst[c * 27 + i] = acc;
-}
-
-int g_bwd_variant = [] { const char* e = getenv("NCAHIP_BWD_VARIANT"); return e ? atoi(e) : 0; }();
-int g_bwd2_prio = [] { const char* e = getenv("NCAHIP_BWD2_PRIO"); return e ? atoi(e) : 0; }();
-
-template <int CP, typename ST, bool BFM = false>
-hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
-    if (g_bwd_variant == 0 && ba.pscr && ba.doscr) {   // default: front kernel + matrix kernel (nca_cond_bwd_fm.hip)
-        if (hipError_t e = nca_launch_cond_step_bwd_fm(ba, st, BFM ? 2 : (ST::BYTES == 2 ? 1 : 0)); e != hipSuccess) return e;
-        if (BFM) hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<uint16_t>, dim3(ba.nblk), dim3(256), 0, st, ba);
-        else hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<float>, dim3(ba.nblk), dim3(256), 0, st, ba);
-        return hipGetLastError();
-    }
-    if (g_bwd_variant == 2) {   // kernel A with a data-path wave and a weight-gradient wave per SIMD (nca_cond_bwd2.hip; measured slower)
-        NcaCondBwdArgs b2 = ba;
-        b2.prio = g_bwd2_prio;
-        if (hipError_t e = nca_launch_cond_step_bwd_a2(b2, st, BFM ? 2 : (ST::BYTES == 2 ? 1 : 0)); e != hipSuccess) return e;
-        if (BFM) hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<uint16_t>, dim3(ba.nblk), dim3(256), 0, st, ba);
-        else hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<float>, dim3(ba.nblk), dim3(256), 0, st, ba);
-        return hipGetLastError();
-    }
-    using K = BCfg<CP>;
-    auto kern = cond_step_bwd_kernel<CP, ST, BFM>;
-    const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
-    static NcaLdsAttr attr;   // per instantiation; keyed by device inside
-    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
+template <int CP, typename ST, bool BFM>
+hipError_t launch_fm(const NcaCondBwdArgs& ba_in, hipStream_t st) {
+    NcaCondBwdArgs ba = ba_in;
+    ba.f.err = nca_error_word_device();
     const NcaCondArgs& a = ba.f;
     const int nst = a.B * ((a.W + 15) / 16) * ((a.H + 15) / 16);
+    {
+        using KF = FrontCfg<CP>;
+        auto kern = cond_step_bwd_front_kernel<CP, ST, BFM>;
+        const size_t lds = (size_t)KF::LDS_FLOATS * sizeof(float);
+        static NcaLdsAttr attr;
+        if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(8 * ((nst + 7) / 8)), dim3(kFrontThreads), lds, st, ba);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    }
+    using KM = MCfg<CP>;
+    auto kern = cond_step_bwd_mlp_kernel<CP, ST, BFM>;
+    const size_t lds = (size_t)KM::LDS_FLOATS * sizeof(float);
+    static NcaLdsAttr attr;
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
     const int grid = nst < ba.nslab ? nst : ba.nslab;   // one slab per workgroup
 #if defined(NCA_STAMPS)
-    NcaCondBwdArgs bd = ba;
-    bd.f.dbg = nca_debug_stamp_ptr();
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), lds, st, bd);
-#else
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), lds, st, ba);
+    ba.f.dbg = nca_debug_stamp_ptr();
 #endif
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (BFM) hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<uint16_t>, dim3(ba.nblk), dim3(256), 0, st, ba);
-    else hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<float>, dim3(ba.nblk), dim3(256), 0, st, ba);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), lds, st, ba);
     return hipGetLastError();
 }
 
 }  // namespace
 
-int nca_cond_bwd_slab_floats(int C, int hidden) { return slab_floats(C, hidden); }
-int nca_cond_bwd_nslab() { return nca_cu_count(); }   // one persistent workgroup (and one slab) per CU
-int nca_cond_bwd_nblk(int B, int C, int H, int W) { return B * C * ((((H + SROWS - 1) / SROWS) * (W / 4) + 255) / 256); }
+// bytes of the two scratch areas for a B x H x W grid (fp32 sizes: the bf16 forms use half)
+size_t nca_cond_bwd_fm_pscr_bytes(int B, int H, int W) { return (size_t)B * ((W + 15) / 16) * ((H + 15) / 16) * 16 * 192 * 16; }
+size_t nca_cond_bwd_fm_doscr_bytes(int B, int H, int W) { return (size_t)B * ((W + 15) / 16) * ((H + 15) / 16) * 16 * 256 * 4; }
 
-static bool g_bwd_bf16_exact = getenv("NCAHIP_BWD_BF16_EXACT") != nullptr;
-void nca_set_bwd_bf16_exact(bool on) { g_bwd_bf16_exact = on; }
-void nca_set_bwd_variant(int v) { g_bwd_variant = v; }
-
-// W % 4 == 0 and 16-byte aligned tensors required (checked by the C ABI).
-hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st, bool bf16) {
-    if (bf16) {   // history (f.x_in, x_next) and goal hold bf16; gradients and scratch stay f32
-        if (g_bwd_bf16_exact) {   // test hook: exact-f32 recomputation from the widened history
-            if (ba.f.C <= 12) return launch_bwd<12, StBF16>(ba, st);
-            if (ba.f.C <= 16) return launch_bwd<16, StBF16>(ba, st);
-            return hipErrorInvalidValue;
-        }
-        if (ba.f.C <= 12) return launch_bwd<12, StBF16, true>(ba, st);
-        if (ba.f.C <= 16) return launch_bwd<16, StBF16, true>(ba, st);
-        return hipErrorInvalidValue;
+// front + matrix kernels (kernel B is launched by the caller).  mode 0 = f32 history, 1 = bf16 history / exact-f32 products,
+// 2 = bf16 history with the products on bf16 MFMA.
+hipError_t nca_launch_cond_step_bwd_fm(const NcaCondBwdArgs& ba, hipStream_t st, int mode) {
+    if (ba.f.C > 16 || !ba.pscr || !ba.doscr) return hipErrorInvalidValue;
+    const bool c12 = ba.f.C <= 12;
+    switch (mode) {
+        case 0: return c12 ? launch_fm<12, StF32, false>(ba, st) : launch_fm<16, StF32, false>(ba, st);
+        case 1: return c12 ? launch_fm<12, StBF16, false>(ba, st) : launch_fm<16, StBF16, false>(ba, st);
+        case 2: return c12 ? launch_fm<12, StBF16, true>(ba, st) : launch_fm<16, StBF16, true>(ba, st);
     }
-    if (ba.f.C <= 12) return launch_bwd<12, StF32>(ba, st);
-    if (ba.f.C <= 16) return launch_bwd<16, StF32>(ba, st);
     return hipErrorInvalidValue;
-}
-
-hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st, bool accumulate) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((m + 15) / 16), dim3(256), 0, st, src, dst, n, m, accumulate ? 1 : 0);
-    return hipGetLastError();
-}
-hipError_t nca_launch_reduce_wp(const float* part, float* dst, int B, int C, int H, int W, hipStream_t st) {
-    const int bpp = (((H + SROWS - 1) / SROWS) * (W / 4) + 255) / 256;
-    hipLaunchKernelGGL(reduce_wp_kernel, dim3(C), dim3(64), 0, st, part, dst, B, C, bpp);
-    return hipGetLastError();
 }

@@ -366,8 +366,9 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
 }
 
 // Resolve the pending life mask, build z = x + goal*pre in LDS (halo 1), keep the resolved state for
-// the residual.  CHECK=false: no bounds logic.
-template <int CP, bool CHECK, bool EXACT = false, typename ST = StF32>
+// the residual.  CHECK=false: no bounds logic.  KEEPX=false: the resolved-state copy XR is not written (callers that only
+// want z, the masks and the fire mask: the backward's front kernel).
+template <int CP, bool CHECK, bool EXACT = false, typename ST = StF32, bool KEEPX = true>
 __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t, const TileLds& L, int lane_in,
                                            const TileRegs<CP, ST>& R, int tile_no) {
     float* const Z = L.Z;
@@ -473,7 +474,7 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
                 for (int j = 0; j < 4; ++j) v[k][j] = wclamp(v[k][j], a.lo, a.hi);
             }
             if ((CHECK && !fok) || ch >= C) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (inner) st4(XR + ch * XRS + (fr - 1) * WTW + 4 * ff, v[k]);
+            if (KEEPX && inner) st4(XR + ch * XRS + (fr - 1) * WTW + 4 * ff, v[k]);
         }
         NCA_STAMP(12);
 #pragma unroll
