@@ -72,8 +72,8 @@ int ncahip_cond_precision(int mode);
  * against the oracle on the same inputs: bit 0 = generic any-shape kernels instead of the aligned fast paths;
  * bit 1 = symmetric wave-private ConditionedNCA kernel instead of the default producer/consumer one;
  * bit 2 = ncahip_cond_grow_bwd_bf16 evaluates its matrix products in exact fp32 instead of on bf16 MFMA;
- * bit 3 = the ConditionedNCA backward runs its main kernel in the two-waves-per-SIMD form (a data-path wave and a
- * weight-gradient wave per SIMD; same results, measured slower: an independent implementation to cross-check with). */
+ * bit 3 = the ConditionedNCA backward runs its main kernel in the other of its two forms (one launch <-> front kernel +
+ * matrix kernel; same results, each mode defaults to the faster one: an independent implementation to cross-check with). */
 int ncahip_debug_force_generic(int on);
 
 /* Device-side check that the MFMA operand/accumulator lane maps the kernels assume hold on

@@ -21,7 +21,7 @@ def ops(request):
     assert torch.cuda.is_available(), "gpu tests need the MI355X"
     from ncahip import ops as _ops
     _ops.selftest()
-    _ops._test_mode = {"fast": 0, "generic": 1, "wave": 2 | 8}[request.param]   # wave: + the two-waves-per-SIMD form of backward kernel A
+    _ops._test_mode = {"fast": 0, "generic": 1, "wave": 2 | 8}[request.param]   # wave: + backward kernel A in the form that is not the mode's default
     _ops.force_generic(_ops._test_mode)
     yield _ops
     _ops.force_generic(False)

@@ -138,7 +138,7 @@ int ncahip_debug_force_generic(int on) {
     nca_set_force_generic((on & 1) != 0);    // bit 0: generic any-shape kernels
     nca_set_cond_variant((on >> 1) & 1);     // bit 1: symmetric wave-private ConditionedNCA kernel instead of producer/consumer
     nca_set_bwd_bf16_exact((on & 4) != 0);   // bit 2: bf16-history backward with exact-f32 products instead of bf16 MFMA
-    nca_set_bwd_variant((on >> 3) & 1);      // bit 3: ConditionedNCA backward kernel A in its two-waves-per-SIMD form (nca_cond_bwd2.hip)
+    nca_set_bwd_variant((on & 8) ? 3 : 0);   // bit 3: ConditionedNCA backward kernel A in the form that is NOT the mode's default (one launch <-> front + matrix)
     return 0;
 }
 

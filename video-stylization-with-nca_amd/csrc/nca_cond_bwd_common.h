@@ -1,6 +1,5 @@
-// nca_cond_bwd_common.h -- pieces shared by the two forms of backward kernel A (nca_cond_bwd.hip: one wave per SIMD, every
-// product in the same wave; nca_cond_bwd2.hip: data-path wave + weight-gradient wave per SIMD): LDS carve, slab layout,
-// operand streaming helper, the bf16 transposition buffer.
+// nca_cond_bwd_common.h -- pieces shared by the two forms of backward kernel A (nca_cond_bwd.hip: one launch; nca_cond_bwd_fm.hip:
+// front kernel + matrix kernel): LDS carve, slab layout, operand streaming helper, the bf16 transposition buffer.
 #pragma once
 #include "nca_cond_tile.h"
 

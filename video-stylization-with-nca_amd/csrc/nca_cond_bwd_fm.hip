@@ -20,11 +20,8 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// F: front kernel.  One workgroup = one 16 x 16 super-tile, 4 waves, wave-private 4 x 16 tiles; 2-3 workgroups per CU.
-constexpr int kFrontWaves = 4, kFrontThreads = 256;
-#ifndef FM_OCC
-#define FM_OCC 2
-#endif
+// F: front kernel.  One workgroup = one 16 x 16 super-tile, 4 waves, wave-private 4 x 16 tiles; three workgroups per CU.
+constexpr int kFrontWaves = 4, kFrontThreads = 256, kFrontOcc = 3;   // 51 KB of LDS and <= 170 registers: three workgroups per CU
 template <int CP>
 struct FrontCfg {
     using F = WCfg<CP>;
@@ -41,7 +38,7 @@ struct FrontCfg {
 };
 
 template <int CP, typename ST, bool BFM>
-__global__ __launch_bounds__(kFrontThreads, FM_OCC) void cond_step_bwd_front_kernel(const NcaCondBwdArgs ba) {
+__global__ __launch_bounds__(kFrontThreads, kFrontOcc) void cond_step_bwd_front_kernel(const NcaCondBwdArgs ba) {
     using K = FrontCfg<CP>;
     using FK = WCfg<CP>;
     const NcaCondArgs& a = ba.f;
@@ -175,14 +172,7 @@ __global__ __launch_bounds__(kFrontThreads, FM_OCC) void cond_step_bwd_front_ker
 #pragma unroll 1
     for (int n0 = 0; n0 < WTH; n0 += 2) {
         float P[2][FK::K1S];
-#if defined(FM_NO_PERCEIVE)
-        for (int n = 0; n < 2; ++n) for (int s_ = 0; s_ < FK::K1S; ++s_) P[n][s_] = Z[lane + n + s_];
-#else
         perceive_tile<CP, 2>(WS, Z, lane, n0, P);
-#endif
-#if defined(FM_NO_PSTORE)
-        if (P[0][0] + P[1][1] == 123.456f)
-#endif
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             if constexpr (BFM) {
@@ -368,6 +358,38 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_mlp_kernel(const
     const int st_x = (W + BSTW - 1) / BSTW, st_y = (H + BSTH - 1) / BSTH;
     const int halo = a.alive_ch >= 0 ? 3 : 1;
     const bool use_alive = a.alive_ch >= 0;
+    // one pass's scratch operands, requested a pass ahead (raw: 16-byte groups of P / 8-byte groups of bf16 P in the low half)
+    f32x4 nP[NT][3];
+    float ndO[NT][4];
+    long pre_rid = -1;
+    auto fetch = [&](long r_) {
+        const int gq = (lane_w >> 4) & 3, cq = lane_w & 15;
+        if constexpr (BFM) {
+            const u32x2* const ps = reinterpret_cast<const u32x2*>(ba.pscr) + (size_t)r_ * 192 + lane_w;
+            const uint16_t* const ds = reinterpret_cast<const uint16_t*>(ba.doscr) + (size_t)r_ * 256 + 64 * gq + cq;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const u32x2 v = ps[n * 192 + q * 64];
+                    nP[n][q] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), 0.0f, 0.0f};
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ndO[n][r] = __uint_as_float((unsigned)ds[n * 256 + 16 * r] << 16);
+            }
+        } else {
+            const f32x4* const ps = reinterpret_cast<const f32x4*>(ba.pscr) + (size_t)r_ * 192 + lane_w;
+            const float* const ds = reinterpret_cast<const float*>(ba.doscr) + (size_t)r_ * 256 + 64 * gq + cq;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) nP[n][q] = ps[n * 192 + q * 64];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ndO[n][r] = ds[n * 256 + 16 * r];
+            }
+        }
+        pre_rid = r_;
+    };
     for (NcaTileWalk tw = nca_tile_walk(a.B * st_x * st_y); tw.t < tw.end; tw.t += tw.stride) {
         int lane = lane_w;   // opaque per tile: lane-derived offsets are recomputed where used, not hoisted out of the tile loop and spilled
         asm volatile("" : "+v"(lane));
@@ -386,34 +408,35 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_mlp_kernel(const
             // ---- forward recompute: P, h1, h2 kept in registers ------------------------------------------
             // ---- this pass's two 16-cell rows from the front kernel's scratch: the perception vector in B-operand order
             //      ([row tile][4-slot group][lane] x 16 B, or x 8 B of bf16) and the gated gradient dO = dL/dx' * fire mask
-            //      ([row tile][channel][cell]) -------------------------------------------------------------------------
+            //      ([row tile][channel][cell]).  They were requested a pass ago (fetch below); the request for the NEXT
+            //      pass -- rows 2, 3 of this tile, or rows 0, 1 of the wave's next tile -- goes out before this pass's MFMAs.
+            const long rid = (long)(rid0 + n0);
+            if (pre_rid != rid) fetch(rid);   // first tile of the wave, or the tile before this one was outside the image
             float P[NT][12];
             float dOin[NT][4];
             bf_s16x4 pbin[NT][3];
-            if constexpr (BFM) {
-                const bf_s16x4* const ps = reinterpret_cast<const bf_s16x4*>(ba.pscr) + (rid0 + n0) * 192 + lane;
-                const uint16_t* const ds = reinterpret_cast<const uint16_t*>(ba.doscr) + (rid0 + n0) * 256 + 64 * g + ci;
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
+            for (int n = 0; n < NT; ++n) {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) pbin[n][q] = ps[n * 192 + q * 64];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dOin[n][r] = 4 * g + r < CP ? __uint_as_float((unsigned)ds[n * 256 + 16 * r] << 16) : 0.0f;
+                for (int q = 0; q < 3; ++q) {
+                    if constexpr (BFM) pbin[n][q] = __builtin_bit_cast(bf_s16x4, u32x2{__float_as_uint(nP[n][q][0]), __float_as_uint(nP[n][q][1])});
+                    else { P[n][4 * q] = nP[n][q][0]; P[n][4 * q + 1] = nP[n][q][1]; P[n][4 * q + 2] = nP[n][q][2]; P[n][4 * q + 3] = nP[n][q][3]; }
                 }
-            } else {
-                const f32x4* const ps = reinterpret_cast<const f32x4*>(ba.pscr) + (rid0 + n0) * 192 + lane;
-                const float* const ds = reinterpret_cast<const float*>(ba.doscr) + (rid0 + n0) * 256 + 64 * g + ci;
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const f32x4 v = ps[n * 192 + q * 64];
-                        P[n][4 * q] = v[0]; P[n][4 * q + 1] = v[1]; P[n][4 * q + 2] = v[2]; P[n][4 * q + 3] = v[3];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dOin[n][r] = 4 * g + r < CP ? ds[n * 256 + 16 * r] : 0.0f;
-                }
+                for (int r = 0; r < 4; ++r) dOin[n][r] = 4 * g + r < CP ? ndO[n][r] : 0.0f;
             }
+            {
+                long nrid = rid + NT;
+                bool has = true;
+                if (pass == WTH / NT - 1) {
+                    const int tn = tw.t + tw.stride;
+                    has = tn < tw.end;
+                    nrid = (long)(((size_t)tn * kBwdWaves + wave) * WTH);
+                }
+                if (has) fetch(nrid);
+                else pre_rid = -1;
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the requests stay here
             NCA_BPHASE(4);   // scratch loads
             f32x4 dp[K::MJ][NT];
             if constexpr (BFM) {

@@ -97,7 +97,6 @@ struct NcaCondBwdArgs {
     float* slabs;           // per-workgroup weight-gradient partials, accumulated   [nslab, slab_floats]
     float* wp_partials;     // per-block perception-weight partials             [nblk, 27] accumulated
     int nslab, nblk;
-    int prio;               // two-wave kernel A: issue priority of the data-path waves (tuning hook, NCAHIP_BWD2_PRIO)
     void* pscr;             // front/matrix form: perception vectors in MFMA-operand order  (nca_cond_bwd_fm_pscr_bytes)
     void* doscr;            // front/matrix form: dL/dx'_t * fire mask, [row tile][channel][cell] (nca_cond_bwd_fm_doscr_bytes)
 };
@@ -105,12 +104,11 @@ int nca_cond_bwd_slab_floats(int C, int hidden);
 int nca_cond_bwd_nslab();
 int nca_cond_bwd_nblk(int B, int C, int H, int W);
 hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& a, hipStream_t st, bool bf16 = false);   // bf16: f.x_in / x_next / f.goal hold bf16
-// kernel A in its two-waves-per-SIMD form (nca_cond_bwd2.hip); mode 0 = f32 history, 1 = bf16 history / exact-f32 products, 2 = bf16 MFMA
-hipError_t nca_launch_cond_step_bwd_a2(const NcaCondBwdArgs& a, hipStream_t st, int mode);
-hipError_t nca_launch_cond_step_bwd_fm(const NcaCondBwdArgs& a, hipStream_t st, int mode);   // front + matrix kernels (nca_cond_bwd_fm.hip)
+// kernel A as two launches (nca_cond_bwd_fm.hip); mode 0 = f32 history, 1 = bf16 history / exact-f32 products, 2 = bf16 MFMA
+hipError_t nca_launch_cond_step_bwd_fm(const NcaCondBwdArgs& a, hipStream_t st, int mode);
 size_t nca_cond_bwd_fm_pscr_bytes(int B, int H, int W);
 size_t nca_cond_bwd_fm_doscr_bytes(int B, int H, int W);
-void nca_set_bwd_variant(int v);   // 0 = front + matrix kernels (default), 1 = one launch, one wave per SIMD (cross-check form), 2 = one launch, two waves per SIMD
+void nca_set_bwd_variant(int v);   // kernel A: 0 = the faster form per mode (bf16 MFMA: front + matrix kernels; fp32 products: one launch), 1 = one launch always, 2 = front + matrix always, 3 = the slower form per mode (cross-check)
 hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st, bool accumulate = false);   // dst (+)= column sums
 // nca_gram.hip: out[ma*nb + ma] = [sum_n a[i][n] * b[j][n] | sum_n a[i][n]] over all B*HW cells; b rows from two tensors
 int nca_dynca_bwd_grid(int B, int H, int W);   // upper bound over C (workspace sizing)
