@@ -730,6 +730,16 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
     //      by now) and added to the WORKGROUP's slab with coalesced accesses; fixed summation order (deterministic).
     const int sf = slab_floats(C, hid);
     static_assert(kBwdWaves * (64 * 3 * CP + 64 * 64 + CP * 64 + 128) <= K::LDS_FLOATS, "slab staging fits the LDS carve");
+    // the read half of the slab's read-modify-write goes out first: one memory round trip, under the LDS staging below
+    float* const slab = ba.slabs + (size_t)blockIdx.x * sf;
+    constexpr int PER = (64 * 3 * CP + 64 * 64 + CP * 64 + 128 + kBwdThreads - 1) / kBwdThreads;
+    float cur[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tid + kBwdThreads * k;
+        cur[k] = i < sf ? slab[i] : 0.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     float* const sw = smem + wave * sf;
 #pragma unroll
@@ -763,9 +773,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float s1 = db1[m][r], s2 = db2[m][r];
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
+            const float s1 = row16_sum(db1[m][r]), s2 = row16_sum(db2[m][r]);
             const int o = 16 * m + 4 * g + r;
             if (ci == 0 && o < hid) {
                 sw[slab_off_b1(C, hid) + o] = s1;
@@ -773,14 +781,6 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
             }
         }
     __syncthreads();
-    float* const slab = ba.slabs + (size_t)blockIdx.x * sf;
-    constexpr int PER = (64 * 3 * CP + 64 * 64 + CP * 64 + 128 + kBwdThreads - 1) / kBwdThreads;
-    float cur[PER];   // all reads of the read-modify-write in flight at once (one round trip, not PER)
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int i = tid + kBwdThreads * k;
-        cur[k] = i < sf ? slab[i] : 0.0f;
-    }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int i = tid + kBwdThreads * k;

@@ -48,6 +48,16 @@ __device__ __forceinline__ float gate_pos(float h, float d) {
 template <int GSZ>
 struct OpN { float v[GSZ]; };
 #define NCA_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Sum over the 16 lanes of a DPP row (the cell lanes of one channel group), left in every lane: four vector adds with lane
+// permutes done by the VALU's data-parallel primitives -- xor 1, xor 2 inside the quads, then the half-row and the row mirrored.
+// Same tree, bit for bit, as the xor-butterfly over __shfl_xor it replaces (which is four dependent LDS-crossbar round trips).
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
 template <int N, typename LD, typename MM>
 __device__ __forceinline__ void piped(LD&& ld, MM&& mm) {
     auto cur = ld(0);
