@@ -37,7 +37,8 @@ struct FrontCfg {
     static_assert(PW % 4 == 0 && PW_A3 % 4 == 0, "16-byte carve");
 };
 
-template <int CP, typename ST, bool BFM>
+// EXACT: the launch guarantees C == CP (no channel-padding clamps in the 45 loads, no ch < C guards in the staging).
+template <int CP, typename ST, bool BFM, bool EXACT>
 __global__ __launch_bounds__(kFrontThreads, kFrontOcc) void cond_step_bwd_front_kernel(const NcaCondBwdArgs ba) {
     using K = FrontCfg<CP>;
     using FK = WCfg<CP>;
@@ -109,11 +110,11 @@ __global__ __launch_bounds__(kFrontThreads, kFrontOcc) void cond_step_bwd_front_
     {
         TileRegs<CP, ST> R;
         if (t.inner) {
-            issue_loads<CP, true, true, 0, false, ST>(a, t, lane, R);
-            stage_tile<CP, false, false, ST, false>(a, t, L, lane, R, 0);
+            issue_loads<CP, true, true, 0, EXACT, ST>(a, t, lane, R);
+            stage_tile<CP, false, EXACT, ST, false>(a, t, L, lane, R, 0);
         } else {
-            issue_loads<CP, true, true, 1, false, ST>(a, t, lane, R);
-            stage_tile<CP, true, false, ST, false>(a, t, L, lane, R, 0);
+            issue_loads<CP, true, true, 1, EXACT, ST>(a, t, lane, R);
+            stage_tile<CP, true, EXACT, ST, false>(a, t, L, lane, R, 0);
         }
     }
     // ---- alpha of the pending state -> A1 (post mask of this step);  z_t interior out (kernel B's perception-weight gradient)
@@ -889,12 +890,16 @@ hipError_t launch_fm(const NcaCondBwdArgs& ba_in, hipStream_t st) {
     const int nst = a.B * ((a.W + 15) / 16) * ((a.H + 15) / 16);
     {
         using KF = FrontCfg<CP>;
-        auto kern = cond_step_bwd_front_kernel<CP, ST, BFM>;
         const size_t lds = (size_t)KF::LDS_FLOATS * sizeof(float);
-        static NcaLdsAttr attr;
-        if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(8 * ((nst + 7) / 8)), dim3(kFrontThreads), lds, st, ba);
-        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+        auto go = [&](auto kern, NcaLdsAttr& attr) -> hipError_t {
+            if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(8 * ((nst + 7) / 8)), dim3(kFrontThreads), lds, st, ba);
+            return hipGetLastError();
+        };
+        static NcaLdsAttr attr_x, attr_g;   // per instantiation; keyed by device inside
+        const hipError_t e = a.C == CP ? go(cond_step_bwd_front_kernel<CP, ST, BFM, true>, attr_x)
+                                       : go(cond_step_bwd_front_kernel<CP, ST, BFM, false>, attr_g);
+        if (e != hipSuccess) return e;
     }
     using KM = MCfg<CP>;
     auto kern = cond_step_bwd_mlp_kernel<CP, ST, BFM>;
