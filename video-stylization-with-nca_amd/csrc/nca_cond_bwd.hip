@@ -947,9 +947,9 @@ __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCon
     __shared__ float red[4][27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) {
-        float v = active ? wsum[i] : 0.0f;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+        float v = row16_sum(active ? wsum[i] : 0.0f);   // 16 lanes on the VALU (DPP), the four rows through two crossbar exchanges
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
         if (lane == 0) red[threadIdx.x >> 6][i] = v;
     }
     __syncthreads();
