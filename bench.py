@@ -165,7 +165,8 @@ def train_leg(dev, world, iters):
     for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
         tr = ConditionedNCATrainer(nca, Targets(), None, nca_steps=[TT, TT], pool_size=2 * TB * world, loss=StandIn(), device=dev,
                                    log_base_path=tempfile.mkdtemp(prefix="ncahip_bench_"), pool_dtype=dt)
-        tr._iteration(0, TB * world)                      # warm-up (allocator, first-touch)
+        for w_ in range(2):                               # warm-up: allocator (history ring, backward workspace), first touch of
+            tr._iteration(0, TB * world)                  # every kernel; one iteration left a one-off 50 ms inside the timed three
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -182,6 +183,10 @@ def train_leg(dev, world, iters):
             dt_s = float(tt.item())
         out[name] = {"ms_per_iteration": dt_s / iters * 1e3, "cell_updates_per_s_fwd_bwd": world * TB * H * W * TT * 2 * iters / dt_s,
                      "last_loss": float(loss)}
+        del tr                                            # the next leg's pool / history have other sizes: start it from an empty cache
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
     out.update({"B_per_gpu": TB, "nca_steps": TT, "train_batches_per_iteration": 2, "iterations": iters,
                 "allreduce_floats": sum(p.numel() for p in nca.parameters() if p.requires_grad), "n_gpus": world,
                 "objective": "stand-in: MSE + overflow (VGG weights unobtainable offline)"})
