@@ -328,11 +328,12 @@ def test_bf16x3_precision_mode(ops, C, shape, gch):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("C,shape,gch,Tn", [(16, (2, 80, 112), 12, 3), (12, (1, 36, 52), 8, 2)])
-def test_cond_backward_kernel_forms_agree_bitwise(ops, dtype, C, shape, gch, Tn):
+def test_cond_backward_kernel_forms_agree(ops, dtype, C, shape, gch, Tn):
     """Backward kernel A exists in two forms (csrc/nca_cond_bwd.hip: ONE launch, everything for a tile in one wave;
     csrc/nca_cond_bwd_fm.hip: a front kernel -- staging, gate, perception into an operand-order scratch -- and a matrix
-    kernel).  Both issue the same products in the same per-wave order, so every gradient must agree BIT FOR BIT -- on
-    evolving life masks, image borders (ragged sizes) included.  Each form is checked against the oracle through the
+    kernel).  With fp32 products both issue the same products in the same per-wave order, so every gradient must agree BIT FOR
+    BIT -- on evolving life masks, image borders (ragged sizes) included; the bf16-MFMA matrix kernel sums in another fixed
+    order (two waves per SIMD), so there the bound is 2e-5 of the largest entry.  Each form is checked against the oracle through the
     kernel-family fixture of test_gpu_parity.py (the default form per mode and, in the third family, the other one); this
     pins them to each other, for the fp32 products and for the bf16-MFMA products."""
     B, H, W = shape
@@ -357,4 +358,10 @@ def test_cond_backward_kernel_forms_agree_bitwise(ops, dtype, C, shape, gch, Tn)
         ops.force_generic(0)
     one, two = res
     for k in one:
-        assert torch.equal(one[k], two[k]), k
+        if dtype == torch.float32:
+            assert torch.equal(one[k], two[k]), k
+        else:
+            # the bf16-MFMA matrix kernel runs two waves per SIMD and merges the pair's partial accumulators at the flush (and takes
+            # its ReLU gates from the stored bf16 activations): same products, another fixed summation order
+            d = float((one[k] - two[k]).abs().max()) / max(1e-12, float(one[k].abs().max()))
+            assert d <= 2e-5, (k, d)

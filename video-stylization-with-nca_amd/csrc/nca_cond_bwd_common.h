@@ -105,6 +105,12 @@ __device__ __forceinline__ bf_s16x4 tb_tr_read(const short* tb, int tile, int la
     const short* a = tb + (4 * g + q) * TBH + tile * 16 + 4 * (p ^ g);
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf_s16x4 __attribute__((address_space(3)))*)(a));
 }
+// element r of a packed bf16x4 is non-zero (ReLU'd activations: non-zero <=> the f32 pre-activation was positive, but for values
+// below the bf16 denormal range)
+__device__ __forceinline__ bool bf_nz(bf_s16x4 v, int r) {
+    const u32x2 w = __builtin_bit_cast(u32x2, v);
+    return (w[r >> 1] & ((r & 1) ? 0x7fff0000u : 0x00007fffu)) != 0u;
+}
 __device__ __forceinline__ void tb_write(short* tb, int tile, int lane, bf_s16x4 v) {
     // accumulator layout: lane (g, cell c) holds features 4g .. 4g+3 of the tile for its cell: chunk g of row c
     const int g = (lane >> 4) & 3, c = lane & 15;

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kFrontThreads, kFrontOcc) void cond_step_bwd_front_
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // M: the matrix part.  4 waves / workgroup / CU (one wave per SIMD: 128 persistent accumulators), persistent over the tiles.
-template <int CP>
+template <int CP, int NW = 4>
 struct MCfg {
     using F = WCfg<CP>;
     static constexpr int K1S = F::K1S;
@@ -209,22 +209,34 @@ struct MCfg {
     static constexpr int OFF_W3T = F::SHARED;               // [4 m][4 s][64]
     static constexpr int OFF_W1T = OFF_W3T + 4 * 4 * 64;    // [MJ][16 s][64]
     static constexpr int SHARED = OFF_W1T + MJ * 16 * 64;
-    static constexpr int PW = 16 * TBS;                     // transposition buffer, 16 cells x 148 rows
+    static constexpr int PW = NW == 8 ? 16 * TBH / 2 : 16 * TBS;   // transposition buffer: 16 cells x 148 f32 rows, or x 144 bf16 (NW = 8 is bf16-only)
+    static constexpr int OFF_DB = SHARED + NW * PW;         // NW = 8: bias-gradient sums, [wave][32 values][64 lanes], accumulated with LDS adds
+    static constexpr int DB = NW == 8 ? NW * 32 * 64 : 0;
     static constexpr int SLABS = kBwdWaves * (64 * 3 * CP + 64 * 64 + CP * 64 + 128);   // the flush stages four partial slabs
-    static constexpr int LDS_FLOATS = (SHARED + kBwdWaves * PW) > SLABS ? (SHARED + kBwdWaves * PW) : SLABS;
+    static constexpr int MERGE = NW == 8 ? 4 * 128 * 64 : 0;   // two waves per SIMD: the pairs' accumulators meet in LDS before the flush
+    static constexpr int LDS_A = (SHARED + NW * PW + DB) > SLABS ? (SHARED + NW * PW + DB) : SLABS;
+    static constexpr int LDS_FLOATS = LDS_A > MERGE ? LDS_A : MERGE;
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
     static_assert(CP <= 16, "one 16-row output tile (M3T == 1)");
 };
 
-template <int CP, typename ST = StF32, bool BFM = false>
-__global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_mlp_kernel(const NcaCondBwdArgs ba) {
-    using K = MCfg<CP>;
+// NW = 4: one wave per SIMD, two 16-cell rows per pass (NT = 2) -- the one-launch kernel's arrangement.  NW = 8 (the bf16-MFMA
+// default): TWO waves per SIMD; the waves 2p and 2p+1 split a 4 x 16 tile into its upper and lower two rows and walk them one
+// row per pass (NT = 1), which with the ReLU gates taken from the stored bf16 activations instead of kept f32 pre-activations
+// fits 256 registers beside the 128 accumulators; their partial accumulators are merged through LDS before the flush.
+template <int CP, typename ST = StF32, bool BFM = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const NcaCondBwdArgs ba) {
+    using K = MCfg<CP, NW>;
     using FK = WCfg<CP>;
-    constexpr int NT = 2;
+    constexpr int NT = NW == 8 ? 1 : 2;
+    constexpr int kThr = 64 * NW;
+    constexpr int DPS = NT == 2 ? 36 : 20;   // row stride of the dL/dperception staging in TB ([3C rows][NT x 16 cells])
+    static_assert(NW == 4 || (NW == 8 && BFM), "two waves per SIMD: bf16-MFMA form only");
     const NcaCondArgs& a = ba.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, lane_w = lane;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tslot = NW == 8 ? wave >> 1 : wave;   // which 4 x 16 tile of the super-tile;  NW == 8: wave & 1 = its upper / lower two rows
     const int C = a.C, H = a.H, W = a.W, hid = a.hidden, K1 = 3 * C;
     const unsigned plane = (unsigned)(H * W);
     const int g = lane >> 4, ci = lane & 15;
@@ -238,13 +250,13 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_mlp_kernel(const
     // ---- forward A-operand images (identical to the forward kernel) + transposed images --------------------
     // Two-phase: all gathers are requested before the first is waited for (one cold round trip instead of ten).
     {
-        FillRegs<4 * FK::K1S * 64, kBwdThreads> fr0;
-        FillRegs<4 * 16 * 64, kBwdThreads> fr1;
-        FillRegs<FK::HID, kBwdThreads> fr2;
-        FillRegs<FK::HID, kBwdThreads> fr3;
-        FillRegs<CP * FK::WPS, kBwdThreads> fr4;
-        FillRegs<4 * 4 * 64, kBwdThreads> fr5;
-        FillRegs<K::MJ * 16 * 64, kBwdThreads> fr6;
+        FillRegs<4 * FK::K1S * 64, kThr> fr0;
+        FillRegs<4 * 16 * 64, kThr> fr1;
+        FillRegs<FK::HID, kThr> fr2;
+        FillRegs<FK::HID, kThr> fr3;
+        FillRegs<CP * FK::WPS, kThr> fr4;
+        FillRegs<4 * 4 * 64, kThr> fr5;
+        FillRegs<K::MJ * 16 * 64, kThr> fr6;
         fill_load(fr0, a.w1, tid, [&](int idx) -> long {
             const int l = idx & 63, s = (idx >> 6) % FK::K1S, m = (idx >> 6) / FK::K1S;
             const int gg = l >> 4, o = 16 * m + (l & 15);
@@ -301,7 +313,7 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_mlp_kernel(const
     static_assert(OP_N * 64 * 2 <= FK::OFF_B1, "bf16 operand image fits over the f32 W1 | W2 | W3 images");
     const bf_s16x4* const BW = reinterpret_cast<const bf_s16x4*>(smem) + lane;      // operand o of this lane: BW[o * 64]
     if constexpr (BFM) {
-        bf_s16x4 img[(OP_N + kBwdWaves - 1) / kBwdWaves];    // this wave's share of the operands (round robin)
+        bf_s16x4 img[(OP_N + NW - 1) / NW];    // this wave's share of the operands (round robin)
         const int w2t_lane0 = (ci & 3) * 64 + (ci >> 2) * 16 + 4 * g;
         auto build = [&](int o) -> bf_s16x4 {
             float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -329,21 +341,41 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_mlp_kernel(const
             return pack4(v[0], v[1], v[2], v[3]);
         };
 #pragma unroll
-        for (int k = 0; k < (OP_N + kBwdWaves - 1) / kBwdWaves; ++k) {
-            const int o = k * kBwdWaves + wave;
+        for (int k = 0; k < (OP_N + NW - 1) / NW; ++k) {
+            const int o = k * NW + wave;
             img[k] = o < OP_N ? build(o) : bf_s16x4{0, 0, 0, 0};
         }
         __syncthreads();                               // every wave has read what it needs of the f32 images
 #pragma unroll
-        for (int k = 0; k < (OP_N + kBwdWaves - 1) / kBwdWaves; ++k) {
-            const int o = k * kBwdWaves + wave;
+        for (int k = 0; k < (OP_N + NW - 1) / NW; ++k) {
+            const int o = k * NW + wave;
             if (o < OP_N) *(reinterpret_cast<bf_s16x4*>(smem) + o * 64 + lane) = img[k];
         }
         __syncthreads();
     }
     // persistent weight-gradient accumulators (D = A * B^T with the cell axis as K)
     f32x4 aW1[4][K::MJ], aW2[4][4], aW3[4];
+    // bias-gradient sums: 32 registers per lane -- or, with two waves per SIMD (no registers to spare), 32 x 64 floats of LDS per
+    // wave, [which][m][lane][4]: one 16-byte read-modify-write per gated tile (lane-private addresses; ds_add_f32 was tried: the
+    // LDS's float atomics run a lane at a time and made the kernel five times slower)
     float db1[4][4], db2[4][4];
+    float* const DBL = smem + K::OFF_DB + wave * (32 * 64) + lane * 4;
+    if constexpr (NW == 8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st4(DBL + i * 256, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    auto db_add4 = [&](int which, int m, const f32x4& d) {
+        if constexpr (NW == 8) {
+            float* const p_ = DBL + (which * 4 + m) * 256;
+            st4(p_, ld4(p_) + d);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (which == 0) db1[m][r] += d[r];
+                else db2[m][r] += d[r];
+            }
+        }
+    };
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         aW3[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -397,21 +429,22 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_mlp_kernel(const
         const int g = (lane >> 4) & 3, ci = lane & 15;
         WTile t;
         t.b = tw.t / (st_x * st_y);
-        t.ty0 = ((tw.t / st_x) % st_y) * BSTH + wave * WTH;
+        t.ty0 = ((tw.t / st_x) % st_y) * BSTH + tslot * WTH;
         t.tx0 = (tw.t % st_x) * BSTW;
         if (t.ty0 >= H || t.tx0 >= W) continue;
         const int ty0 = t.ty0, tx0 = t.tx0;
         NCA_BPHASE(0);   // loop overhead / previous tile's tail
-        const size_t rid0 = ((size_t)tw.t * kBwdWaves + wave) * WTH;   // 16-cell row tiles of the front kernel's scratch
+        const int nbase = NW == 8 ? (wave & 1) * 2 : 0;   // first row of this wave inside the tile
+        const size_t rid0 = ((size_t)tw.t * kBwdWaves + tslot) * WTH + nbase;   // 16-cell row tiles of the front kernel's scratch
 #pragma unroll 1
-        for (int pass = 0; pass < WTH / NT; ++pass) {
-            const int n0 = pass * NT;
+        for (int pass = 0; pass < 2; ++pass) {   // (both forms: two passes per wave)
+            const int n0 = nbase + pass * NT;
             // ---- forward recompute: P, h1, h2 kept in registers ------------------------------------------
             // ---- this pass's two 16-cell rows from the front kernel's scratch: the perception vector in B-operand order
             //      ([row tile][4-slot group][lane] x 16 B, or x 8 B of bf16) and the gated gradient dO = dL/dx' * fire mask
             //      ([row tile][channel][cell]).  They were requested a pass ago (fetch below); the request for the NEXT
             //      pass -- rows 2, 3 of this tile, or rows 0, 1 of the wave's next tile -- goes out before this pass's MFMAs.
-            const long rid = (long)(rid0 + n0);
+            const long rid = (long)(rid0 + pass * NT);
             if (pre_rid != rid) fetch(rid);   // first tile of the wave, or the tile before this one was outside the image
             float P[NT][12];
             float dOin[NT][4];
@@ -429,10 +462,10 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_mlp_kernel(const
             {
                 long nrid = rid + NT;
                 bool has = true;
-                if (pass == WTH / NT - 1) {
+                if (pass == 1) {
                     const int tn = tw.t + tw.stride;
                     has = tn < tw.end;
-                    nrid = (long)(((size_t)tn * kBwdWaves + wave) * WTH);
+                    nrid = (long)(((size_t)tn * kBwdWaves + tslot) * WTH + nbase);
                 }
                 if (has) fetch(nrid);
                 else pre_rid = -1;
@@ -497,7 +530,8 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_mlp_kernel(const
                     for (int n = 0; n < NT; ++n) {
                         f32x4 d = mfma_bf16(BW[(OP_W3T + m) * 64], dOb[n], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { d[r] = h2f[m][n][r] > 0.0f ? d[r] : 0.0f; db2[m][r] += d[r]; }
+                        for (int r = 0; r < 4; ++r) { d[r] = (NW == 8 ? bf_nz(h2b[m][n], r) : h2f[m][n][r] > 0.0f) ? d[r] : 0.0f; }
+                        db_add4(1, m, d);
                         d2b[m][n] = pack4(d[0], d[1], d[2], d[3]);
                     }
                 NCA_BPHASE(6);   // layer 3
@@ -526,7 +560,8 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_mlp_kernel(const
 #pragma unroll
                         for (int mp = 0; mp < 4; ++mp) d = mfma_bf16(BW[(OP_W2T + m * 4 + mp) * 64], d2b[mp][n], d);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { d[r] = h1f[m][n][r] > 0.0f ? d[r] : 0.0f; db1[m][r] += d[r]; }
+                        for (int r = 0; r < 4; ++r) { d[r] = (NW == 8 ? bf_nz(h1b[m][n], r) : h1f[m][n][r] > 0.0f) ? d[r] : 0.0f; }
+                        db_add4(0, m, d);
                         d1b[m][n] = pack4(d[0], d[1], d[2], d[3]);
                     }
                 NCA_BPHASE(7);   // layer 2
@@ -783,18 +818,18 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_mlp_kernel(const
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) TB[(16 * mj + 4 * g + r) * 36 + n * 16 + ci] = dp[mj][n][r];
+                    for (int r = 0; r < 4; ++r) TB[(16 * mj + 4 * g + r) * DPS + n * 16 + ci] = dp[mj][n][r];
             wave_sync();
             {
-                const int rr = (lane >> 2) & 1, ff = lane & 3, jl = lane >> 3;  // 8 rows of j per instruction
+                const int rr = NT == 2 ? (lane >> 2) & 1 : 0, ff = lane & 3, jl = NT == 2 ? lane >> 3 : lane >> 2;  // 8 (NT = 1: 16) rows of j per instruction
                 const int gy = ty0 + n0 + rr, gx = tx0 + 4 * ff;
                 const bool ok = gy < H && gx + 3 < W;
                 float* const po = ba.dP + (size_t)t.b * 3 * C * plane + (ok ? (unsigned)(gy * W + gx) : 0u);
                 uint16_t* const po16 = reinterpret_cast<uint16_t*>(ba.dP) + (size_t)t.b * 3 * C * plane + (ok ? (unsigned)(gy * W + gx) : 0u);
 #pragma unroll
-                for (int k = 0; k < 2 * K::MJ; ++k) {
-                    const int j = 8 * k + jl;
-                    const f32x4 v = ld4(TB + j * 36 + rr * 16 + 4 * ff);
+                for (int k = 0; k < (NT == 2 ? 2 : 1) * K::MJ; ++k) {
+                    const int j = (NT == 2 ? 8 : 16) * k + jl;
+                    const f32x4 v = ld4(TB + j * DPS + rr * 16 + 4 * ff);
                     if (ok && j < K1) {
                         if constexpr (BFM) *reinterpret_cast<u32x2*>(po16 + (unsigned)j * plane) = u32x2{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3])};
                         else st4(po + (unsigned)j * plane, v);
@@ -821,16 +856,64 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_mlp_kernel(const
     static_assert(kBwdWaves * (64 * 3 * CP + 64 * 64 + CP * 64 + 128) <= K::LDS_FLOATS, "slab staging fits the LDS carve");
     // the read half of the slab's read-modify-write goes out first: one memory round trip, under the LDS staging below
     float* const slab = ba.slabs + (size_t)blockIdx.x * sf;
-    constexpr int PER = (64 * 3 * CP + 64 * 64 + CP * 64 + 128 + kBwdThreads - 1) / kBwdThreads;
+    constexpr int PER = (64 * 3 * CP + 64 * 64 + CP * 64 + 128 + kThr - 1) / kThr;
     float cur[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int i = tid + kBwdThreads * k;
+        const int i = tid + kThr * k;
         cur[k] = i < sf ? slab[i] : 0.0f;
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    float* const sw = smem + wave * sf;
+    if constexpr (NW == 8) {
+        // the bias sums leave their LDS accumulators (the merge below reuses that part of the carve)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { db1[m][r] = DBL[m * 256 + r]; db2[m][r] = DBL[(4 + m) * 256 + r]; }
+        __syncthreads();
+    }
+    if constexpr (NW == 8) {
+        // the pair's partial sums meet in the even wave: the odd wave parks its accumulators in LDS (16-byte groups, lane-major:
+        // conflict-free), the even wave adds them; then the bias sums the same way.  Fixed order: deterministic.
+        float* const xb = smem + (size_t)(wave >> 1) * (128 * 64) + lane * 4;
+        const bool odd = (wave & 1) != 0;
+        auto each_acc = [&](auto&& f) {
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < K::MJ; ++j) f(aW1[i][j], q++);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f(aW2[i][j], q++);
+                f(aW3[i], q++);
+            }
+        };
+        if (odd) each_acc([&](f32x4& v, int q) { st4(xb + q * 256, v); });
+        __syncthreads();
+        if (!odd) each_acc([&](f32x4& v, int q) { v += ld4(xb + q * 256); });
+        __syncthreads();
+        if (odd) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                st4(xb + m * 256, f32x4{db1[m][0], db1[m][1], db1[m][2], db1[m][3]});
+                st4(xb + (4 + m) * 256, f32x4{db2[m][0], db2[m][1], db2[m][2], db2[m][3]});
+            }
+        }
+        __syncthreads();
+        if (!odd) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 u = ld4(xb + m * 256), v = ld4(xb + (4 + m) * 256);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { db1[m][r] += u[r]; db2[m][r] += v[r]; }
+            }
+        }
+        __syncthreads();
+    }
+    const bool stager = NW == 4 || (wave & 1) == 0;
+    float* const sw = smem + tslot * sf;
+    if (stager) {
 #pragma unroll
     for (int ma = 0; ma < 4; ++ma)
 #pragma unroll
@@ -869,10 +952,11 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_mlp_kernel(const
                 sw[slab_off_b2(C, hid) + o] = s2;
             }
         }
+    }   // stager
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int i = tid + kBwdThreads * k;
+        const int i = tid + kThr * k;
         if (i < sf) slab[i] = cur[k] + ((smem[i] + smem[sf + i]) + (smem[2 * sf + i] + smem[3 * sf + i]));
     }
 #if defined(NCA_STAMPS)
@@ -901,8 +985,9 @@ hipError_t launch_fm(const NcaCondBwdArgs& ba_in, hipStream_t st) {
                                        : go(cond_step_bwd_front_kernel<CP, ST, BFM, false>, attr_g);
         if (e != hipSuccess) return e;
     }
-    using KM = MCfg<CP>;
-    auto kern = cond_step_bwd_mlp_kernel<CP, ST, BFM>;
+    constexpr int NW = BFM ? 8 : 4;   // bf16 MFMA: two waves per SIMD
+    using KM = MCfg<CP, NW>;
+    auto kern = cond_step_bwd_mlp_kernel<CP, ST, BFM, NW>;
     const size_t lds = (size_t)KM::LDS_FLOATS * sizeof(float);
     static NcaLdsAttr attr;
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
@@ -910,7 +995,7 @@ hipError_t launch_fm(const NcaCondBwdArgs& ba_in, hipStream_t st) {
 #if defined(NCA_STAMPS)
     ba.f.dbg = nca_debug_stamp_ptr();
 #endif
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBwdThreads), lds, st, ba);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, ba);
     return hipGetLastError();
 }
 
