@@ -247,55 +247,53 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_last)::"memory");
     ph_t0 = ph_last;
 #endif
-    // ---- forward A-operand images (identical to the forward kernel) + transposed images --------------------
-    // Two-phase: all gathers are requested before the first is waited for (one cold round trip instead of ten).
+    // ---- A-operand images.  Index maps: element idx of an image <- offset into the weight tensor (or -1: zero) -----------
+    auto map_w1 = [&](int idx) -> long {          // forward W1: [4 m][K1S s][64]
+        const int l = idx & 63, s = (idx >> 6) % FK::K1S, m = (idx >> 6) / FK::K1S;
+        const int gg = l >> 4, o = 16 * m + (l & 15);
+        const int ch = 4 * (s / 3) + gg, f = s % 3;
+        return (ch < C && o < hid) ? (long)o * K1 + 3 * ch + f : -1;
+    };
+    auto map_w2 = [&](int idx) -> long {          // forward W2: [4 m2][16 s][64]
+        const int l = idx & 63, s = (idx >> 6) % 16, m = (idx >> 6) / 16;
+        const int gg = l >> 4, o = 16 * m + (l & 15);
+        const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
+        return (o < hid && k < hid) ? (long)o * hid + k : -1;
+    };
+    auto map_w3t = [&](int idx) -> long {         // W3^T: lane (gg,i) of (m, s) holds W3[ch = 4gg+s][h2 = 16m+i]
+        const int l = idx & 63, s = (idx >> 6) % 4, m = (idx >> 6) / 4;
+        const int ch = 4 * (l >> 4) + s, h2 = 16 * m + (l & 15);
+        return (ch < C && h2 < hid) ? (long)ch * hid + h2 : -1;
+    };
+    auto map_w1t = [&](int idx) -> long {         // W1^T: lane (gg,i) of (mj, s) holds W1[h1 = 16(s/4)+4gg+s%4][j = 16mj+i]
+        const int l = idx & 63, s = (idx >> 6) % 16, mj = (idx >> 6) / 16;
+        const int h1 = 16 * (s >> 2) + 4 * (l >> 4) + (s & 3), j = 16 * mj + (l & 15);
+        return (h1 < hid && j < K1) ? (long)h1 * K1 + j : -1;
+    };
     {
-        FillRegs<4 * FK::K1S * 64, kThr> fr0;
-        FillRegs<4 * 16 * 64, kThr> fr1;
         FillRegs<FK::HID, kThr> fr2;
         FillRegs<FK::HID, kThr> fr3;
-        FillRegs<CP * FK::WPS, kThr> fr4;
-        FillRegs<4 * 4 * 64, kThr> fr5;
-        FillRegs<K::MJ * 16 * 64, kThr> fr6;
-        fill_load(fr0, a.w1, tid, [&](int idx) -> long {
-            const int l = idx & 63, s = (idx >> 6) % FK::K1S, m = (idx >> 6) / FK::K1S;
-            const int gg = l >> 4, o = 16 * m + (l & 15);
-            const int ch = 4 * (s / 3) + gg, f = s % 3;
-            return (ch < C && o < hid) ? (long)o * K1 + 3 * ch + f : -1;
-        });
-        fill_load(fr1, a.w2, tid, [&](int idx) -> long {
-            const int l = idx & 63, s = (idx >> 6) % 16, m = (idx >> 6) / 16;
-            const int gg = l >> 4, o = 16 * m + (l & 15);
-            const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
-            return (o < hid && k < hid) ? (long)o * hid + k : -1;
-        });
         fill_load(fr2, a.b1, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
         fill_load(fr3, a.b2, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
-        fill_load(fr4, a.wp, tid, [&](int idx) -> long {
-            const int ch = idx / FK::WPS, j = idx % FK::WPS;
-            return (ch < C && j < 27) ? (long)ch * 27 + j : -1;
-        });
-        // W3^T: lane (gg,i) of (m, s) holds W3[ch = 4gg+s][h2 = 16m+i]
-        fill_load(fr5, a.w3, tid, [&](int idx) -> long {
-            const int l = idx & 63, s = (idx >> 6) % 4, m = (idx >> 6) / 4;
-            const int ch = 4 * (l >> 4) + s, h2 = 16 * m + (l & 15);
-            return (ch < C && h2 < hid) ? (long)ch * hid + h2 : -1;
-        });
-        // W1^T: lane (gg,i) of (mj, s) holds W1[h1 = 16(s/4)+4gg+s%4][j = 16mj+i]
-        fill_load(fr6, a.w1, tid, [&](int idx) -> long {
-            const int l = idx & 63, s = (idx >> 6) % 16, mj = (idx >> 6) / 16;
-            const int h1 = 16 * (s >> 2) + 4 * (l >> 4) + (s & 3), j = 16 * mj + (l & 15);
-            return (h1 < hid && j < K1) ? (long)h1 * K1 + j : -1;
-        });
-        fill_store(fr0, smem + FK::OFF_W1, tid);
-        fill_store(fr1, smem + FK::OFF_W2, tid);
+        if constexpr (!BFM) {
+            // f32 images, two-phase: all gathers are requested before the first is waited for (one cold round trip instead of ten)
+            FillRegs<4 * FK::K1S * 64, kThr> fr0;
+            FillRegs<4 * 16 * 64, kThr> fr1;
+            FillRegs<4 * 4 * 64, kThr> fr5;
+            FillRegs<K::MJ * 16 * 64, kThr> fr6;
+            fill_load(fr0, a.w1, tid, map_w1);
+            fill_load(fr1, a.w2, tid, map_w2);
+            fill_load(fr5, a.w3, tid, map_w3t);
+            fill_load(fr6, a.w1, tid, map_w1t);
+            fill_store(fr0, smem + FK::OFF_W1, tid);
+            fill_store(fr1, smem + FK::OFF_W2, tid);
+            fill_store(fr5, smem + K::OFF_W3T, tid);
+            fill_store(fr6, smem + K::OFF_W1T, tid);
+        }
         fill_store(fr2, smem + FK::OFF_B1, tid);
         fill_store(fr3, smem + FK::OFF_B2, tid);
-        fill_store(fr4, smem + FK::OFF_WP, tid);
-        fill_store(fr5, smem + K::OFF_W3T, tid);
-        fill_store(fr6, smem + K::OFF_W1T, tid);
     }
-    __syncthreads();
+    if constexpr (!BFM) __syncthreads();
 
     const float* const W1L = smem + FK::OFF_W1;
     const float* const W2L = smem + FK::OFF_W2;
@@ -305,51 +303,54 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
     const float* const W1T = smem + K::OFF_W1T;
     float* const TB = smem + K::SHARED + wave * K::PW;   // this wave's transposition buffer (the only per-wave LDS left)
 
-    // BFM: bf16 A operands of every product, built once per launch from the f32 LDS images (same k orders as the f32 path) and
-    // kept as ONE packed image in LDS, [operand][lane] x 8 bytes, over the (then dead) f32 images: 120 operand registers per
-    // lane would not fit beside the 128 weight-gradient accumulators.
+    // BFM: bf16 A operands of every product, kept as ONE packed image in LDS, [operand][lane] x 8 bytes (120 operand registers
+    // per lane would not fit beside the 128 weight-gradient accumulators).  Each wave gathers its share of the operands straight
+    // from the weight tensors (through the index maps of the f32 images composed with the operand order: all loads in flight
+    // together, one round trip), rounds and stores them: no f32 images, one barrier.
     constexpr int KS1 = (K::K1S + 3) / 4;                 // bf16 k-steps of layer 1 (slots q = 3*c4 + f, zero padded)
     constexpr int OP_W1 = 0, OP_W2 = OP_W1 + 4 * KS1, OP_W3T = OP_W2 + 16, OP_W2T = OP_W3T + 4, OP_W1T = OP_W2T + 16, OP_N = OP_W1T + 4 * K::MJ;
-    static_assert(OP_N * 64 * 2 <= FK::OFF_B1, "bf16 operand image fits over the f32 W1 | W2 | W3 images");
+    static_assert(OP_N * 64 * 2 <= FK::OFF_B1, "bf16 operand image fits below the bias vectors");
     const bf_s16x4* const BW = reinterpret_cast<const bf_s16x4*>(smem) + lane;      // operand o of this lane: BW[o * 64]
     if constexpr (BFM) {
-        bf_s16x4 img[(OP_N + NW - 1) / NW];    // this wave's share of the operands (round robin)
+        constexpr int NOP = (OP_N + NW - 1) / NW;    // this wave's share of the operands (round robin)
+        float raw[NOP][4];
         const int w2t_lane0 = (ci & 3) * 64 + (ci >> 2) * 16 + 4 * g;
-        auto build = [&](int o) -> bf_s16x4 {
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
+        auto gw = [&](const float* w, long off) -> float {   // unconditional load (clamped), zeroed afterwards: no branch per element
+            const float v = w[off < 0 ? 0 : off];
+            return off < 0 ? 0.0f : v;
+        };
+#pragma unroll
+        for (int k = 0; k < NOP; ++k) {
+            const int o = k * NW + wave;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) raw[k][r] = 0.0f;
             if (o < OP_W2) {                           // W1 forward: (m, s)
                 const int m = o / KS1, s_ = o % KS1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = 4 * s_ + r < K::K1S ? W1L[(m * K::K1S + 4 * s_ + r) * 64 + lane] : 0.0f;
+                for (int r = 0; r < 4; ++r)
+                    if (4 * s_ + r < K::K1S) raw[k][r] = gw(a.w1, map_w1((m * K::K1S + 4 * s_ + r) * 64 + lane));
             } else if (o < OP_W3T) {                   // W2 forward: (m2, kk)
                 const int m2 = (o - OP_W2) >> 2, kk = (o - OP_W2) & 3;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = W2L[(m2 * 16 + 4 * kk + r) * 64 + lane];
+                for (int r = 0; r < 4; ++r) raw[k][r] = gw(a.w2, map_w2((m2 * 16 + 4 * kk + r) * 64 + lane));
             } else if (o < OP_W2T) {                   // W3^T: m
                 const int m = o - OP_W3T;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = W3T[(m * 4 + r) * 64 + lane];
-            } else if (o < OP_W1T) {                   // W2^T: (m, mp) = W2[h2 = 16mp+4g+r][h1 = 16m+ci]
+                for (int r = 0; r < 4; ++r) raw[k][r] = gw(a.w3, map_w3t((m * 4 + r) * 64 + lane));
+            } else if (o < OP_W1T) {                   // W2^T: (m, mp) = W2[h2 = 16mp+4g+r][h1 = 16m+ci]: four consecutive image elements
                 const int m = (o - OP_W2T) >> 2, mp = (o - OP_W2T) & 3;
-                const f32x4 t = ld4(W2L + (mp * 16 + 4 * m) * 64 + w2t_lane0);
-                v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-            } else {                                   // W1^T: (mj, kk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) raw[k][r] = gw(a.w2, map_w2((mp * 16 + 4 * m) * 64 + w2t_lane0 + r));
+            } else if (o < OP_N) {                     // W1^T: (mj, kk)
                 const int mj = (o - OP_W1T) >> 2, kk = (o - OP_W1T) & 3;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = W1T[(mj * 16 + 4 * kk + r) * 64 + lane];
+                for (int r = 0; r < 4; ++r) raw[k][r] = gw(a.w1, map_w1t((mj * 16 + 4 * kk + r) * 64 + lane));
             }
-            return pack4(v[0], v[1], v[2], v[3]);
-        };
-#pragma unroll
-        for (int k = 0; k < (OP_N + NW - 1) / NW; ++k) {
-            const int o = k * NW + wave;
-            img[k] = o < OP_N ? build(o) : bf_s16x4{0, 0, 0, 0};
         }
-        __syncthreads();                               // every wave has read what it needs of the f32 images
 #pragma unroll
-        for (int k = 0; k < (OP_N + NW - 1) / NW; ++k) {
+        for (int k = 0; k < NOP; ++k) {
             const int o = k * NW + wave;
-            if (o < OP_N) *(reinterpret_cast<bf_s16x4*>(smem) + o * 64 + lane) = img[k];
+            if (o < OP_N) *(reinterpret_cast<bf_s16x4*>(smem) + o * 64 + lane) = pack4(raw[k][0], raw[k][1], raw[k][2], raw[k][3]);
         }
         __syncthreads();
     }
