@@ -170,19 +170,18 @@ def train_leg(dev, world, iters):
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
-        t0 = time.perf_counter()
-        for i in range(iters):
+        times = []
+        for i in range(iters):                            # every iteration timed on its own (synchronised): the MEDIAN is reported, one
+            t0 = time.perf_counter()                      # slow iteration (allocator, clocks) does not move it
             _, _, _, loss, _ = tr._iteration(i + 1, TB * world)
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        tt = torch.tensor(times, device=dev, dtype=torch.float64)
         if world > 1:
-            torch.distributed.barrier()
-        dt_s = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt_s], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            dt_s = float(tt.item())
-        out[name] = {"ms_per_iteration": dt_s / iters * 1e3, "cell_updates_per_s_fwd_bwd": world * TB * H * W * TT * 2 * iters / dt_s,
-                     "last_loss": float(loss)}
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)   # an iteration ends when its slowest rank does
+        med, mean = float(tt.median().item()), float(tt.mean().item())
+        out[name] = {"ms_per_iteration": med * 1e3, "ms_per_iteration_mean": mean * 1e3,
+                     "cell_updates_per_s_fwd_bwd": world * TB * H * W * TT * 2 / med, "last_loss": float(loss)}
         del tr                                            # the next leg's pool / history have other sizes: start it from an empty cache
         import gc
         gc.collect()
@@ -200,7 +199,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + rooflines only (profiling passes)")
-    ap.add_argument("--train-iters", type=int, default=3, help="iterations of the training-shaped leg (0: skip)")
+    ap.add_argument("--train-iters", type=int, default=5, help="iterations of the training-shaped leg (0: skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
