@@ -365,3 +365,50 @@ def test_cond_backward_kernel_forms_agree(ops, dtype, C, shape, gch, Tn):
             # its ReLU gates from the stored bf16 activations): same products, another fixed summation order
             d = float((one[k] - two[k]).abs().max()) / max(1e-12, float(one[k].abs().max()))
             assert d <= 2e-5, (k, d)
+
+
+def test_cond_backward_forms_fuzz(ops):
+    """Seeded shape / option fuzz of the two forms of backward kernel A against each other (fp32 products: bit for bit; bf16
+    MFMA: 2e-5 of the largest entry): ragged heights, widths that are multiples of 4 only, C in 9..16 (padded channel counts),
+    goal widths, alive channel on / off, explicit uniforms or in-kernel Philox, 1..4 steps.  NCAHIP_FUZZ_SEED / _CASES widen it."""
+    import os
+    import numpy as np
+    from test_gpu_parity import rand_cond_prm
+    rng = np.random.RandomState(int(os.environ.get("NCAHIP_FUZZ_SEED", "4242")))
+    for case in range(int(os.environ.get("NCAHIP_FUZZ_CASES", "10"))):
+        C = int(rng.randint(9, 17))
+        gch = int(rng.randint(0, C - 3))
+        B, H, W, Tn = int(rng.randint(1, 4)), int(rng.randint(5, 50)), 4 * int(rng.randint(2, 14)), int(rng.randint(1, 5))
+        ach = 3 if rng.rand() < 0.8 else -1
+        dtype = torch.bfloat16 if rng.rand() < 0.6 else torch.float32
+        philox = rng.rand() < 0.5
+        gen = torch.Generator().manual_seed(1000 + case)
+        prm = rand_cond_prm(C, seed=50 + case, out_scale=1.0)
+        x0 = bfr(torch.rand(B, C, H, W, generator=gen))
+        x0[0, :, : H // 3] = 0.0
+        goal = bfr(torch.randn(B, gch, H, W, generator=gen) * 0.5) if gch else None
+        us = None if philox else torch.rand(Tn, B, 1, H, W, generator=gen).to(DEV)
+        cot = torch.randn(B, C, H, W, generator=gen).to(DEV)
+        xd = x0.to(DEV).to(dtype)
+        gd = goal.to(DEV).to(dtype) if gch else None
+        w = weights(ops, prm, xd)
+        _, states, pre = ops.cond_grow(xd, Tn, gd, us, w, ach, seed=case, keep_history=True)
+        res = []
+        try:
+            for form in (0, 8):
+                ops.force_generic(form)
+                res.append(ops.cond_grow_backward(states, pre, gd, us, w, cot, Tn, ach, seed=case))
+                ops.check_errors()
+        finally:
+            ops.force_generic(0)
+        one, two = res
+        tag = (case, C, gch, B, H, W, Tn, ach, str(dtype), philox)
+        for k in one:
+            if one[k] is None:
+                assert two[k] is None
+                continue
+            if dtype == torch.float32:
+                assert torch.equal(one[k], two[k]), (k, tag)
+            else:
+                d = float((one[k] - two[k]).abs().max()) / max(1e-12, float(one[k].abs().max()))
+                assert d <= 2e-5, (k, d, tag)
