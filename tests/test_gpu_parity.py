@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import nca_oracle as O
 from util import REL_TOL, T, load, rel_err, sd
@@ -334,6 +335,24 @@ def _grad_close(got, ref, tol=2e-4):
     got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
     scale = max(float(ref.abs().max()), 1e-6)
     return float((got - ref).abs().max()) / scale < tol
+
+
+def _dynca_gate_ambiguous(x0, cond, us, prm, pad, rate=0.5, k=4e-6):
+    """Does the oracle trajectory contain a hidden pre-activation of an UPDATED cell that lies within rounding of zero
+    (|w1 y + b1| < k * (|w1| |y| + |b1|), k a few fp32 ulps times the summation-order spread of a 67..131-term dot product)?
+    Its ReLU gate may then resolve differently under the MFMA's and the CPU convolution's summation orders, and the gradients that
+    pass through that one unit -- dL/dx of its cell and stencil neighbourhood, its row of dW1, its db1 entry -- move by 1e-3 ..
+    1e-1 of the maximum (the smaller the model, the more one unit weighs) while the forward and everything else agree to 1e-6.
+    Seen once in a few dozen fuzz cases with the scale-3 weights drawn here (seeds 31337 / 90210 / 1)."""
+    x = x0
+    for u in us:
+        r = O.dynca_step(x, cond, u, prm, pad, rate, return_all=True)
+        pre = F.conv2d(r["y"], prm["w1.weight"], prm["w1.bias"])
+        bound = F.conv2d(r["y"].abs(), prm["w1.weight"].abs(), prm["w1.bias"].abs())
+        if bool(((pre.abs() < k * bound) & (r["m"] > 0)).any()):
+            return True
+        x = r["x"]
+    return False
 
 
 def test_cond_grow_backward_golden_g8(ops):
@@ -714,7 +733,8 @@ def test_dynca_backward_shape_fuzz(ops):
     stencil adjoint all see odd sizes here."""
     rng = np.random.RandomState(int(os.environ.get("NCAHIP_FUZZ_SEED", "888")))
     pads = ["replicate", "circular", "reflect", "constant"]
-    for case in range(int(os.environ.get("NCAHIP_FUZZ_CASES", "14"))):
+    ncases, ambiguous = int(os.environ.get("NCAHIP_FUZZ_CASES", "14")), 0
+    for case in range(ncases):
         # (round 2: C up to 32 and hidden layers beyond 128 -- 128-wide slices -- through the C driver as well)
         C, fc = [(12, 96), (16, 128), (8, 64), (16, 96), (5, 40), (32, 256), (20, 100), (24, 192), (16, 320), (32, 128)][int(rng.randint(0, 10))]
         cc = int(rng.choice([0, 2, 3]))
@@ -734,9 +754,13 @@ def test_dynca_backward_shape_fuzz(ops):
         _, states = ops.dynca_nsteps(x0.to(DEV), 2, cd, us.to(DEV), w, pad, 0.5, keep_history=True)
         gr = ops.dynca_nsteps_backward(states, cd, us.to(DEV), w, cot.to(DEV), None, 2, pad, 0.5)
         tag = (case, C, fc, cc, B, H, W, pad)
-        assert _grad_close(gr["x0"], dx0), tag
-        assert _grad_close(gr["w1"], grads["w1.weight"][:, :, 0, 0]) and _grad_close(gr["b1"], grads["w1.bias"]), tag
-        assert _grad_close(gr["w2"], grads["w2.weight"][:, :, 0, 0]) and _grad_close(gr["b2"], grads["w2.bias"]), tag
+        ok = (_grad_close(gr["x0"], dx0) and _grad_close(gr["w1"], grads["w1.weight"][:, :, 0, 0]) and _grad_close(gr["b1"], grads["w1.bias"])
+              and _grad_close(gr["w2"], grads["w2.weight"][:, :, 0, 0]) and _grad_close(gr["b2"], grads["w2.bias"]))
+        if not ok and rel_err(states[-1].cpu(), xT) < 1e-5 and _dynca_gate_ambiguous(x0, cond, list(us), prm, pad):
+            ambiguous += 1      # a ReLU gate within rounding of zero: the two sides may legitimately differ (see the helper)
+            continue
+        assert ok, tag
+    assert 4 * ambiguous <= ncases, (ambiguous, ncases)
 
 
 def test_dynca_step_shape_fuzz(ops):
