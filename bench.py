@@ -17,6 +17,7 @@ Extra objects on the JSON line:
                     the HIP-event launch time (events on the launch stream).
   roofline_stencil  standalone DyNCA perception stencil: HBM bound, 20*C bytes/cell.
   bf16_storage      the same grow loop on the bf16-storage kernels (informational; `value` stays the fp32 path).
+  backward          the recompute-based backward of the same loop (fp32 / bf16 history), per step (informational).
   f32_bf16x3        the same loop with ncahip_cond_precision(1) (opt-in bf16-pair emulation of the fp32 products).
   cpu_baseline      the CPU oracle (pure-PyTorch restatement == the reference's CPU path, bit-identical)
                     timed on this box's host cores on a bounded sample (rank 0, N=1 only).
@@ -348,6 +349,19 @@ def main():
             ms_t = event_ms(lambda: ops.cond_grow(xd, T, gd, torch.stack([torch.rand_like(xd[:, 0:1]) for _ in range(T)]), w, ALIVE_CH), 5) / T
             result["mask_rng_torch"] = {"value": cells / (ms_t * 1e-3), "unit": "cell-updates/s", "launch_ms": ms_t,
                                         "note": "explicit uniforms drawn with torch.rand_like per step (drop-in default)"}
+            # ---- the recompute-based backward of the same loop at the same shape (ncahip_cond_grow_bwd_f32 / _bf16: 16 steps with
+            # history, cotangent of the final state; fp32 history with exact-f32 products, bf16 history with bf16-MFMA products):
+            # informational -- the kernels the `train` leg spends its time in, without the trainer around them
+            TB_ = 16
+            cot = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(11)).to(dev)
+            result["backward"] = {"nca_steps": TB_}
+            for name, xq, gq in (("f32", xd, gd), ("bf16", xb16, gb16)):
+                _, st_h, pre_h = ops.cond_grow(xq, TB_, gq, None, w, ALIVE_CH, seed=42, keep_history=True)
+                ms_f = event_ms(lambda: ops.cond_grow(xq, TB_, gq, None, w, ALIVE_CH, seed=42, keep_history=True), 5) / TB_
+                ms_w = event_ms(lambda: ops.cond_grow_backward(st_h, pre_h, gq, None, w, cot, TB_, ALIVE_CH, seed=42), 5) / TB_
+                result["backward"][name] = {"fwd_us_per_step": ms_f * 1e3, "bwd_us_per_step": ms_w * 1e3, "bwd_over_fwd": ms_w / ms_f,
+                                            "fwd_bwd_cell_updates_per_s": cells / ((ms_f + ms_w) * 1e-3)}
+                del st_h, pre_h
     # ---- training-shaped leg on EVERY rank (the path that contains the gradient all-reduce when N > 1): informational
     train = train_leg(dev, world, args.train_iters) if (args.train_iters > 0 and not args.no_extras) else None
     if rank == 0:
