@@ -236,3 +236,21 @@ def test_slw_and_gram_follow_the_reference_reductions():
         gg = float(G({"generated_images": gen, "nca_state": gen})[0])
         fr = sum(float((_gram(G.style_feats[l]) - _gram(G.vgg(gen, STYLE_LAYERS)[l])).square().mean()) for l in STYLE_LAYERS)
         assert abs(gg - fr) < 1e-5 * abs(fr)
+
+
+def test_traffic_stamp_hash_matches_bench():
+    """bench.py reports `roofline.traffic` only from a profiles/*_traffic.json whose `_meta.csrc_sha16` equals the hash of the kernel
+    sources it runs on; tools/collect_traffic.py writes that stamp.  Both must hash the same files the same way (a kernel edit
+    without a new PMC pass only warns here: bench.py then reports `traffic: null` and names the stale file)."""
+    import glob, hashlib, json, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "video-stylization-with-nca_amd", "csrc", "*"))):   # as tools/collect_traffic.py
+        h.update(open(f, "rb").read())
+    assert bench.csrc_sha16() == h.hexdigest()[:16]
+    stamps = [json.load(open(f)).get("_meta", {}).get("csrc_sha16") for f in glob.glob(os.path.join(root, "profiles", "*_traffic.json"))]
+    if bench.csrc_sha16() not in stamps:   # legitimate while kernels are being edited: bench.py then reports `traffic: null`
+        import warnings
+        warnings.warn("no profiles/*_traffic.json was collected from the current kernel sources: run tools/gpu_round.sh")
