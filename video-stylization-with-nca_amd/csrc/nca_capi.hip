@@ -534,10 +534,9 @@ static int dynca_nsteps_bwd_impl(bool two_scale, const void* states_v, int sb, i
             x_t = x32;
         }
         float* const g_out = t == 0 ? g_x0 : gbuf[t & 1];
-        if (int rc = hip_result(nca_launch_dynca_perceive(x_t, y, B, C, H, W, pad_mode, st), "dynca nsteps bwd perceive")) return rc;
-        if (two_scale) {   // y <- two-scale perception of x_t (the B rows of the layer-1 weight-gradient product)
+        // y (the B rows of the layer-1 weight-gradient product) is written by the first slice's step kernel, which recomputes it anyway
+        if (two_scale) {   // coarse level of the two-scale perception: input of the step kernel
             if (int rc = hip_result(nca_launch_dynca_coarse_perceive(x_t, pcb, B, C, H, W, pad_mode, st), "dynca nsteps bwd coarse perceive")) return rc;
-            if (int rc = hip_result(nca_launch_dynca_ms_combine(y, pcb, B, C, H, W, st), "dynca nsteps bwd combine")) return rc;
         }
         for (int sl = 0; sl < p.nsl; ++sl) {
             const int h0 = sl * 128, fs = fc - h0 < 128 ? fc - h0 : 128;
@@ -546,6 +545,7 @@ static int dynca_nsteps_bwd_impl(bool two_scale, const void* states_v, int sb, i
             a.w2_ld = fc;
             a.gw2_ws = ws2;
             a.pc = pcb;
+            a.ybuf = sl == 0 ? y : nullptr;
             if (int rc = hip_result(nca_launch_dynca_step_bwd_mlp(a, st, sl > 0), "dynca nsteps bwd step")) return rc;
             // slabs hold [C x fs | C] of THIS slice (compact); slices narrower than p.fs use the front of their accumulator
             if (int rc = hip_result(nca_launch_reduce_rows(ws2, acc2 + (size_t)sl * a2n, p.grid2, C * fs + C, st, true), "dynca nsteps bwd reduce")) return rc;

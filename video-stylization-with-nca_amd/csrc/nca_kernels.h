@@ -65,6 +65,8 @@ struct NcaDyncaArgs {
     const float* pc;       // two-scale perception (perception_scales = [0, 1]): coarse-level perception [B,4C,H/2,W/2], or null
     const float* coarse_add;  // backward stencil, two-scale: dL/dx of the coarse level [B,C,H/2,W/2]; 0.25 * parent is added to g_out
     int dy_half;              // backward stencil, two-scale: the fine level carries 0.5 * dL/dy
+    float* ybuf;              // backward MLP kernel: if set, the recomputed perception y (two-scale: the combined one) is written here,
+                              // [B,4C,H,W] in perceive_torch's row order -- the B rows of the layer-1 weight-gradient product
 };
 
 struct NcaCondArgs {

@@ -450,6 +450,29 @@ __global__ __launch_bounds__(kThreads, ((BWD && CP > 16) || MS) ? 1 : 2) void dy
                             dO[n][m2][r] = (live[n] && ch < C) ? gv * mk : 0.0f;
                         }
                 }
+                // The perception just recomputed is also the B operand of the layer-1 weight-gradient product (dW1 = dh y^T, in
+                // gram_rows_kernel): written out here -- slot 4c'+f of lane (g, cell) is channel 4c'+g, filter f, i.e. row
+                // f*C + 4c'+g of perceive_torch's output; lane part of the address once per n, row part a scalar offset -- instead
+                // of a perception (and, two-scale, a combine) launch of its own that re-reads x_t.
+                if constexpr (!ACC) {
+                    if (a.ybuf) {
+                        const unsigned pl4 = (unsigned)plane * 4u;
+                        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.ybuf + (size_t)b * 4 * C * plane, 0, -1, 0x00020000);
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            if (!live[n]) continue;
+                            const unsigned vy = (unsigned)((ty0 + r0[n]) * W + tx0 + q0[n]) * 4u + (unsigned)g * pl4;
+#pragma unroll
+                            for (int cq4 = 0; cq4 < CP / 4; ++cq4)
+                                if (4 * cq4 + g < C) {
+#pragma unroll
+                                    for (int f = 0; f < 4; ++f)
+                                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(P[n][4 * cq4 + f]), ry, (int)vy,
+                                                                              (int)((unsigned)(f * C + 4 * cq4) * pl4), 0);
+                                }
+                        }
+                    }
+                }
                 // Output addressing: the lane's part (cell, lane-dependent row group) is ONE vector offset per n, the remaining row
                 // index of each store a scalar offset -- per-store 64-bit vector address arithmetic was ~1300 VALU instructions per
                 // pass, in the same issue slots as the exact-f32 MFMAs.  (Launcher: fc*H*W*4 and 4C*H*W*4 below 4 GiB.)
