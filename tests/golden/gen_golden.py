@@ -9,7 +9,7 @@ The GPU box and CI replay them through tests/test_oracle_golden.py.
     python tests/golden/gen_golden.py            # rewrites every fixture
 
 Reference entry points exercised (file:line in the reference checkout):
-  EncoderConditioning/nca.py:61-215      ConditionedNCA.forward / grow / alive / generate_seed
+  EncoderConditioning/nca.py:61-215      ConditionedNCA.forward / grow / alive / generate_seed (default arguments: C = 20, G11)
   EncoderConditioning/encoder.py:5-64    ImageEncoder
   ConditioneDyNCA/models/dynca.py:7-253  DyNCA.forward / forward_nsteps / perceive_torch / seed, EdgeExtractor, CPE2D
   ExtraChannels/models/dynca.py:7-167    DyNCA (state-concat conditioning variant)
@@ -407,6 +407,51 @@ def g8_grads():
     save("g8_dynca_grads", T=T, **arrs)
 
 
+# ---------------------------------------------------------------- G11: gradients of the reference's DEFAULT model (C = 20) and C = 32
+def g11_cond_grads_wide():
+    """ConditionedNCA with its default arguments (nca.py:62-74: num_hidden_channels = 16 -> C = 3 + 16 + 1 = 20) and a
+    28-hidden-channel one (C = 32): d<cot, grow(x0, T, goal)> / d{x0, goal, weights, encoder.embed} through the reference's
+    own grow (nca.py:197-209, encoder included) under the reference's autograd."""
+    arrs = {}
+    for tag, hidden, T, seed in (("c20", 16, 4, 11), ("c32", 28, 3, 12)):
+        torch.manual_seed(seed)
+        m = ref_nca.ConditionedNCA(target_shape=(3, 16, 16), num_hidden_channels=hidden)
+        rand_biases_(m.update_net)
+        with torch.no_grad():
+            m.update_net.out[4].weight.mul_(3.0)
+        C = m.num_channels
+        torch.manual_seed(seed + 100)
+        x0 = torch.rand(2, C, 16, 16).requires_grad_(True)
+        x0.data[0, :, :5] = 0.0                     # dead cells
+        x0.data[1, :, 8:10, 8:10] *= 40.0           # clamp gating
+        goal = torch.rand(2, 3, 16, 16)
+        cot = torch.randn(2, C, 16, 16)
+        genc = m.encode(goal)                       # [B, hidden, H, W]
+        genc.retain_grad()
+        gpad = torch.nn.functional.pad(genc, (0, 0, 0, 0, C - hidden, 0))
+        us = []
+        x = x0
+        for t in range(T):
+            torch.manual_seed(900 + t); us.append(torch.rand_like(x[:, 0:1]))
+            torch.manual_seed(900 + t); x, _ = m.forward((x, gpad))
+        # grow() is encode + pad + T x forward (nca.py:197-209): checked here against the loop above's pieces under one seed
+        with torch.no_grad():
+            torch.manual_seed(77); xa = m.grow(x0.detach(), T, goal)
+            torch.manual_seed(77); xb = x0.detach()
+            for t in range(T):
+                xb, _ = m.forward((xb, gpad.detach()))
+        assert torch.equal(xa, xb)
+        (x * cot).sum().backward()
+        arrs.update({f"{tag}.x0": x0.detach(), f"{tag}.goal_img": goal, f"{tag}.goal_enc": genc.detach(), f"{tag}.cot": cot,
+                     f"{tag}.us": torch.stack(us), f"{tag}.xT": x.detach(), f"{tag}.d_x0": x0.grad, f"{tag}.d_goal_enc": genc.grad,
+                     f"{tag}.T": T, f"{tag}.alive_ch": m.living_channel_dim})
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                arrs[f"{tag}.grad." + n] = p.grad
+        arrs.update({f"{tag}." + k: v for k, v in sd_np(m).items()})
+    save("g11_cond_grads_wide", thr=0.1, fire_rate=0.5, **arrs)
+
+
 # ---------------------------------------------------------------- G9: seeds
 def g9_seeds():
     m = ref_nca.ConditionedNCA(target_shape=(3, 16, 16), num_hidden_channels=8, living_channel_dim=3)
@@ -426,4 +471,4 @@ if __name__ == "__main__":
     with torch.no_grad():
         pass
     g1_cond_step(); g2_cond_grow(); g2l_cfg1(); g3_dynca(); g4_perception(); g5_real_weights()
-    g6_extra_channels(); g7_encoders(); g8_grads(); g9_seeds(); g10_two_scale_video_model()
+    g6_extra_channels(); g7_encoders(); g8_grads(); g9_seeds(); g10_two_scale_video_model(); g11_cond_grads_wide()

@@ -295,6 +295,41 @@ def test_dynca_c32_trains_through_composed_path():
     assert rel_err(m.w1.weight.grad.cpu(), prm["w1.weight"].grad) < 2e-4
 
 
+@pytest.mark.parametrize("tag,hidden", [("c20", 16), ("c32", 28)])
+def test_default_model_grow_backward_matches_reference_autograd_g11(tag, hidden, monkeypatch):
+    """The drop-in class with the reference's DEFAULT arguments (num_hidden_channels = 16 -> C = 20, nca.py:62-74; train.py
+    -N 16) and a C = 32 one: grow() + backward on the fused kernels, every gradient (x0, UpdateNet, perception, encoder.embed)
+    against the reference's own autograd (G11) at 2e-4 -- and the composed eager pass is unreachable for these shapes."""
+    from ncahip import autograd as AG
+    from ncahip.nca import ConditionedNCA
+
+    def _no(*a, **k):
+        raise AssertionError("the composed eager pass was reached")
+    monkeypatch.setattr(AG, "_cond_grow_composed", _no)
+    g = load("g11_cond_grads_wide")
+    m = ConditionedNCA(target_shape=(3, 16, 16)) if hidden == 16 else ConditionedNCA(target_shape=(3, 16, 16), num_hidden_channels=hidden)
+    m.load_state_dict({k[len(tag) + 4:]: T(v) for k, v in g.items() if k.startswith(tag + ".sd.")}, strict=True)
+    Tn = int(g[f"{tag}.T"])
+    md = m.to(DEV)
+    _inject(md, [T(u) for u in g[f"{tag}.us"]])
+    xd = T(g[f"{tag}.x0"], DEV).requires_grad_(True)
+    out = md.grow(xd, Tn, T(g[f"{tag}.goal_img"], DEV))
+    assert rel_err(out, T(g[f"{tag}.xT"])) < REL_TOL
+    (out * T(g[f"{tag}.cot"], DEV)).sum().backward()
+
+    def close(got, ref, tol=2e-4):
+        got, ref = got.detach().double().cpu(), ref.double()
+        return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-6) < tol
+    assert close(xd.grad, T(g[f"{tag}.d_x0"]))
+    n = 0
+    for name, w in md.named_parameters():
+        key = f"{tag}.grad.{name}"
+        if key in g:
+            assert close(w.grad, T(g[key])), name
+            n += 1
+    assert n == 9
+
+
 def test_conditioned_nca_default_arguments_c20():
     """ConditionedNCA() exactly as the reference constructs it by default (target 3x64x64, 16 hidden channels -> C = 20,
     nca.py:62-94; train.py -N 16): forward on the fused generic kernels (two output tiles), gradients through the composed

@@ -381,7 +381,34 @@ def test_cond_grow_backward_golden_g8(ops):
         assert torch.equal(gr[k], gr2[k]), k
 
 
-@pytest.mark.parametrize("C,shape,gch,alive,Tn", [(16, (2, 32, 48), 12, 3, 3), (12, (1, 20, 36), 8, 3, 2), (16, (2, 16, 16), 16, -1, 2)])
+@pytest.mark.parametrize("tag", ["c20", "c32"])
+def test_cond_grow_backward_golden_g11_wide(ops, tag):
+    """16 < C <= 32 on the fused backward (front + matrix kernels at CP = 20 / 32, stencil adjoint): the reference's DEFAULT
+    model (C = 20, nca.py:62-74) and a C = 32 one against the reference's own autograd (G11), 2e-4."""
+    g = load("g11_cond_grads_wide")
+    prm = {k[len(tag) + 4:]: T(v) for k, v in g.items() if k.startswith(tag + ".sd.")}
+    C, a, Tn = g[f"{tag}.x0"].shape[1], int(g[f"{tag}.alive_ch"]), int(g[f"{tag}.T"])
+    x0, goal, us, cot = T(g[f"{tag}.x0"], DEV), T(g[f"{tag}.goal_enc"], DEV), T(g[f"{tag}.us"], DEV), T(g[f"{tag}.cot"], DEV)
+    w = cond_w(ops, prm, x0)
+    xT, states, pre = ops.cond_grow(x0, Tn, goal, us, w, a, keep_history=True)
+    assert rel_err(xT, T(g[f"{tag}.xT"])) < REL_TOL
+    gr = ops.cond_grow_backward(states, pre, goal, us, w, cot, Tn, a)
+    assert _grad_close(gr["x0"], T(g[f"{tag}.d_x0"]))
+    assert _grad_close(gr["goal"], T(g[f"{tag}.d_goal_enc"]))
+    assert _grad_close(gr["wp"].view(3 * C, 1, 3, 3), T(g[f"{tag}.grad.perception_net.weight"]))
+    assert _grad_close(gr["w1"], T(g[f"{tag}.grad.update_net.out.0.weight"])[:, :, 0, 0])
+    assert _grad_close(gr["b1"], T(g[f"{tag}.grad.update_net.out.0.bias"]))
+    assert _grad_close(gr["w2"], T(g[f"{tag}.grad.update_net.out.2.weight"])[:, :, 0, 0])
+    assert _grad_close(gr["b2"], T(g[f"{tag}.grad.update_net.out.2.bias"]))
+    assert _grad_close(gr["w3"], T(g[f"{tag}.grad.update_net.out.4.weight"])[:, :, 0, 0])
+    gr2 = ops.cond_grow_backward(states, pre, goal, us, w, cot, Tn, a)   # deterministic: bitwise identical on a second run
+    for k in gr:
+        assert torch.equal(gr[k], gr2[k]), k
+
+
+@pytest.mark.parametrize("C,shape,gch,alive,Tn", [(16, (2, 32, 48), 12, 3, 3), (12, (1, 20, 36), 8, 3, 2), (16, (2, 16, 16), 16, -1, 2),
+                                                  (20, (2, 32, 48), 16, 3, 3), (24, (1, 20, 36), 20, 3, 2), (32, (2, 24, 16), 28, -1, 2),
+                                                  (17, (1, 9, 20), 3, 3, 2), (28, (1, 37, 44), 28, 3, 2), (22, (3, 5, 8), 0, 4, 2)])
 def test_cond_grow_backward_vs_oracle_autograd(ops, C, shape, gch, alive, Tn):
     B, H, W = shape
     gen = torch.Generator().manual_seed(C + W)
@@ -390,16 +417,19 @@ def test_cond_grow_backward_vs_oracle_autograd(ops, C, shape, gch, alive, Tn):
     if alive >= 0:
         x0[0, :, : H // 4] = 0.0
         x0[-1, :, H // 2: H // 2 + 2, 4:8] *= 30.0
-    goal = torch.randn(B, gch, H, W, generator=gen)
+    goal = torch.randn(B, gch, H, W, generator=gen) if gch else None
     us = torch.rand(Tn, B, 1, H, W, generator=gen)
     cot = torch.randn(B, C, H, W, generator=gen)
-    xT, dx0, dg, grads = O.cond_grow_loss_grads(x0, O.cond_pad_goal(goal, C), list(us), prm, max(alive, 0), 0.1, 0.5, cot) \
+    gpad = O.cond_pad_goal(goal, C) if gch else torch.zeros_like(x0)
+    xT, dx0, dg, grads = O.cond_grow_loss_grads(x0, gpad, list(us), prm, max(alive, 0), 0.1, 0.5, cot) \
         if alive >= 0 else _oracle_noalive_grads(x0, goal, us, prm, cot, C)
     w = cond_w(ops, prm, x0.to(DEV))
-    _, states, pre = ops.cond_grow(x0.to(DEV), Tn, goal.to(DEV), us.to(DEV), w, alive, keep_history=True)
-    gr = ops.cond_grow_backward(states, pre, goal.to(DEV), us.to(DEV), w, cot.to(DEV), Tn, alive)
+    gd = goal.to(DEV) if gch else None
+    _, states, pre = ops.cond_grow(x0.to(DEV), Tn, gd, us.to(DEV), w, alive, keep_history=True)
+    gr = ops.cond_grow_backward(states, pre, gd, us.to(DEV), w, cot.to(DEV), Tn, alive)
     assert _grad_close(gr["x0"], dx0)
-    assert _grad_close(gr["goal"], dg[:, C - gch:])
+    if gch:
+        assert _grad_close(gr["goal"], dg[:, C - gch:])
     assert _grad_close(gr["wp"].view(3 * C, 1, 3, 3), grads["perception_net.weight"])
     for k, n in (("w1", "update_net.out.0.weight"), ("w2", "update_net.out.2.weight"), ("w3", "update_net.out.4.weight")):
         assert _grad_close(gr[k], grads[n][:, :, 0, 0]), k
@@ -685,8 +715,8 @@ def test_cond_backward_shape_fuzz(ops):
     threshold are skipped (the mask's derivative is zero almost everywhere; on the threshold the two sides disagree)."""
     rng = np.random.RandomState(int(os.environ.get("NCAHIP_FUZZ_SEED", "777")))
     done = 0
-    for case in range(int(os.environ.get("NCAHIP_FUZZ_CASES", "8"))):
-        C = int(rng.choice([5, 8, 12, 13, 16]))
+    for case in range(int(os.environ.get("NCAHIP_FUZZ_CASES", "16"))):
+        C = int(rng.choice([5, 8, 12, 13, 16, 17, 20, 23, 24, 29, 32]))
         B = int(rng.randint(1, 3)); H = int(rng.randint(1, 25)); W = 4 * int(rng.randint(1, 11))
         alive = int(rng.choice([-1, 3, min(4, C - 1)]))
         gch = int(rng.choice([0, 1, max(1, C - 4), C]))

@@ -205,6 +205,30 @@ def test_g8_cond_grads(golden_dir):
                           "update_net.out.2.weight", "update_net.out.2.bias", "update_net.out.4.weight"}
 
 
+def test_g11_cond_grads_wide(golden_dir):
+    """The reference's DEFAULT model (C = 20) and a C = 32 one: gradients of <cot, grow> through the reference's own autograd,
+    encoder included (generated by importing the reference: tests/golden/gen_golden.py g11_cond_grads_wide)."""
+    g = load(golden_dir, "g11_cond_grads_wide")
+    for tag in ("c20", "c32"):
+        prm = {k[len(tag) + 4:]: T(v) for k, v in g.items() if k.startswith(tag + ".sd.")}
+        C = g[f"{tag}.x0"].shape[1]
+        p = {k: v.clone().requires_grad_(k.startswith(("perception", "update")) or "embed" in k) for k, v in prm.items()}
+        x0 = T(g[f"{tag}.x0"]).requires_grad_(True)
+        genc = O.image_encoder(T(g[f"{tag}.goal_img"]), p)
+        genc.retain_grad()
+        assert same(genc.detach(), g[f"{tag}.goal_enc"]), tag
+        x = O.cond_grow(x0, O.cond_pad_goal(genc, C), [T(u) for u in g[f"{tag}.us"]], p, int(g[f"{tag}.alive_ch"]),
+                        float(g["thr"]), float(g["fire_rate"]))
+        (x * T(g[f"{tag}.cot"])).sum().backward()
+        assert same(x.detach(), g[f"{tag}.xT"]) and same(x0.grad, g[f"{tag}.d_x0"]) and same(genc.grad, g[f"{tag}.d_goal_enc"]), tag
+        n = 0
+        for k, v in p.items():
+            if v.grad is not None:
+                assert same(v.grad, g[f"{tag}.grad.{k}"]), (tag, k)
+                n += 1
+        assert n == 9, (tag, n)
+
+
 def test_g8_dynca_grads(golden_dir):
     g = load(golden_dir, "g8_dynca_grads")
     for pad in O.PAD_MODES:

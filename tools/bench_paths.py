@@ -3,6 +3,7 @@
 HIP events on the launch stream).  `python tools/bench_paths.py [names...]`; without names: all.
 
   cond_train      ConditionedNCA grow with history + backward, B=8 T=16 (fp32 and bf16 history)
+  cond_c20        the reference's DEFAULT ConditionedNCA (C = 20, 16 hidden channels): forward, forward with history + fused backward
   cfg3            BASELINE configs[2] shape: B=32 C=16 256^2 T=96, forward with history + backward, fp32 and bf16
   dynca_fwd       DyNCA forward steps: C=16/fc=128, C=12/fc=96, C=32/fc=128 and C=32/fc=256 at 2x512^2 (configs[4])
   dynca_train     DyNCA forward with history + backward (the C driver): C=16/fc=128, C=12/fc=96, C=32/fc=256 at 2x512^2
@@ -48,19 +49,29 @@ def emit(**kw):
     print(json.dumps(kw), flush=True)
 
 
+def wide_weights(C, gen, hidden=64):
+    """bench.make_weights' distribution at another channel count"""
+    return {"perception_net.weight": torch.randn(3 * C, 1, 3, 3, generator=gen) * 0.3,
+            "update_net.out.0.weight": torch.randn(hidden, 3 * C, 1, 1, generator=gen) / (3 * C) ** 0.5,
+            "update_net.out.0.bias": torch.randn(hidden, generator=gen) * 0.1,
+            "update_net.out.2.weight": torch.randn(hidden, hidden, 1, 1, generator=gen) / hidden ** 0.5,
+            "update_net.out.2.bias": torch.randn(hidden, generator=gen) * 0.1,
+            "update_net.out.4.weight": torch.randn(C, hidden, 1, 1, generator=gen) * (0.02 / hidden ** 0.5)}
+
+
 def cond_case(B, H=256, W=256, C=16, dtype=torch.float32):
     gen = torch.Generator().manual_seed(0)
-    prm = bench.make_weights(gen)
+    prm = bench.make_weights(gen) if C == 16 else wide_weights(C, gen)
     x = torch.rand(B, C, H, W, generator=gen).to(DEV, dtype)
-    goal = (torch.randn(B, 12, H, W, generator=gen) * 0.5).to(DEV, dtype)
+    goal = (torch.randn(B, C - 4, H, W, generator=gen) * 0.5).to(DEV, dtype)
     cot = torch.randn(B, C, H, W, generator=gen).to(DEV)
     w = ops.CondWeights(prm["perception_net.weight"], prm["update_net.out.0.weight"], prm["update_net.out.0.bias"],
                         prm["update_net.out.2.weight"], prm["update_net.out.2.bias"], prm["update_net.out.4.weight"], x)
     return x, goal, cot, w
 
 
-def cond_train(B, T, dtype, name, iters=10):
-    x, goal, cot, w = cond_case(B, dtype=dtype)
+def cond_train(B, T, dtype, name, iters=10, C=16):
+    x, goal, cot, w = cond_case(B, C=C, dtype=dtype)
     box = {}
 
     def fwd():
@@ -72,7 +83,8 @@ def cond_train(B, T, dtype, name, iters=10):
 
     (tf, tb), (mf, mb) = timed([fwd, bwd], iters=iters)
     cells = B * 256 * 256 * T
-    emit(path=name, storage=str(dtype).split(".")[-1], B=B, T=T, fwd_ms=tf, bwd_ms=tb, fwd_us_per_step=tf / T * 1e3,
+    flop = 2 * (27 * C + 256 * C + 4096)      # forward flop per cell-update; the backward is ~2.4x that on MFMA
+    emit(path=name, C=C, storage=str(dtype).split(".")[-1], B=B, T=T, fwd_frac_f32_mfma=cells * flop / tf / 1e9 / 157.3, fwd_ms=tf, bwd_ms=tb, fwd_us_per_step=tf / T * 1e3,
          bwd_us_per_step=tb / T * 1e3, fwd_bwd_Gcells_s=cells / (tf + tb) / 1e6, bwd_over_fwd=tb / tf,
          history_GB=(T + 1) * x.numel() * x.element_size() / 1e9, min_fwd_ms=mf, min_bwd_ms=mb)
 
@@ -175,6 +187,9 @@ def main(names):
     if allp or "cond_train" in names:
         cond_train(8, 16, torch.float32, "cond_train")
         cond_train(8, 16, torch.bfloat16, "cond_train")
+    if allp or "cond_c20" in names:
+        cond_train(8, 16, torch.float32, "cond_c20", C=20)
+        cond_train(8, 16, torch.float32, "cond_c32", C=32)
     if allp or "cfg3" in names:
         cond_train(32, 96, torch.float32, "cfg3", iters=10)
         cond_train(32, 96, torch.bfloat16, "cfg3", iters=10)

@@ -639,7 +639,7 @@ size_t ncahip_cond_grow_bwd_workspace(int B, int C, int H, int W, int hidden) {
     return 4 * align256(n) + align256(3 * n) +
            align256((size_t)(nca_cond_bwd_nslab() + 1) * nca_cond_bwd_slab_floats(C, hidden) * sizeof(float)) +
            align256((size_t)nca_cond_bwd_nblk(B, C, H, W) * 27 * sizeof(float)) +
-           align256(nca_cond_bwd_fm_pscr_bytes(B, H, W)) + align256(nca_cond_bwd_fm_doscr_bytes(B, H, W));
+           align256(nca_cond_bwd_fm_pscr_bytes(B, C, H, W)) + align256(nca_cond_bwd_fm_doscr_bytes(B, C, H, W));
 }
 
 // states / goal: fp32 or bf16 (sb = bytes per element); everything else fp32
@@ -654,13 +654,14 @@ static int cond_grow_bwd_impl(const void* states_v, int sb, const uint8_t* pre, 
     const bool bf16 = sb == 2;
     if (T < 1 || !states || !pre || !g_final || !g_x0 || !g_wp || !g_w1 || !g_b1 || !g_w2 || !g_b2 || !g_w3 || !workspace)
         return fail(NCAHIP_EINVAL, "cond grow bwd: null pointer or T < 1");
-    if (int rc = check_cond(states, g_x0, pre, goal_v, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch)) return rc;
+    // fp32 history: C <= 32 (16 < C <= 32 on the front + matrix kernels); bf16 history: C <= 16 (as the bf16 forward)
+    if (int rc = check_cond(states, g_x0, pre, goal_v, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch, bf16 ? kMaxC : kMaxCCondFwd)) return rc;
     if (goal_ch > 0 && !g_goal) return fail(NCAHIP_EINVAL, "cond grow bwd: g_goal required when goal_ch > 0");
     const uintptr_t amask = bf16 ? 7 : 15;   // state-type tensors: 4-cell groups (16 bytes fp32, 8 bytes bf16)
     if (W % 4 != 0 || (((uintptr_t)states | (uintptr_t)goal_v) & amask) != 0 ||
         ((uintptr_t)g_final | (uintptr_t)g_x0 | (uintptr_t)workspace) % 16 != 0)
         return fail(NCAHIP_ERANGE, "cond grow bwd: needs W %% 4 == 0 and 16-byte aligned buffers (8-byte for bf16 states / goal)");
-    if ((size_t)H * W >= ((size_t)1 << 24) || (size_t)16 * H * W * 4 >= ((size_t)1 << 32))
+    if ((size_t)H * W >= ((size_t)1 << 24) || (size_t)(C > 16 ? C : 16) * H * W * 4 >= ((size_t)1 << 32))
         return fail(NCAHIP_ERANGE, "cond grow bwd: grid too large for the tile kernels' 32-bit addressing (H*W < 2^24)");
     if (workspace_bytes < ncahip_cond_grow_bwd_workspace(B, C, H, W, hidden))
         return fail(NCAHIP_EINVAL, "cond grow bwd: workspace too small");
@@ -678,7 +679,7 @@ static int cond_grow_bwd_impl(const void* states_v, int sb, const uint8_t* pre, 
     float* red = slabs + (size_t)nslab * sf;  // one extra slab: the reduced gradients
     p += align256((size_t)(nslab + 1) * sf * sizeof(float));
     float* wpp = (float*)p; p += align256((size_t)nblk * 27 * sizeof(float));
-    void* pscr = p; p += align256(nca_cond_bwd_fm_pscr_bytes(B, H, W));   // front kernel -> matrix kernel scratch (operand order)
+    void* pscr = p; p += align256(nca_cond_bwd_fm_pscr_bytes(B, C, H, W));   // front kernel -> matrix kernel scratch (operand order)
     void* doscr = p;
     hipError_t e = hipMemsetAsync(slabs, 0, (size_t)nslab * sf * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(wpp, 0, (size_t)nblk * 27 * sizeof(float), st);

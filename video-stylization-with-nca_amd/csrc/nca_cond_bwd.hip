@@ -1053,6 +1053,12 @@ hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st, bo
     }
     if (ba.f.C <= 12) return launch_bwd<12, StF32>(ba, st);
     if (ba.f.C <= 16) return launch_bwd<16, StF32>(ba, st);
+    if (ba.f.C <= 32) {   // 16 < C <= 32 (the reference's default model is C = 20, nca.py:62-94): front + matrix kernels only
+        if (!ba.pscr || !ba.doscr) return hipErrorInvalidValue;
+        if (hipError_t e = nca_launch_cond_step_bwd_fm(ba, st, 0); e != hipSuccess) return e;
+        hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<float>, dim3(ba.nblk), dim3(256), 0, st, ba);
+        return hipGetLastError();
+    }
     return hipErrorInvalidValue;
 }
 

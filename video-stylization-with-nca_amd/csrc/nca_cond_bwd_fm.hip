@@ -17,14 +17,23 @@
 
 #include "nca_cond_bwd_common.h"
 
+#ifndef NCA_FM_NT32
+#define NCA_FM_NT32 1   // 16-cell rows per pass of the matrix kernel at CP = 32 (two rows: 58 spilled vector registers)
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // F: front kernel.  One workgroup = one 16 x 16 super-tile, 4 waves, wave-private 4 x 16 tiles; three workgroups per CU.
-constexpr int kFrontWaves = 4, kFrontThreads = 256, kFrontOcc = 3;   // 51 KB of LDS and <= 170 registers: three workgroups per CU
+constexpr int kFrontWaves = 4, kFrontThreads = 256;
 template <int CP>
 struct FrontCfg {
     using F = WCfg<CP>;
+    // workgroups per CU: CP <= 16: 51 KB of LDS and <= 170 registers -> three; the wide instantiations (16 < C <= 32: the
+    // reference's default model is C = 20) are LDS-bound at two (CP <= 24: 70 KB) / one (CP = 32: 89 KB)
+    static constexpr int OCC = CP <= 16 ? 3 : (CP <= 24 ? 2 : 1);
+    static constexpr int KQ = F::K1S4;                          // 16-byte groups of the perception vector per lane (scratch P: [row tile][KQ][64 lanes])
+    static constexpr int DOS = 256 * F::M3T;                    // scratch dO: [row tile][16 M3T channels][16 cells]
     static constexpr int PW_Z = 0;                              // z halo 1: [CP][6][RS]
     static constexpr int PW_A3 = CP * CS;                       // alpha' halo 3 (10 rows); later rows 0-5 = PN, rows 6-9 = fire mask
     static constexpr int PW_LIFE = PW_A3 + (WTH + 6) * RS;
@@ -39,7 +48,7 @@ struct FrontCfg {
 
 // EXACT: the launch guarantees C == CP (no channel-padding clamps in the 45 loads, no ch < C guards in the staging).
 template <int CP, typename ST, bool BFM, bool EXACT>
-__global__ __launch_bounds__(kFrontThreads, kFrontOcc) void cond_step_bwd_front_kernel(const NcaCondBwdArgs ba) {
+__global__ __launch_bounds__(kFrontThreads, FrontCfg<CP>::OCC) void cond_step_bwd_front_kernel(const NcaCondBwdArgs ba) {
     using K = FrontCfg<CP>;
     using FK = WCfg<CP>;
     const NcaCondArgs& a = ba.f;
@@ -150,8 +159,8 @@ __global__ __launch_bounds__(kFrontThreads, kFrontOcc) void cond_step_bwd_front_
             lf[j] = life;
         }
         float* const go = ba.gx + (size_t)t.b * C * plane + off;
-        float* const dso = reinterpret_cast<float*>(ba.doscr) + (rid0 + row) * 256 + 4 * ff;
-        uint16_t* const dso16 = reinterpret_cast<uint16_t*>(ba.doscr) + (rid0 + row) * 256 + 4 * ff;
+        float* const dso = reinterpret_cast<float*>(ba.doscr) + (rid0 + row) * K::DOS + 4 * ff;
+        uint16_t* const dso16 = reinterpret_cast<uint16_t*>(ba.doscr) + (rid0 + row) * K::DOS + 4 * ff;
 #pragma unroll
         for (int k = 0; k < CP / 4; ++k) {
             const int ch = 4 * k + g;
@@ -177,18 +186,18 @@ __global__ __launch_bounds__(kFrontThreads, kFrontOcc) void cond_step_bwd_front_
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             if constexpr (BFM) {
-                bf_s16x4* const ps = reinterpret_cast<bf_s16x4*>(ba.pscr) + (rid0 + n0 + n) * 192 + lane;
+                bf_s16x4* const ps = reinterpret_cast<bf_s16x4*>(ba.pscr) + (rid0 + n0 + n) * (K::KQ * 64) + lane;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < K::KQ; ++q) {
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = 4 * q + r < FK::K1S ? P[n][4 * q + r] : 0.0f;
                     ps[q * 64] = pack4(v[0], v[1], v[2], v[3]);
                 }
             } else {
-                f32x4* const ps = reinterpret_cast<f32x4*>(ba.pscr) + (rid0 + n0 + n) * 192 + lane;
+                f32x4* const ps = reinterpret_cast<f32x4*>(ba.pscr) + (rid0 + n0 + n) * (K::KQ * 64) + lane;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < K::KQ; ++q) {
                     f32x4 v;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = 4 * q + r < FK::K1S ? P[n][4 * q + r] : 0.0f;
@@ -205,30 +214,43 @@ template <int CP, int NW = 4>
 struct MCfg {
     using F = WCfg<CP>;
     static constexpr int K1S = F::K1S;
-    static constexpr int MJ = (3 * CP + 15) / 16;
-    static constexpr int OFF_W3T = F::SHARED;               // [4 m][4 s][64]
-    static constexpr int OFF_W1T = OFF_W3T + 4 * 4 * 64;    // [MJ][16 s][64]
+    static constexpr int KQ = F::K1S4;                      // 16-byte groups of the perception vector per lane (front kernel's scratch)
+    static constexpr int DOS = 256 * F::M3T;                // scratch dO: [row tile][16 M3T channels][16 cells]
+    static constexpr int MJ = (3 * CP + 15) / 16;           // 16-row tiles of the perception index
+    static constexpr int M3T = F::M3T;                      // 16-row tiles of the channel index (2 for 16 < CP <= 32)
+    static constexpr int OFF_W3T = F::SHARED;               // [4 m][4 M3T s][64]
+    static constexpr int OFF_W1T = OFF_W3T + 4 * 4 * M3T * 64;    // [MJ][16 s][64]
     static constexpr int SHARED = OFF_W1T + MJ * 16 * 64;
-    static constexpr int PW = NW == 8 ? 16 * TBH / 2 : 16 * TBS;   // transposition buffer: 16 cells x 148 f32 rows, or x 144 bf16 (NW = 8 is bf16-only)
+    // transposition buffer: [16 cells][TBW f32 rows] (rows: the two factors of one weight-gradient product: at most
+    // max(16 M3T + 64, 128, 64 + 3 CP)); TBW % 32 == 20 keeps the 16-byte writes of a cell row conflict-free.  The same area
+    // stages dL/dperception on the way out ([3C rows][NT x 16 cells], row stride 36).
+    static constexpr int TBW = 64 + 3 * CP <= TBS ? TBS : 180;
+    static_assert(TBW % 32 == 20 && TBW >= 64 + 3 * CP && TBW >= 16 * M3T + 64 && TBW >= 128, "transposition buffer rows");
+    static constexpr int PW_F32 = 16 * TBW > 16 * MJ * 36 ? 16 * TBW : 16 * MJ * 36;
+    static constexpr int PW = NW == 8 ? 16 * TBH / 2 : PW_F32;   // (NW = 8 is bf16-only: x 144 bf16)
     static constexpr int OFF_DB = SHARED + NW * PW;         // NW = 8: bias-gradient sums, [wave][32 values][64 lanes], accumulated with LDS adds
     static constexpr int DB = NW == 8 ? NW * 32 * 64 : 0;
-    static constexpr int SLABS = kBwdWaves * (64 * 3 * CP + 64 * 64 + CP * 64 + 128);   // the flush stages four partial slabs
+    // the flush stages four partial slabs: all of them at once when that fits (CP <= 16), else in two sections (w1 | the rest)
+    static constexpr int SEC1 = 64 * 3 * CP, SEC2 = 64 * 64 + CP * 64 + 128;
+    static constexpr bool SPLIT_FLUSH = kBwdWaves * (SEC1 + SEC2) * 4 > 160 * 1024;
+    static constexpr int SLABS = SPLIT_FLUSH ? kBwdWaves * (SEC1 > SEC2 ? SEC1 : SEC2) : kBwdWaves * (SEC1 + SEC2);
     static constexpr int MERGE = NW == 8 ? 4 * 128 * 64 : 0;   // two waves per SIMD: the pairs' accumulators meet in LDS before the flush
     static constexpr int LDS_A = (SHARED + NW * PW + DB) > SLABS ? (SHARED + NW * PW + DB) : SLABS;
     static constexpr int LDS_FLOATS = LDS_A > MERGE ? LDS_A : MERGE;
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
-    static_assert(CP <= 16, "one 16-row output tile (M3T == 1)");
+    static_assert(CP <= 16 || NW == 4, "wide channel counts: fp32 products, one wave per SIMD");
 };
 
 // NW = 4: one wave per SIMD, two 16-cell rows per pass (NT = 2) -- the one-launch kernel's arrangement.  NW = 8 (the bf16-MFMA
 // default): TWO waves per SIMD; the waves 2p and 2p+1 split a 4 x 16 tile into its upper and lower two rows and walk them one
 // row per pass (NT = 1), which with the ReLU gates taken from the stored bf16 activations instead of kept f32 pre-activations
 // fits 256 registers beside the 128 accumulators; their partial accumulators are merged through LDS before the flush.
-template <int CP, typename ST = StF32, bool BFM = false, int NW = 4>
+template <int CP, typename ST = StF32, bool BFM = false, int NW = 4, int NTW = 2>
 __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const NcaCondBwdArgs ba) {
     using K = MCfg<CP, NW>;
     using FK = WCfg<CP>;
-    constexpr int NT = NW == 8 ? 1 : 2;
+    constexpr int NT = NW == 8 ? 1 : NTW;              // 16-cell rows per pass
+    constexpr int NPASS = (NW == 8 ? 2 : WTH) / NT;    // passes of a wave over its rows of a 4 x 16 tile
     constexpr int kThr = 64 * NW;
     constexpr int DPS = NT == 2 ? 36 : 20;   // row stride of the dL/dperception staging in TB ([3C rows][NT x 16 cells])
     static_assert(NW == 4 || (NW == 8 && BFM), "two waves per SIMD: bf16-MFMA form only");
@@ -260,9 +282,9 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
         const int k = 16 * (s >> 2) + 4 * gg + (s & 3);
         return (o < hid && k < hid) ? (long)o * hid + k : -1;
     };
-    auto map_w3t = [&](int idx) -> long {         // W3^T: lane (gg,i) of (m, s) holds W3[ch = 4gg+s][h2 = 16m+i]
-        const int l = idx & 63, s = (idx >> 6) % 4, m = (idx >> 6) / 4;
-        const int ch = 4 * (l >> 4) + s, h2 = 16 * m + (l & 15);
+    auto map_w3t = [&](int idx) -> long {         // W3^T: lane (gg,i) of (m, s) holds W3[ch = 16(s/4)+4gg+s%4][h2 = 16m+i]
+        const int l = idx & 63, s = (idx >> 6) % (4 * K::M3T), m = (idx >> 6) / (4 * K::M3T);
+        const int ch = 16 * (s >> 2) + 4 * (l >> 4) + (s & 3), h2 = 16 * m + (l & 15);
         return (ch < C && h2 < hid) ? (long)ch * hid + h2 : -1;
     };
     auto map_w1t = [&](int idx) -> long {         // W1^T: lane (gg,i) of (mj, s) holds W1[h1 = 16(s/4)+4gg+s%4][j = 16mj+i]
@@ -279,7 +301,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
             // f32 images, two-phase: all gathers are requested before the first is waited for (one cold round trip instead of ten)
             FillRegs<4 * FK::K1S * 64, kThr> fr0;
             FillRegs<4 * 16 * 64, kThr> fr1;
-            FillRegs<4 * 4 * 64, kThr> fr5;
+            FillRegs<4 * 4 * K::M3T * 64, kThr> fr5;
             FillRegs<K::MJ * 16 * 64, kThr> fr6;
             fill_load(fr0, a.w1, tid, map_w1);
             fill_load(fr1, a.w2, tid, map_w2);
@@ -355,7 +377,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
         __syncthreads();
     }
     // persistent weight-gradient accumulators (D = A * B^T with the cell axis as K)
-    f32x4 aW1[4][K::MJ], aW2[4][4], aW3[4];
+    f32x4 aW1[4][K::MJ], aW2[4][4], aW3[K::M3T][4];
     // bias-gradient sums: 32 registers per lane -- or, with two waves per SIMD (no registers to spare), 32 x 64 floats of LDS per
     // wave, [which][m][lane][4]: one 16-byte read-modify-write per gated tile (lane-private addresses; ds_add_f32 was tried: the
     // LDS's float atomics run a lane at a time and made the kernel five times slower)
@@ -379,7 +401,8 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
     };
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        aW3[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m3 = 0; m3 < K::M3T; ++m3) aW3[m3][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) { aW2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; db1[i][j] = 0.f; db2[i][j] = 0.f; }
 #pragma unroll
@@ -393,33 +416,38 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
     const int halo = a.alive_ch >= 0 ? 3 : 1;
     const bool use_alive = a.alive_ch >= 0;
     // one pass's scratch operands, requested a pass ahead (raw: 16-byte groups of P / 8-byte groups of bf16 P in the low half)
-    f32x4 nP[NT][3];
-    float ndO[NT][4];
+    f32x4 nP[NT][K::KQ];
+    float ndO[NT][4 * K::M3T];
     long pre_rid = -1;
     auto fetch = [&](long r_) {
         const int gq = (lane_w >> 4) & 3, cq = lane_w & 15;
         if constexpr (BFM) {
-            const u32x2* const ps = reinterpret_cast<const u32x2*>(ba.pscr) + (size_t)r_ * 192 + lane_w;
-            const uint16_t* const ds = reinterpret_cast<const uint16_t*>(ba.doscr) + (size_t)r_ * 256 + 64 * gq + cq;
+            const u32x2* const ps = reinterpret_cast<const u32x2*>(ba.pscr) + (size_t)r_ * (K::KQ * 64) + lane_w;
+            const uint16_t* const ds = reinterpret_cast<const uint16_t*>(ba.doscr) + (size_t)r_ * K::DOS + 64 * gq + cq;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const u32x2 v = ps[n * 192 + q * 64];
+                for (int q = 0; q < K::KQ; ++q) {
+                    const u32x2 v = ps[n * (K::KQ * 64) + q * 64];
                     nP[n][q] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), 0.0f, 0.0f};
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ndO[n][r] = __uint_as_float((unsigned)ds[n * 256 + 16 * r] << 16);
+                for (int r = 0; r < 4; ++r) ndO[n][r] = __uint_as_float((unsigned)ds[n * K::DOS + 16 * r] << 16);
             }
         } else {
-            const f32x4* const ps = reinterpret_cast<const f32x4*>(ba.pscr) + (size_t)r_ * 192 + lane_w;
-            const float* const ds = reinterpret_cast<const float*>(ba.doscr) + (size_t)r_ * 256 + 64 * gq + cq;
+            const f32x4* const ps = reinterpret_cast<const f32x4*>(ba.pscr) + (size_t)r_ * (K::KQ * 64) + lane_w;
+            const float* const ds = reinterpret_cast<const float*>(ba.doscr) + (size_t)r_ * K::DOS + 64 * gq + cq;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) nP[n][q] = ps[n * 192 + q * 64];
+                for (int q = 0; q < K::KQ; ++q) nP[n][q] = ps[n * (K::KQ * 64) + q * 64];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ndO[n][r] = ds[n * 256 + 16 * r];
+                for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {   // channel 16 m3 + 4 gq + r (rows >= CP of the scratch are never written)
+                        if (CP % 16 == 0 || 16 * m3 + 4 * gq + r < CP) ndO[n][4 * m3 + r] = ds[n * K::DOS + 256 * m3 + 16 * r];
+                        else ndO[n][4 * m3 + r] = 0.0f;
+                    }
             }
         }
         pre_rid = r_;
@@ -438,7 +466,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
         const int nbase = NW == 8 ? (wave & 1) * 2 : 0;   // first row of this wave inside the tile
         const size_t rid0 = ((size_t)tw.t * kBwdWaves + tslot) * WTH + nbase;   // 16-cell row tiles of the front kernel's scratch
 #pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {   // (both forms: two passes per wave)
+        for (int pass = 0; pass < NPASS; ++pass) {
             const int n0 = nbase + pass * NT;
             // ---- forward recompute: P, h1, h2 kept in registers ------------------------------------------
             // ---- this pass's two 16-cell rows from the front kernel's scratch: the perception vector in B-operand order
@@ -447,23 +475,25 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
             //      pass -- rows 2, 3 of this tile, or rows 0, 1 of the wave's next tile -- goes out before this pass's MFMAs.
             const long rid = (long)(rid0 + pass * NT);
             if (pre_rid != rid) fetch(rid);   // first tile of the wave, or the tile before this one was outside the image
-            float P[NT][12];
-            float dOin[NT][4];
-            bf_s16x4 pbin[NT][3];
+            float P[NT][4 * K::KQ];
+            float dOin[NT][4 * K::M3T];
+            bf_s16x4 pbin[NT][K::KQ];
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < K::KQ; ++q) {
                     if constexpr (BFM) pbin[n][q] = __builtin_bit_cast(bf_s16x4, u32x2{__float_as_uint(nP[n][q][0]), __float_as_uint(nP[n][q][1])});
                     else { P[n][4 * q] = nP[n][q][0]; P[n][4 * q + 1] = nP[n][q][1]; P[n][4 * q + 2] = nP[n][q][2]; P[n][4 * q + 3] = nP[n][q][3]; }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dOin[n][r] = 4 * g + r < CP ? ndO[n][r] : 0.0f;
+                for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dOin[n][4 * m3 + r] = 16 * m3 + 4 * g + r < CP ? ndO[n][4 * m3 + r] : 0.0f;
             }
             {
                 long nrid = rid + NT;
                 bool has = true;
-                if (pass == 1) {
+                if (pass == NPASS - 1) {
                     const int tn = tw.t + tw.stride;
                     has = tn < tw.end;
                     nrid = (long)(((size_t)tn * kBwdWaves + tslot) * WTH + nbase);
@@ -523,7 +553,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
                     wave_sync();
                     const bf_s16x4 ta = tb_tr_read(tb16, 0, lane);
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) aW3[nb] = mfma_bf16(ta, tb_tr_read(tb16, 1 + nb, lane), aW3[nb]);
+                    for (int nb = 0; nb < 4; ++nb) aW3[0][nb] = mfma_bf16(ta, tb_tr_read(tb16, 1 + nb, lane), aW3[0][nb]);
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
@@ -652,53 +682,59 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
                     }
                 });
             NCA_BPHASE(5);   // forward recompute
-            float dO[NT][4];
+            float dO[NT][4 * K::M3T];
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dO[n][r] = dOin[n][r];
+                for (int r = 0; r < 4 * K::M3T; ++r) dO[n][r] = dOin[n][r];
             // Backward data path and weight gradients, layer by layer from the output: each layer's weight-gradient product
             // is issued as soon as its two factors exist, so h2 dies after layer 3, d2 and h1 after layer 2, P and d1 after
             // layer 1 (all five tiles alive at once through a separate weight-gradient phase cost 36 spilled registers).
             // Weight gradients go per 16-cell tile through the cell-major buffer TB[cell][row]: lane (g,ci) writes its 4
             // accumulator rows of a tile with ONE 16-byte store; operand fragments A[i][k=g] = TB[4s+g][rowA+i],
             // B[k=g][j] = TB[4s+g][rowB+j] are 16 consecutive floats per lane group.
+            constexpr int TBS = K::TBW;                          // (row pitch of this instantiation's transposition buffer)
             float* const tw_ = TB + ci * TBS + 4 * g;            // this lane's cell row, accumulator-row offset
             const float* const tr_ = TB + g * TBS + ci;           // operand reads: cell 4s+g -> + 4*s*TBS
             f32x4 d2[4][NT], d1[4][NT];
-            // ---- layer 3: dW3 = dO (rows 0..15) x h2 (rows 16..79);  d2 = (W3^T dO) * 1[h2 > 0] ---------------------------
+            // ---- layer 3: dW3 = dO (rows 0..16 M3T-1) x h2 (the next 64 rows);  d2 = (W3^T dO) * 1[h2 > 0] -------------------
+            constexpr int M3 = K::M3T;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 wave_sync();  // TB free (gradient tile consumed above / previous products done)
-                st4(tw_, f32x4{dO[n][0], dO[n][1], dO[n][2], dO[n][3]});
 #pragma unroll
-                for (int m = 0; m < 4; ++m) st4(tw_ + 16 + 16 * m, h2[m][n]);
+                for (int m3 = 0; m3 < M3; ++m3) st4(tw_ + 16 * m3, f32x4{dO[n][4 * m3], dO[n][4 * m3 + 1], dO[n][4 * m3 + 2], dO[n][4 * m3 + 3]});
+#pragma unroll
+                for (int m = 0; m < 4; ++m) st4(tw_ + 16 * M3 + 16 * m, h2[m][n]);
                 wave_sync();
                 piped<4>(
                     [&](int s_) {
-                        OpN<5> o;
-                        o.v[0] = tr_[4 * s_ * TBS];
+                        OpN<M3 + 4> o;
 #pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) o.v[1 + nb] = tr_[4 * s_ * TBS + 16 + 16 * nb];
+                        for (int m3 = 0; m3 < M3; ++m3) o.v[m3] = tr_[4 * s_ * TBS + 16 * m3];
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) o.v[M3 + nb] = tr_[4 * s_ * TBS + 16 * M3 + 16 * nb];
                         return o;
                     },
-                    [&](int, const OpN<5>& o) {
+                    [&](int, const OpN<M3 + 4>& o) {
 #pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) aW3[nb] = nca_mfma(o.v[0], o.v[1 + nb], aW3[nb]);
+                        for (int m3 = 0; m3 < M3; ++m3)
+#pragma unroll
+                            for (int nb = 0; nb < 4; ++nb) aW3[m3][nb] = nca_mfma(o.v[m3], o.v[M3 + nb], aW3[m3][nb]);
                     });
             }
             piped<4>(
                 [&](int m) {
-                    OpN<4> o;
+                    OpN<4 * M3> o;
 #pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_) o.v[s_] = W3T[(m * 4 + s_) * 64 + lane];
+                    for (int s_ = 0; s_ < 4 * M3; ++s_) o.v[s_] = W3T[(m * 4 * M3 + s_) * 64 + lane];
                     return o;
                 },
-                [&](int m, const OpN<4>& o) {
+                [&](int m, const OpN<4 * M3>& o) {
 #pragma unroll
                     for (int n = 0; n < NT; ++n) d2[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_)
+                    for (int s_ = 0; s_ < 4 * M3; ++s_)
 #pragma unroll
                         for (int n = 0; n < NT; ++n) d2[m][n] = nca_mfma(o.v[s_], dO[n][s_], d2[m][n]);
 #pragma unroll
@@ -854,7 +890,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
     // ---- weight-gradient partials: the four waves' accumulators are summed through LDS (tiles and weight images are dead
     //      by now) and added to the WORKGROUP's slab with coalesced accesses; fixed summation order (deterministic).
     const int sf = slab_floats(C, hid);
-    static_assert(kBwdWaves * (64 * 3 * CP + 64 * 64 + CP * 64 + 128) <= K::LDS_FLOATS, "slab staging fits the LDS carve");
+    static_assert(K::SLABS <= K::LDS_FLOATS, "slab staging fits the LDS carve");
     // the read half of the slab's read-modify-write goes out first: one memory round trip, under the LDS staging below
     float* const slab = ba.slabs + (size_t)blockIdx.x * sf;
     constexpr int PER = (64 * 3 * CP + 64 * 64 + CP * 64 + 128 + kThr - 1) / kThr;
@@ -887,7 +923,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
                 for (int j = 0; j < K::MJ; ++j) f(aW1[i][j], q++);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) f(aW2[i][j], q++);
-                f(aW3[i], q++);
+                f(aW3[0][i], q++);
             }
         };
         if (odd) each_acc([&](f32x4& v, int q) { st4(xb + q * 256, v); });
@@ -913,8 +949,63 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
         __syncthreads();
     }
     const bool stager = NW == 4 || (wave & 1) == 0;
-    float* const sw = smem + tslot * sf;
-    if (stager) {
+    // section 1 = the w1 part of the slab (indices [0, hid * 3C)), section 2 = w2 | w3 | b1 | b2 behind it
+    auto stage_w1 = [&](float* const sw) {
+#pragma unroll
+        for (int ma = 0; ma < 4; ++ma)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * ma + 4 * g + r;
+                if (o < hid) {
+#pragma unroll
+                    for (int nb = 0; nb < K::MJ; ++nb) {
+                        if constexpr (BFM) {   // column 16nb + ci = 12 g' + q, q = 3 c4 + f: channel 4 c4 + g', filter f
+                            const int col = 16 * nb + ci, gp = col / 12, q = col - 12 * gp, j = 3 * (4 * (q / 3) + gp) + q % 3;
+                            if (gp < 4 && q < K::K1S && j < K1) sw[o * K1 + j] = aW1[ma][nb][r];
+                        } else if (16 * nb + ci < K1) sw[o * K1 + 16 * nb + ci] = aW1[ma][nb][r];
+                    }
+                }
+            }
+    };
+    auto stage_rest = [&](float* const sw) {   // sw[i] <-> slab index slab_off_w2 + i
+        const int o3 = hid * hid, ob1 = o3 + C * hid, ob2 = ob1 + hid;
+#pragma unroll
+        for (int ma = 0; ma < 4; ++ma)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * ma + 4 * g + r;
+                if (o < hid) {
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+                        if (16 * nb + ci < hid) sw[o * hid + 16 * nb + ci] = aW2[ma][nb][r];
+                }
+            }
+#pragma unroll
+        for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = 16 * m3 + 4 * g + r;
+                if (ch < C) {
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+                        if (16 * nb + ci < hid) sw[o3 + ch * hid + 16 * nb + ci] = aW3[m3][nb][r];
+                }
+            }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s1 = row16_sum(db1[m][r]), s2 = row16_sum(db2[m][r]);
+                const int o = 16 * m + 4 * g + r;
+                if (ci == 0 && o < hid) {
+                    sw[ob1 + o] = s1;
+                    sw[ob2 + o] = s2;
+                }
+            }
+    };
+    if constexpr (!K::SPLIT_FLUSH) {
+        float* const sw = smem + tslot * sf;
+        if (stager) {
 #pragma unroll
     for (int ma = 0; ma < 4; ++ma)
 #pragma unroll
@@ -934,12 +1025,14 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
             }
         }
 #pragma unroll
+    for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int ch = 4 * g + r;
+        const int ch = 16 * m3 + 4 * g + r;
         if (ch < C) {
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
-                if (16 * nb + ci < hid) sw[slab_off_w3(C, hid) + ch * hid + 16 * nb + ci] = aW3[nb][r];
+                if (16 * nb + ci < hid) sw[slab_off_w3(C, hid) + ch * hid + 16 * nb + ci] = aW3[m3][nb][r];
         }
     }
 #pragma unroll
@@ -953,12 +1046,31 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
                 sw[slab_off_b2(C, hid) + o] = s2;
             }
         }
-    }   // stager
-    __syncthreads();
+        }   // stager
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int i = tid + kThr * k;
-        if (i < sf) slab[i] = cur[k] + ((smem[i] + smem[sf + i]) + (smem[2 * sf + i] + smem[3 * sf + i]));
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + kThr * k;
+            if (i < sf) slab[i] = cur[k] + ((smem[i] + smem[sf + i]) + (smem[2 * sf + i] + smem[3 * sf + i]));
+        }
+    } else {
+        // wide channel counts: four partial slabs do not fit the LDS at once -- two sections, same sums in the same order
+        const int sec1 = slab_off_w2(C, hid), sec2 = sf - sec1;
+        if (stager) stage_w1(smem + tslot * sec1);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + kThr * k;
+            if (i < sec1) slab[i] = cur[k] + ((smem[i] + smem[sec1 + i]) + (smem[2 * sec1 + i] + smem[3 * sec1 + i]));
+        }
+        __syncthreads();
+        if (stager) stage_rest(smem + tslot * sec2);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + kThr * k, j = i - sec1;
+            if (i >= sec1 && i < sf) slab[i] = cur[k] + ((smem[j] + smem[sec2 + j]) + (smem[2 * sec2 + j] + smem[3 * sec2 + j]));
+        }
     }
 #if defined(NCA_STAMPS)
     NCA_BPHASE(11);  // slab flush
@@ -967,7 +1079,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
 }
 
 
-template <int CP, typename ST, bool BFM>
+template <int CP, typename ST, bool BFM, int NTW = 2>
 hipError_t launch_fm(const NcaCondBwdArgs& ba_in, hipStream_t st) {
     NcaCondBwdArgs ba = ba_in;
     ba.f.err = nca_error_word_device();
@@ -988,7 +1100,7 @@ hipError_t launch_fm(const NcaCondBwdArgs& ba_in, hipStream_t st) {
     }
     constexpr int NW = BFM ? 8 : 4;   // bf16 MFMA: two waves per SIMD
     using KM = MCfg<CP, NW>;
-    auto kern = cond_step_bwd_mlp_kernel<CP, ST, BFM, NW>;
+    auto kern = cond_step_bwd_mlp_kernel<CP, ST, BFM, NW, NTW>;
     const size_t lds = (size_t)KM::LDS_FLOATS * sizeof(float);
     static NcaLdsAttr attr;
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
@@ -1002,14 +1114,28 @@ hipError_t launch_fm(const NcaCondBwdArgs& ba_in, hipStream_t st) {
 
 }  // namespace
 
-// bytes of the two scratch areas for a B x H x W grid (fp32 sizes: the bf16 forms use half)
-size_t nca_cond_bwd_fm_pscr_bytes(int B, int H, int W) { return (size_t)B * ((W + 15) / 16) * ((H + 15) / 16) * 16 * 192 * 16; }
-size_t nca_cond_bwd_fm_doscr_bytes(int B, int H, int W) { return (size_t)B * ((W + 15) / 16) * ((H + 15) / 16) * 16 * 256 * 4; }
+// channel padding of the instantiation that serves C channels
+static int fm_cp(int C) { return C <= 12 ? 12 : (C <= 16 ? 16 : (C <= 20 ? 20 : (C <= 24 ? 24 : 32))); }
+// bytes of the two scratch areas for a B x C x H x W grid (fp32 sizes: the bf16 forms use half): per 16-cell row tile,
+// [K1S4 16-byte groups][64 lanes] of perception values and [16 M3T channels][16 cells] of gated gradient
+size_t nca_cond_bwd_fm_pscr_bytes(int B, int C, int H, int W) {
+    const int kq = (3 * fm_cp(C) / 4 + 3) / 4;
+    return (size_t)B * ((W + 15) / 16) * ((H + 15) / 16) * 16 * (size_t)kq * 64 * 16;
+}
+size_t nca_cond_bwd_fm_doscr_bytes(int B, int C, int H, int W) {
+    return (size_t)B * ((W + 15) / 16) * ((H + 15) / 16) * 16 * (C <= 16 ? 256 : 512) * 4;
+}
 
 // front + matrix kernels (kernel B is launched by the caller).  mode 0 = f32 history, 1 = bf16 history / exact-f32 products,
 // 2 = bf16 history with the products on bf16 MFMA.
 hipError_t nca_launch_cond_step_bwd_fm(const NcaCondBwdArgs& ba, hipStream_t st, int mode) {
-    if (ba.f.C > 16 || !ba.pscr || !ba.doscr) return hipErrorInvalidValue;
+    if (ba.f.C > 32 || !ba.pscr || !ba.doscr) return hipErrorInvalidValue;
+    if (ba.f.C > 16) {   // wide channel counts (the reference's default model is C = 20): fp32 history and products only
+        if (mode != 0) return hipErrorInvalidValue;
+        if (ba.f.C <= 20) return launch_fm<20, StF32, false>(ba, st);
+        if (ba.f.C <= 24) return launch_fm<24, StF32, false>(ba, st);
+        return launch_fm<32, StF32, false, NCA_FM_NT32>(ba, st);
+    }
     const bool c12 = ba.f.C <= 12;
     switch (mode) {
         case 0: return c12 ? launch_fm<12, StF32, false>(ba, st) : launch_fm<16, StF32, false>(ba, st);

@@ -41,7 +41,9 @@ struct WCfg {
     static constexpr int PW = PW_A2 + (WTH + 4) * RS;
     static constexpr int LDS_FLOATS = SHARED + kWaves * PW;
     static_assert(CP % 4 == 0 && SHARED % 4 == 0 && PW % 4 == 0 && PW_XR % 4 == 0 && PW_A3 % 4 == 0, "16-byte carve");
-    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+    // the 8-wave carve fits for CP <= 16 (checked where a kernel is launched with it); wider CP only borrows the weight-image
+    // offsets and the per-wave sub-offsets (backward front / matrix kernels, 4 waves with their own carve)
+    static constexpr bool kFits8 = LDS_FLOATS * 4 <= 160 * 1024;
 };
 
 #if defined(NCA_STAMPS)

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_wave_kernel(const 
 template <int CP>
 hipError_t launch_cond_wave(const NcaCondArgs& a, hipStream_t st) {
     using K = WCfg<CP>;
+    static_assert(K::kFits8, "LDS budget (8-wave carve)");
     auto kern = cond_step_fwd_wave_kernel<CP>;
     const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
     static NcaLdsAttr attr;   // per instantiation; keyed by device inside

@@ -108,8 +108,8 @@ int nca_cond_bwd_nblk(int B, int C, int H, int W);
 hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& a, hipStream_t st, bool bf16 = false);   // bf16: f.x_in / x_next / f.goal hold bf16
 // kernel A as two launches (nca_cond_bwd_fm.hip); mode 0 = f32 history, 1 = bf16 history / exact-f32 products, 2 = bf16 MFMA
 hipError_t nca_launch_cond_step_bwd_fm(const NcaCondBwdArgs& a, hipStream_t st, int mode);
-size_t nca_cond_bwd_fm_pscr_bytes(int B, int H, int W);
-size_t nca_cond_bwd_fm_doscr_bytes(int B, int H, int W);
+size_t nca_cond_bwd_fm_pscr_bytes(int B, int C, int H, int W);
+size_t nca_cond_bwd_fm_doscr_bytes(int B, int C, int H, int W);
 void nca_set_bwd_variant(int v);   // kernel A: 0 = the faster form per mode (bf16 MFMA: front + matrix kernels; fp32 products: one launch), 1 = one launch always, 2 = front + matrix always, 3 = the slower form per mode (cross-check)
 hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st, bool accumulate = false);   // dst (+)= column sums
 // nca_gram.hip: out[ma*nb + ma] = [sum_n a[i][n] * b[j][n] | sum_n a[i][n]] over all B*HW cells; b rows from two tensors

@@ -61,8 +61,8 @@ class _HipCondPerceive(torch.autograd.Function):
 
 
 def _cond_grow_composed(model, x, goal, T, us):
-    """Differentiable grow for shapes the fused backward kernels do not cover (C > 16 -- the reference's DEFAULT model is
-    C = 20, nca.py:62-94 -- or W % 4 != 0): every step is the reference's sequence (nca.py:181-195) with the alive masks and the
+    """Differentiable grow for shapes the fused backward kernels do not cover (W % 4 != 0, or C > 32; the reference's
+    DEFAULT model, C = 20, nca.py:62-94, runs the fused kernels): every step is the reference's sequence (nca.py:181-195) with the alive masks and the
     depthwise perception on the HIP kernels and the three 1x1 convolutions as library GEMMs, under PyTorch autograd."""
     a, thr, C = model._alive_ch(), model.alpha_living_threshold, model.num_channels
     gpad = None
@@ -86,6 +86,10 @@ def cond_grow_autograd(model, x: torch.Tensor, goal: Optional[torch.Tensor], T: 
     if T == 0:
         return x
     bf16 = x.dtype == torch.bfloat16      # bf16 pool (BASELINE configs[2]): bf16-storage kernels, forward and backward
+    if bf16 and x.shape[1] > 16:
+        # the bf16-storage kernels cover C <= 16; a wider model (the reference default is C = 20) keeps its bf16 POOL but
+        # steps in fp32 (widening is exact) and returns the pool's dtype
+        return cond_grow_autograd(model, x.float(), goal, T).to(torch.bfloat16)
     x = x.contiguous() if bf16 else x.float().contiguous()
     u = model.update_net.out
     params = (model.perception_net.weight, u[0].weight, u[0].bias, u[2].weight, u[2].bias, u[4].weight)
@@ -94,8 +98,8 @@ def cond_grow_autograd(model, x: torch.Tensor, goal: Optional[torch.Tensor], T: 
                lo=-10.0, hi=10.0, seed=model.mask_seed, step0=model._mask_step)
     model._mask_step += T
     if _needs_grad(x, goal, *params):
-        if x.shape[1] > 16 or x.shape[3] % 4 != 0:     # beyond the fused backward kernels (include/ncahip.h): composed pass
-            return _cond_grow_composed(model, x.float(), goal, T, us)
+        if x.shape[1] > 32 or x.shape[3] % 4 != 0:     # beyond the fused backward kernels (include/ncahip.h): composed pass
+            return _cond_grow_composed(model, x.float(), goal, T, us).to(x.dtype)
         return _CondGrow.apply(x, goal, *params, cfg)
     if bf16:
         goal = None if goal is None else goal.detach().to(torch.bfloat16)
