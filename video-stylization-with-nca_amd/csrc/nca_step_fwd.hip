@@ -809,7 +809,7 @@ __device__ __forceinline__ float nca_max3x3(const float* p, int stride) {
 }
 
 template <int CP, int TH, int TW, int NT, bool VEC>
-__global__ __launch_bounds__(kThreads, 2) void cond_step_fwd_kernel(const NcaCondArgs a) {
+__global__ __launch_bounds__(kThreads, CP > 16 ? 1 : 2) void cond_step_fwd_kernel(const NcaCondArgs a) {   // CP > 16: 84+ KB of LDS -> one workgroup per CU anyway: 512 registers per lane
     using K = CondCfg<CP, TH, TW, NT>;
     using Pos = TilePos<TH, TW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
