@@ -73,11 +73,14 @@ def test_single_process_is_a_noop():
 # Both trainers under world_size 2: shared T, rank-offset sampling, fresh seeds per GLOBAL batch, and the optimiser step equal
 # to the single-process large-batch step.
 class _StubNCA(nn.Module):
-    def __init__(self, C=8, size=12):
+    def __init__(self, C=8, size=12, random_init=False):
         super().__init__()
         self.num_channels, self.image_size, self.living_channel_dim = C, size, 3
         self.scale = nn.Parameter(torch.tensor(0.5))
         self.shift = nn.Parameter(torch.linspace(-0.2, 0.2, C))
+        if random_init:   # as a real model: drawn from this process's torch generator
+            self.scale = nn.Parameter(0.4 + 0.2 * torch.rand(()))
+            self.shift = nn.Parameter(0.2 * torch.randn(C))
         self.mask_seed = 0
         self.steps_seen = []
 
@@ -116,11 +119,14 @@ class _Loss(nn.Module):
 
 
 class _StubDyNCA(nn.Module):
-    def __init__(self, c=6):
+    def __init__(self, c=6, random_init=False):
         super().__init__()
         self.c_in, self.c_out = c, 3
         self.gain = nn.Parameter(torch.tensor(0.9))
         self.bias = nn.Parameter(torch.linspace(-0.1, 0.1, c))
+        if random_init:
+            self.gain = nn.Parameter(0.8 + 0.2 * torch.rand(()))
+            self.bias = nn.Parameter(0.1 * torch.randn(c))
         self.mask_seed = 0
         self.seen = []
 
@@ -137,9 +143,9 @@ def _dyn_loss(d):
     return d["generated_image_list"][0].pow(2).mean() + d["nca_state"].abs().mean()
 
 
-def _cond_trainer(pool_size):
+def _cond_trainer(pool_size, random_init=False):
     from ncahip.conditioned_trainer import ConditionedNCATrainer
-    nca, ds = _StubNCA(), _Targets()
+    nca, ds = _StubNCA(random_init=random_init), _Targets()
     tr = ConditionedNCATrainer(nca, ds, None, nca_steps=[3, 9], lr=1e-2, pool_size=pool_size, log_base_path="/tmp/ncahip_dp_test",
                                loss=_Loss(), device=torch.device("cpu"), sample_seed=7)
     return tr, nca, ds
@@ -189,7 +195,31 @@ def _trainer_worker(rank, world, port, q):
     _, t_used = dt.step()
     xin, _ = m.seen[-1]
     dyn = dict(T=t_used, xin=xin.numpy(), params=[p.detach().clone().numpy() for p in m.parameters()])
-    q.put((rank, it, tb_res, dyn))
+    # ---- replicas built under DIFFERENT per-rank seeds (what a real torchrun launch does): the trainers' constructors must
+    #      broadcast rank 0's parameters, and one iteration later the replicas must still be bit-equal ------------------------
+    from ncahip.nca import ConditionedNCA
+    from ncahip.models.dynca import DyNCA
+    torch.manual_seed(9000 + 17 * rank)
+    real = ConditionedNCA(target_shape=(3, 12, 12), num_hidden_channels=4)       # default random init, per-rank generator state
+    before = {k: v.clone() for k, v in real.state_dict().items()}
+    nd.broadcast_parameters(real)
+    same_as_before = all(torch.equal(before[k], v) for k, v in real.state_dict().items())
+    real_sd = {k: v.numpy().copy() for k, v in real.state_dict().items()}
+    dyn_real = DyNCA(6, 3, fc_dim=16, conditioning="none", device=torch.device("cpu"))
+    DyNCATrainer(dyn_real, _dyn_loss, pool_size=4, size=(8, 6), batch_size=2, device=torch.device("cpu"))   # constructor broadcasts
+    dyn_sd = {k: v.numpy().copy() for k, v in dyn_real.state_dict().items()}
+    tr3, nca3, _ = _cond_trainer(pool_size=16, random_init=True)
+    init3 = [p.detach().clone().numpy() for p in nca3.parameters()]
+    for i in range(8):
+        tr3.pool[i] = torch.rand(8, 12, 12, generator=torch.Generator().manual_seed(50 * rank + i)) + 0.2
+    tr3._iteration(0, batch_size=4)
+    m3 = _StubDyNCA(random_init=True)
+    dt3 = DyNCATrainer(m3, _dyn_loss, pool_size=12, size=(8, 6), batch_size=4, nca_steps=(4, 9), lr=1e-2, device=torch.device("cpu"))
+    dt3.pool += 1.0 + rank
+    dt3.step()
+    sync = dict(same_as_before=same_as_before, real_sd=real_sd, dyn_sd=dyn_sd, init3=init3,
+                after3=[p.detach().clone().numpy() for p in nca3.parameters()], dyn3=[p.detach().clone().numpy() for p in m3.parameters()])
+    q.put((rank, it, tb_res, dyn, sync))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -206,7 +236,18 @@ def test_trainers_data_parallel_semantics():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, it0, tb0, dy0), (_, it1, tb1, dy1) = res
+    (_, it0, tb0, dy0, sy0), (_, it1, tb1, dy1, sy1) = res
+    # replicas constructed under different per-rank seeds: rank 0 keeps its weights, rank 1 receives them (parameters AND
+    # buffers, real model classes), and after one data-parallel iteration the replicas are still bit-equal
+    assert sy0["same_as_before"] and not sy1["same_as_before"]
+    for key in ("real_sd", "dyn_sd"):
+        assert set(sy0[key]) == set(sy1[key]) and len(sy0[key]) > 0
+        for k in sy0[key]:
+            assert (sy0[key][k] == sy1[key][k]).all(), (key, k)
+    for key in ("init3", "after3", "dyn3"):
+        for a, b in zip(sy0[key], sy1[key]):
+            assert (a == b).all(), key
+    assert any((a != b).any() for a, b in zip(sy0["init3"], sy0["after3"]))        # the iteration did move the weights
     # ConditionedNCATrainer iteration: local batch 2, the SAME two T values on both ranks, one fresh seed each (2 per global
     # batch), different target picks, identical parameters afterwards
     assert it0["shape"] == it1["shape"] == (2, 8, 12, 12)

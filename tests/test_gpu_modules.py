@@ -180,6 +180,53 @@ def test_trainer_iterations_on_gpu():
     assert sum(tr.pool[i] is not None for i in range(16)) >= 4 and tr.pool._dense.is_cuda
 
 
+@pytest.mark.parametrize("pool_dtype", [torch.float32, torch.bfloat16])
+def test_trainer_default_model_c20_pool_dtypes(pool_dtype, monkeypatch):
+    """ConditionedNCATrainer around the reference's DEFAULT model (C = 20): fused forward + backward for an fp32 pool; a bf16
+    POOL keeps its storage type (the steps run in fp32 on the exactly widened state -- the bf16-storage kernels cover C <= 16)
+    and update_pool's scatter receives the pool's dtype."""
+    from ncahip import autograd as AG
+    from ncahip.conditioned_trainer import ConditionedNCATrainer
+    from ncahip.nca import ConditionedNCA
+
+    def _no(*a, **k):
+        raise AssertionError("the composed eager pass was reached")
+    monkeypatch.setattr(AG, "_cond_grow_composed", _no)
+
+    class DS:
+        target_size = (3, 32, 32)
+
+        def __init__(self):
+            self.x = torch.rand(6, 3, 32, 32)
+
+        def __len__(self):
+            return 6
+
+        def __getitem__(self, i):
+            return self.x[i]
+
+    class PixLoss(torch.nn.Module):
+        def forward(self, d):
+            s = d["nca_state"].float()
+            l = (d["generated_images"].float() - d["target_images"]).pow(2).mean() + (s - s.clamp(-1, 1)).abs().mean()
+            return [l, {"pix": l.detach()}]
+
+    torch.manual_seed(3)
+    m = ConditionedNCA(target_shape=(3, 32, 32)).to(DEV)
+    assert m.num_channels == 20
+    w0 = m.update_net.out[0].weight.detach().clone()
+    tr = ConditionedNCATrainer(m, DS(), None, nca_steps=[4, 8], lr=2e-3, pool_size=16, log_base_path="/tmp/ncahip_gpu_test",
+                               loss=PixLoss(), device=torch.device(DEV), pool_dtype=pool_dtype)
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    tr.train(batch_size=4, epochs=2)
+    assert not torch.equal(m.update_net.out[0].weight.detach(), w0)
+    assert tr.pool._dense.dtype == pool_dtype and tr.pool._dense.is_cuda
+    assert bool(torch.isfinite(tr.pool._dense.float()).all())
+    with torch.no_grad():     # no-grad grow of a bf16 state at C = 20: fp32 steps, bf16 out
+        out = m.grow(m.generate_seed(2).to(DEV, pool_dtype), 3, torch.rand(2, 3, 32, 32, device=DEV))
+    assert out.dtype == pool_dtype
+
+
 def test_dynca_autograd_through_module():
     """loss.backward() through DyNCA.forward_nsteps incl. the rgb head and intermediate features."""
     from ncahip.models.dynca import DyNCA

@@ -50,6 +50,7 @@ class ConditionedNCATrainer(NCATrainer):
         self.min_steps, self.max_steps = nca_steps
         self.damage_radius = damage_radius
         self.log_every = 1
+        ncadist.broadcast_parameters(nca)      # data parallel: every replica starts from rank 0's weights (no-op in one process)
         self.optimizer = torch.optim.Adam(nca.parameters(), lr=lr)
         self.lr_sched = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=[5000], gamma=0.3)
         # objective

@@ -8,6 +8,9 @@ one strategy BASELINE.json's north_star asks for:
     gradient (~10.7k floats = 43 KB: latency-bound, so one bucket / one call), issued BEFORE the per-parameter
     gradient normalisation (conditioned_trainer.py:134-136) so the normalised direction equals the
     single-process large-batch one;
+  * the replicas START equal: `broadcast_parameters` sends rank 0's parameters and buffers to every rank (one flat bucket
+    per dtype) when a trainer is constructed, before its optimiser exists -- each process builds its model under its own
+    (rank-offset) RNG state, and Adam would keep differently initialised replicas apart silently;
   * every rank runs the same number of NCA steps: rank 0 draws T with the reference's own call and broadcasts it
     (`shared_int`), so no rank idles at the collective; everything else that is sampled (pool slots, targets, fire
     masks) comes from rank-offset generators (`rank_seed`) so the shards contribute DIFFERENT samples to the global batch;
@@ -74,14 +77,39 @@ def allreduce_mean_grads(params: Iterable[torch.nn.Parameter], group=None) -> in
     return flat.numel()
 
 
+def _coll_device() -> torch.device:
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+@torch.no_grad()
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> int:
+    """Make every rank's replica equal to rank `src`'s: all parameters and buffers of `module` travel in ONE flat bucket per
+    dtype (a handful of KB for the NCA models: latency-bound, so one call) and are copied back in place.  Returns the number
+    of elements sent.  A no-op in a single process."""
+    if world_size() == 1:
+        return 0
+    tensors = [t for t in list(module.parameters()) + list(module.buffers()) if t.numel()]
+    sent = 0
+    for dtype in sorted({t.dtype for t in tensors}, key=str):
+        group_t = [t for t in tensors if t.dtype == dtype]
+        dev = _coll_device()
+        flat = torch.cat([t.detach().reshape(-1).to(dev) for t in group_t])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for t in group_t:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t).to(t.device))
+            off += n
+        sent += flat.numel()
+    return sent
+
+
 def shared_int(value: int = 0) -> int:
     """Rank 0's `value` on every rank (one 8-byte broadcast): the per-iteration step count T, drawn by rank 0 with the
     reference's own RNG call, so that every rank runs the same number of NCA steps and none idles at the all-reduce."""
     if world_size() == 1:
         return int(value)
-    t = torch.tensor([int(value)], dtype=torch.int64)
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    t = t.to(dev)
+    t = torch.tensor([int(value)], dtype=torch.int64).to(_coll_device())
     dist.broadcast(t, src=0)
     return int(t.item())
 

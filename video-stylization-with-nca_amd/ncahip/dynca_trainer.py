@@ -35,6 +35,7 @@ class DyNCATrainer:
         self.min_steps, self.max_steps = nca_steps
         self.inject_seed_step, self.reseed_offset = inject_seed_step, reseed_offset
         self.pool_size = ncadist.shard_size(pool_size)
+        ncadist.broadcast_parameters(model)    # data parallel: every replica starts from rank 0's weights (no-op in one process)
         with torch.no_grad():
             self.pool = model.seed(self.pool_size, size=size).to(self.device)
         self.optimizer = torch.optim.Adam(model.parameters(), lr=lr)

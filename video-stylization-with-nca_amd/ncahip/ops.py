@@ -25,6 +25,28 @@ def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     return t.contiguous()
 
 
+_WS_CACHE = {}
+
+
+def _workspace(nbytes: int, device: torch.device) -> torch.Tensor:
+    """Scratch for the backward drivers, kept per (device, stream) and grown on demand: the drivers take a caller-owned
+    workspace of up to ~0.5 GB (BASELINE configs[2]); allocating it afresh per call costs a torch.empty of that size per
+    training step.  Work on one stream is ordered, so consecutive calls may share it."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = None
+        _WS_CACHE.pop(key, None)
+        ws = torch.empty(max(nbytes, 1), device=device, dtype=torch.uint8)
+        _WS_CACHE[key] = ws
+    return ws
+
+
+def release_workspaces() -> None:
+    """Drop the cached backward workspaces (they are re-created on the next backward)."""
+    _WS_CACHE.clear()
+
+
 def _state_dtype(x: torch.Tensor):
     """The fused steps exist for fp32 and for bf16 state storage (ncahip_*_bf16, see include/ncahip.h)."""
     if x.dtype not in (torch.float32, torch.bfloat16):
@@ -293,7 +315,7 @@ def cond_grow_backward(states: torch.Tensor, pre: torch.Tensor, goal: Optional[t
          "b1": torch.empty(hid, device=dev, dtype=f32), "w2": torch.empty(hid, hid, device=dev, dtype=f32),
          "b2": torch.empty(hid, device=dev, dtype=f32), "w3": torch.empty(C, hid, device=dev, dtype=f32)}
     nbytes = lib().ncahip_cond_grow_bwd_workspace(B, C, H, W, hid)
-    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    ws = _workspace(nbytes, dev)
     check(getattr(lib(), "ncahip_cond_grow_bwd_" + sfx)(
         _p(states), _p(pre), T, _p(goal), gch, _p(us), _p(w.wp), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), _p(w.w3), B, C, H, W,
         hid, alive_ch, thr, fire_rate, lo, hi, seed, step0, _p(g_final), _p(g["x0"]), _p(g["goal"]), _p(g["wp"]), _p(g["w1"]),
@@ -361,7 +383,7 @@ def dynca_nsteps_backward(states: torch.Tensor, cond: Optional[torch.Tensor], us
     fn = "ncahip_dynca_nsteps_bwd_bf16" if dsfx == "bf16" else f"ncahip_dynca_nsteps_bwd{sfx}_f32"
     wsfn = "ncahip_dynca_nsteps_bwd_bf16_workspace" if dsfx == "bf16" else f"ncahip_dynca_nsteps_bwd{sfx}_workspace"
     nbytes = getattr(lib(), wsfn)(B, C, H, W, fc, c_cond)
-    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    ws = _workspace(nbytes, dev)
     check(getattr(lib(), fn)(_p(states), T, _p(cond), _p(us), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C, H, W, fc,
                                             c_cond, PAD_MODES[pad_mode], update_rate, seed, step0, _p(g), _p(g_states), _p(out["x0"]),
                                             _p(out["w1"]), _p(out["b1"]), _p(out["w2"]), _p(out["b2"]), _p(ws), nbytes, _stream()),

@@ -67,5 +67,5 @@ class SamplePool(Dataset):
     def scatter(self, idxs: Iterable[int], batch: torch.Tensor) -> None:
         idxs = [int(i) for i in idxs]
         self._ensure(batch)
-        self._dense.index_copy_(0, torch.as_tensor(idxs, device=self._dense.device), batch.detach().to(self._dense.device))
+        self._dense.index_copy_(0, torch.as_tensor(idxs, device=self._dense.device), batch.detach().to(self._dense.device, self._dense.dtype))
         self._valid[idxs] = True
