@@ -19,6 +19,9 @@ Extra objects on the JSON line:
   bf16_storage      the same grow loop on the bf16-storage kernels (informational; `value` stays the fp32 path).
   backward          the recompute-based backward of the same loop (fp32 / bf16 history), per step (informational).
   f32_bf16x3        the same loop with ncahip_cond_precision(1) (opt-in bf16-pair emulation of the fp32 products).
+  train             ConditionedNCATrainer iterations at BASELINE configs[2] as written (B=32, T=96, bf16 pool, the default
+                    objective on seeded-random VGG16) + stand-in objective lines, with per-phase device times; on every rank
+                    (contains the RCCL all-reduce when N > 1).  Informational.
   cpu_baseline      the CPU oracle (pure-PyTorch restatement == the reference's CPU path, bit-identical)
                     timed on this box's host cores on a bounded sample (rank 0, N=1 only).
 """
@@ -131,13 +134,23 @@ def cpu_baseline(prm, x0, goal):
 
 
 def train_leg(dev, world, iters):
-    """ConditionedNCATrainer iterations at BASELINE configs[3]'s per-GPU shape (32 grids of 16 x 256 x 256 per rank, pool
-    sharded over the ranks): sample -> 2 x {grow 64 steps with history, objective, backward through the fused backward kernels,
-    ONE flat-bucket gradient all-reduce (RCCL when N > 1), per-tensor normalisation, Adam} -> pool write-back.  The objective is
-    a stand-in (MSE to the target + the reference's overflow term): the VGG weights of the style loss cannot be fetched here."""
+    """ConditionedNCATrainer iterations at BASELINE configs[2] AS WRITTEN, per GPU (= configs[3]'s per-rank shape: 32 grids of
+    16 x 256 x 256 per rank, pool sharded over the ranks): sample -> 2 x {grow T = 96 steps with history, objective, backward
+    through the fused backward kernels, ONE flat-bucket gradient all-reduce (RCCL when N > 1), per-tensor normalisation, Adam}
+    -> pool write-back (conditioned_trainer.py:122-171).  Lines:
+      cfg3_bf16_loss     bf16 pool + the reference's default objective (loss/loss.py:61-76: OT appearance + content + overflow)
+                         on VGG16 features with seeded-random weights in bf16 (the ImageNet weights cannot be fetched here: the
+                         WORK is the same, the loss VALUE is not comparable) -- configs[2];
+      bf16_standin       the same loop with a stand-in objective (MSE to the target + overflow): what the NCA kernels cost alone;
+      f32_standin        fp32 pool, stand-in objective.
+    Each line carries per-phase device times (HIP events on the stream, ms per ITERATION = two train_batch calls): grow forward,
+    objective forward+backward, grow backward (+ encoder), all-reduce, normalise + Adam, report (the step's one host sync)."""
+    import gc
     import tempfile
-    from ncahip import dist as nd
-    from ncahip.conditioned_trainer import ConditionedNCATrainer
+    import warnings
+    import numpy as np
+    from ncahip.conditioned_trainer import ConditionedNCATrainer, PhaseTimer
+    from ncahip.loss import Loss
     from ncahip.nca import ConditionedNCA
 
     class Targets:
@@ -158,38 +171,56 @@ def train_leg(dev, world, iters):
             l = (d["generated_images"] - d["target_images"]).square().mean() + (s - s.clamp(-1.0, 1.0)).abs().mean()
             return [l, {}]
 
-    torch.manual_seed(0)                                  # identical initial weights on every rank
+    torch.manual_seed(0)
     nca = ConditionedNCA(target_shape=(3, H, W), num_hidden_channels=C - 4, living_channel_dim=ALIVE_CH).to(dev)
     nca.mask_rng = "philox"
-    TB, TT = 32, 64
+    TB, TT = 32, 96
+    style = (np.random.RandomState(0).rand(H, W, 3) * 255).astype(np.uint8)
     out = {}
-    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
-        tr = ConditionedNCATrainer(nca, Targets(), None, nca_steps=[TT, TT], pool_size=2 * TB * world, loss=StandIn(), device=dev,
+    for name, dt, default_obj in (("cfg3_bf16_loss", torch.bfloat16, True), ("bf16_standin", torch.bfloat16, False),
+                                  ("f32_standin", torch.float32, False)):
+        if default_obj:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                objective = Loss(dev, target_style_image=style, feature_dtype=torch.bfloat16)
+        else:
+            objective = StandIn()
+        tr = ConditionedNCATrainer(nca, Targets(), None, nca_steps=[TT, TT], pool_size=2 * TB * world, loss=objective, device=dev,
                                    log_base_path=tempfile.mkdtemp(prefix="ncahip_bench_"), pool_dtype=dt)
         for w_ in range(2):                               # warm-up: allocator (history ring, backward workspace), first touch of
-            tr._iteration(0, TB * world)                  # every kernel; one iteration left a one-off 50 ms inside the timed three
+            tr._iteration(0, TB * world)                  # every kernel
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
-        times = []
-        for i in range(iters):                            # every iteration timed on its own (synchronised): the MEDIAN is reported, one
-            t0 = time.perf_counter()                      # slow iteration (allocator, clocks) does not move it
+        tr.phase_timer = PhaseTimer()
+        times, phases = [], []
+        for i in range(iters):                            # every iteration timed on its own (synchronised): the MEDIAN is reported
+            tr.phase_timer.reset()
+            t0 = time.perf_counter()
             _, _, _, loss, _ = tr._iteration(i + 1, TB * world)
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
+            phases.append(tr.phase_timer.summary())
         tt = torch.tensor(times, device=dev, dtype=torch.float64)
         if world > 1:
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)   # an iteration ends when its slowest rank does
         med, mean = float(tt.median().item()), float(tt.mean().item())
+        ph = {k: float(np.median([p.get(k, 0.0) for p in phases])) for k in sorted({k for p in phases for k in p})}
         out[name] = {"ms_per_iteration": med * 1e3, "ms_per_iteration_mean": mean * 1e3,
-                     "cell_updates_per_s_fwd_bwd": world * TB * H * W * TT * 2 / med, "last_loss": float(loss)}
-        del tr                                            # the next leg's pool / history have other sizes: start it from an empty cache
-        import gc
+                     "cell_updates_per_s_fwd_bwd": world * TB * H * W * TT * 2 / med, "last_loss": float(loss),
+                     "phase_ms_per_iteration": ph, "phase_ms_sum": sum(ph.values())}
+        tr.phase_timer = None
+        del tr, objective                                 # the next leg's pool / history have other sizes: start it from an empty cache
+        from ncahip import ops as _ops
+        _ops.release_workspaces()
         gc.collect()
         torch.cuda.empty_cache()
     out.update({"B_per_gpu": TB, "nca_steps": TT, "train_batches_per_iteration": 2, "iterations": iters,
                 "allreduce_floats": sum(p.numel() for p in nca.parameters() if p.requires_grad), "n_gpus": world,
-                "objective": "stand-in: MSE + overflow (VGG weights unobtainable offline)"})
+                "config": "BASELINE configs[2] per GPU: B=32 C=16 256x256, 96 steps + VGG style loss backprop, bf16 pool",
+                "objective": {"cfg3_bf16_loss": "ncahip.loss.Loss: OT appearance (batched) + content + overflow, VGG16 seeded-random "
+                                                "weights, bf16 features (loss value not comparable with the reference)",
+                              "*_standin": "MSE + overflow"}})
     return out
 
 
@@ -200,7 +231,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + rooflines only (profiling passes)")
-    ap.add_argument("--train-iters", type=int, default=5, help="iterations of the training-shaped leg (0: skip)")
+    ap.add_argument("--train-iters", type=int, default=5, help="iterations of the training-shaped legs (0: skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -24,7 +24,7 @@ fi
 timeout -k 10 400 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err || { tail -20 $out/${tag}_bench.err; exit 1; }
 cat $out/${tag}_bench.json
 P="python bench.py --no-cpu-baseline --no-extras"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/${tag}_prof -o stats --output-format csv -- $P --steps 3 --warmup 1 > $out/${tag}_prof.log 2>&1 || { tail -20 $out/${tag}_prof.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/${tag}_prof -o stats --output-format csv -- $P --steps 20 --warmup 3 > $out/${tag}_prof.log 2>&1 || { tail -20 $out/${tag}_prof.log; exit 1; }
 stats $out/${tag}_prof $out/${tag}_kernel_stats.txt 8
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $out/${tag}_pmc/f -o f --output-format csv -- $P --steps 1 --warmup 0 > $out/${tag}_pmcf.log 2>&1 || { tail -20 $out/${tag}_pmcf.log; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $out/${tag}_pmc/w -o w --output-format csv -- $P --steps 1 --warmup 0 > $out/${tag}_pmcw.log 2>&1 || { tail -20 $out/${tag}_pmcw.log; exit 1; }

@@ -33,6 +33,34 @@ from .trainer import NCATrainer
 _GRAD_EPS = 1e-10
 
 
+class PhaseTimer:
+    """Optional per-phase device timing of train_batch (bench.py's `train` leg): `mark(name)` records an event on the current
+    stream; the time between two consecutive marks is booked under the LATER mark's name.  Never on unless a caller sets
+    `trainer.phase_timer = PhaseTimer()`; no host synchronisation until `summary()`."""
+
+    def __init__(self):
+        self.events = []
+
+    def mark(self, name: str) -> None:
+        if torch.cuda.is_available():
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.events.append((name, ev))
+
+    def reset(self) -> None:
+        self.events = []
+
+    def summary(self) -> Dict[str, float]:
+        """ms per phase, summed over everything recorded since the last reset ('start' marks open an interval)."""
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        out: Dict[str, float] = {}
+        for (_, e0), (n1, e1) in zip(self.events, self.events[1:]):
+            if n1 != "start":
+                out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
+        return out
+
+
 class ConditionedNCATrainer(NCATrainer):
     def __init__(self, nca, target_dataset, target_style_image, nca_steps=[48, 96], lr: float = 2e-3,
                  pool_size: int = 512, num_damaged: int = 0, log_base_path: str = "test", damage_radius: int = 3,
@@ -59,6 +87,7 @@ class ConditionedNCATrainer(NCATrainer):
                         appearance_loss_weight=appearance_loss_weight, content_loss_weight=content_loss_weight,
                         overflow_loss_weight=overflow_loss_weight)
         self.loss = loss
+        self.phase_timer: Optional[PhaseTimer] = None
         # storage type of the pool and of the grow loop's history ring: float32 (the reference) or bfloat16 (BASELINE
         # configs[2]: half the saved-for-backward set; bf16-storage kernels forward, fp32 gradients)
         self.pool_dtype = pool_dtype
@@ -103,11 +132,15 @@ class ConditionedNCATrainer(NCATrainer):
     def _normalise_and_step(self) -> List[torch.nn.Parameter]:
         live = [p for p in self.nca.parameters() if p.requires_grad]
         ncadist.allreduce_mean_grads(live)               # global-batch gradient first, then the per-tensor normalisation
+        if self.phase_timer:
+            self.phase_timer.mark("allreduce")
         for p in live:
             if p.grad is not None:
                 p.grad.div_(p.grad.norm() + _GRAD_EPS)
         self.optimizer.step()
         self.lr_sched.step()
+        if self.phase_timer:
+            self.phase_timer.mark("normalise_adam")
         return live
 
     def _report(self, loss: torch.Tensor, parts: Optional[Dict]) -> Dict[str, float]:
@@ -125,14 +158,25 @@ class ConditionedNCATrainer(NCATrainer):
 
     def train_batch(self, batch, targets):
         steps = ncadist.shared_int(random.randint(self.min_steps, self.max_steps))   # every rank: rank 0's draw
+        pt = self.phase_timer
+        if pt:
+            pt.mark("start")
         grown = self.nca.grow(batch, num_steps=steps, goal=targets)
+        if pt:
+            pt.mark("grow_fwd")
+            if grown.requires_grad:       # fires when dL/d(grown) exists: the objective's forward + backward end here
+                grown.register_hook(lambda g: (pt.mark("objective_fwd_bwd"), g)[1])
         gf = grown.float()                                    # a bf16 pool: the objective is evaluated in fp32
         loss, parts = self.loss({"generated_images": gf[:, :self.num_target_channels], "nca_state": gf,
                                  "target_images": targets})
         self.optimizer.zero_grad()
         loss.backward()
+        if pt:
+            pt.mark("grow_bwd")              # fused backward of the T steps + the conditioning encoder's backward
         self._normalise_and_step()
         report = self._report(loss, parts)
+        if pt:
+            pt.mark("report")
         return grown.detach(), report["loss"], report
 
     # ------------------------------------------------------------------------------------------------ loop
