@@ -284,6 +284,76 @@ def cond_grow_loss_grads(x0, goal_enc_padded, us, prm, alive_ch, thr, fire_rate,
     return xT.detach(), x0.grad, g.grad, grads
 
 
+def cond_gate_margin(x0, goal_enc_padded, us, prm, alive_ch, thr=0.1, fire_rate=0.5, use_living_channel=True):
+    """Proof hook for gradient comparisons: per batch item, the smallest RELATIVE margin of a ReLU gate that carries
+    gradient along the oracle trajectory -- min over steps, over cells that fired and live (r * life = 1: nca.py:189-193) and
+    over the 128 hidden units of |pre-activation| / (sum_k |w_k| |in_k| + |b|).  A gate whose margin is below the rounding
+    spread of an fp32 dot product (n terms: at worst n * 2^-24, typically sqrt(n) * 2^-24) may resolve differently under
+    another summation order (MFMA vs CPU convolution): ONE such unit moves the gradients through it by O(1e-3) of the maximum
+    while the forward agrees to 1e-6.  Items whose margin is well above that have no such excuse."""
+    w1, b1 = prm["update_net.out.0.weight"], prm["update_net.out.0.bias"]
+    w2, b2 = prm["update_net.out.2.weight"], prm["update_net.out.2.bias"]
+    x = x0
+    best = torch.full((x0.shape[0],), float("inf"))
+    with torch.no_grad():
+        for u in us:
+            d = cond_step(x, goal_enc_padded, u, prm, alive_ch, thr, fire_rate, use_living_channel, return_all=True)
+            carries = (d["rmask"] * d["life"][:, :1]) > 0     # [B,1,H,W] (life has C channels when use_living_channel is off)
+            pre1 = F.conv2d(d["p"], w1, b1)
+            bnd1 = F.conv2d(d["p"].abs(), w1.abs(), b1.abs())
+            h1 = F.relu(pre1)
+            pre2 = F.conv2d(h1, w2, b2)
+            bnd2 = F.conv2d(h1, w2.abs(), b2.abs())
+            for pre, bnd in ((pre1, bnd1), (pre2, bnd2)):
+                m = (pre.abs() / bnd.clamp_min(1e-30)).masked_fill(~carries.expand_as(pre), float("inf"))
+                best = torch.minimum(best, m.flatten(1).min(dim=1).values)
+            x = d["x2"]
+    return best
+
+
+def cond_gate_influence(x0, goal_enc_padded, us, prm, alive_ch, k, thr=0.1, fire_rate=0.5, use_living_channel=True):
+    """Where may dL/dx0 and dL/dgoal legitimately differ between two fp32 evaluations?  A gradient-carrying gate with relative
+    margin < k at step t (0-based), cell c, perturbs dL/dz_t on c's 3x3 neighbourhood, and every earlier step's stencil
+    adjoint widens that by one cell: dL/dx0 and dL/dgoal can move within Chebyshev distance t + 1 of c, nowhere else.
+    Returns (region [B,1,H,W] bool, number of such gates per item [B])."""
+    w1, b1 = prm["update_net.out.0.weight"], prm["update_net.out.0.bias"]
+    w2, b2 = prm["update_net.out.2.weight"], prm["update_net.out.2.bias"]
+    x = x0
+    region = torch.zeros(x0.shape[0], 1, x0.shape[2], x0.shape[3], dtype=torch.bool)
+    count = torch.zeros(x0.shape[0], dtype=torch.long)
+    with torch.no_grad():
+        for t, u in enumerate(us):
+            d = cond_step(x, goal_enc_padded, u, prm, alive_ch, thr, fire_rate, use_living_channel, return_all=True)
+            carries = (d["rmask"] * d["life"][:, :1]) > 0
+            pre1 = F.conv2d(d["p"], w1, b1)
+            bnd1 = F.conv2d(d["p"].abs(), w1.abs(), b1.abs())
+            h1 = F.relu(pre1)
+            pre2 = F.conv2d(h1, w2, b2)
+            bnd2 = F.conv2d(h1, w2.abs(), b2.abs())
+            amb = ((pre1.abs() < k * bnd1).any(1, keepdim=True) | (pre2.abs() < k * bnd2).any(1, keepdim=True)) & carries
+            count += ((pre1.abs() < k * bnd1) & carries).flatten(1).sum(1) + ((pre2.abs() < k * bnd2) & carries).flatten(1).sum(1)
+            r = t + 1
+            region |= F.max_pool2d(amb.float(), 2 * r + 1, 1, r) > 0
+            x = d["x2"]
+    return region, count
+
+
+def dynca_gate_margin(x0, cond, us, prm, pad_mode, update_rate=0.5, scales=(0,)):
+    """As cond_gate_margin for the DyNCA step (one hidden layer, dynca.py:126-133): per batch item, min over steps, updated
+    cells (m = 1) and hidden units of |w1 y + b1| / (|w1| |y| + |b1|)."""
+    x = x0
+    best = torch.full((x0.shape[0],), float("inf"))
+    with torch.no_grad():
+        for u in us:
+            r = dynca_step(x, cond, u, prm, pad_mode, update_rate, scales, return_all=True)
+            pre = F.conv2d(r["y"], prm["w1.weight"], prm["w1.bias"])
+            bnd = F.conv2d(r["y"].abs(), prm["w1.weight"].abs(), prm["w1.bias"].abs())
+            m = (pre.abs() / bnd.clamp_min(1e-30)).masked_fill(~(r["m"] > 0).expand_as(pre), float("inf"))
+            best = torch.minimum(best, m.flatten(1).min(dim=1).values)
+            x = r["x"]
+    return best
+
+
 def dynca_nsteps_loss_grads(x0, cond, us, prm, pad_mode, update_rate, cot, scales=(0,)):
     x0 = x0.clone().requires_grad_(True)
     p = {k: prm[k].clone().requires_grad_(True) for k in ("w1.weight", "w1.bias", "w2.weight", "w2.bias")}

@@ -15,7 +15,7 @@ import pytest
 import torch
 
 from oracle import nca_oracle as O
-from util import REL_TOL, T, load, rel_err, sd
+from util import GATE_K, REL_TOL, T, grads_match_outside, load, rel_err, sd
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -197,6 +197,7 @@ def test_cfg3_forward_backward_vs_oracle_on_crops(ops, storage):
     if bf:
         x, goal = x.bfloat16().float(), goal.bfloat16().float()
     # oracle on the crops
+    regions, n_amb = [], []
     gx_ref = torch.zeros(B, C, CR, CR)
     gg_ref = torch.zeros(B, C - 4, CR, CR)
     out_ref = torch.zeros(B, C, CR, CR)
@@ -208,6 +209,10 @@ def test_cfg3_forward_backward_vs_oracle_on_crops(ops, storage):
                                                     prm, 3, 0.1, 0.5, cot[sl])
         out_ref[b], gx_ref[b], gg_ref[b] = xT[0], gx0[0], ggoal[0, 4:]
         wsum = gw if wsum is None else {k: wsum[k] + v for k, v in gw.items()}
+        if not bf:   # proof hook: where the oracle's own near-zero ReLU gates can move this item's gradients (util.GATE_K)
+            reg, cnt = O.cond_gate_influence(x[sl], O.cond_pad_goal(goal[sl], C), [u[sl[0], :, sl[2], sl[3]] for u in us], prm, 3, GATE_K)
+            regions.append(reg[0])
+            n_amb.append(int(cnt[0]))
     dt = torch.bfloat16 if bf else torch.float32
     xd, gd = x.to(DEV, dt), goal.to(DEV, dt)
     w = cond_w(ops, prm, xd)
@@ -217,30 +222,44 @@ def test_cfg3_forward_backward_vs_oracle_on_crops(ops, storage):
     # bf16 recomputation): the trajectory and a few per cent of the gates differ from the fp32 oracle's, so forward within 3e-2
     # max-norm and gradients within 8 % relative L2 (tests/test_gpu_bf16.py bounds the same kernel at 2-4 % against the oracle
     # that shares its rounding points)
-    # fp32 gradients: relative L2 within 1e-3 plus a cap of 1e-2 on the largest single deviation.  Not a max-norm bound of 2e-4:
-    # with ~1e8 hidden pre-activations in this test a handful lie within fp32 rounding of zero, their ReLU gate resolves differently
-    # under the MFMA's and the CPU convolution's summation orders, and each such unit moves ONE cell's gradient by ~1e-3 of the
-    # maximum and, carried through the later steps' stencils, the item's relative L2 by ~2.5e-4 (seen: 1e-3 and 3e-3 at single
-    # cells, L2 2.6e-4 for that item, different items for different host thread counts; items without such a unit sit at ~1e-6).
-    ftol, gtol = (REL_TOL, 1e-3) if not bf else (3e-2, 8e-2)
-
-    def gerr(a, b_):
-        if not bf:
-            assert _rel(a, b_) < 1e-2, _rel(a, b_)
-        return _rel2(a, b_)
+    # fp32 gradients, per item: the north_star-level max-norm bound 2e-4.  With ~1e8 hidden pre-activations in this test a few
+    # lie within fp32 rounding of zero; such a gate resolves differently under the MFMA's and the CPU convolution's summation
+    # orders and moves ONE cell's gradient by ~1e-3 of the maximum (seen: 1e-3 / 3e-3 at single cells, a different item for a
+    # different host thread count).  That excuse is PROVEN per item, not assumed: an item that misses 2e-4 must (i) miss it only
+    # inside the influence region of gates the ORACLE itself reports within GATE_K of zero (cond_gate_influence: Chebyshev
+    # distance t + 1 of the cell), (ii) still meet relative L2 1e-3 with the largest deviation below 1e-2, and (iii) such items
+    # are at most 4 of the 32.  The weight gradients (sums over every cell of every item) get the L2 bound only when some item
+    # needed the excuse, the max-norm bound otherwise.
+    ftol = REL_TOL if not bf else 3e-2
+    excused = []
     for b in range(B):
         y0, x0_ = wins[b]
         win = (b, slice(None), slice(y0, y0 + CR), slice(x0_, x0_ + CR))
         assert rel_err(out[win].float(), out_ref[b]) < ftol, b
-        assert gerr(gr["x0"][win], gx_ref[b]) < gtol, b
-        assert gerr(gr["goal"][win], gg_ref[b]) < gtol, b
+        if bf:
+            assert _rel2(gr["x0"][win], gx_ref[b]) < 8e-2 and _rel2(gr["goal"][win], gg_ref[b]) < 8e-2, b
+        else:
+            strict = _rel(gr["x0"][win], gx_ref[b]) < 2e-4 and _rel(gr["goal"][win], gg_ref[b]) < 2e-4
+            if not strict:
+                ok1, out1, in1 = grads_match_outside(gr["x0"][win], gx_ref[b], regions[b])
+                ok2, out2, in2 = grads_match_outside(gr["goal"][win], gg_ref[b], regions[b])
+                assert n_amb[b] > 0 and ok1 and ok2, (b, n_amb[b], out1, in1, out2, in2)      # (i)
+                assert _rel2(gr["x0"][win], gx_ref[b]) < 1e-3 and _rel(gr["x0"][win], gx_ref[b]) < 1e-2, b   # (ii)
+                assert _rel2(gr["goal"][win], gg_ref[b]) < 1e-3 and _rel(gr["goal"][win], gg_ref[b]) < 1e-2, b
+                excused.append(b)
         dead = torch.ones(S, S, dtype=torch.bool)
         dead[y0:y0 + CR, x0_:x0_ + CR] = False
         assert float(gr["x0"][b][:, dead.to(DEV)].abs().max()) == 0.0 and float(out[b][:, dead.to(DEV)].float().abs().max()) == 0.0
+    assert len(excused) <= 4, excused                                                        # (iii)
     names = {"wp": "perception_net.weight", "w1": "update_net.out.0.weight", "b1": "update_net.out.0.bias",
              "w2": "update_net.out.2.weight", "b2": "update_net.out.2.bias", "w3": "update_net.out.4.weight"}
     for k, n in names.items():
-        assert gerr(gr[k].reshape(-1), wsum[n].reshape(-1)) < gtol, k
+        if bf:
+            assert _rel2(gr[k].reshape(-1), wsum[n].reshape(-1)) < 8e-2, k
+        elif excused:
+            assert _rel2(gr[k].reshape(-1), wsum[n].reshape(-1)) < 1e-3 and _rel(gr[k].reshape(-1), wsum[n].reshape(-1)) < 1e-2, k
+        else:
+            assert _rel(gr[k].reshape(-1), wsum[n].reshape(-1)) < 2e-4, k
 
 
 def test_cfg3_batch_independence_and_determinism(ops):

@@ -379,8 +379,8 @@ def test_default_model_grow_backward_matches_reference_autograd_g11(tag, hidden,
 
 def test_conditioned_nca_default_arguments_c20():
     """ConditionedNCA() exactly as the reference constructs it by default (target 3x64x64, 16 hidden channels -> C = 20,
-    nca.py:62-94; train.py -N 16): forward on the fused generic kernels (two output tiles), gradients through the composed
-    pass, both against the oracle."""
+    nca.py:62-94; train.py -N 16): forward on the fused generic kernels (two output tiles), gradients through the fused
+    backward (front + matrix kernels at CP = 20), both against the oracle."""
     from ncahip.nca import ConditionedNCA
     torch.manual_seed(2)
     m = ConditionedNCA()
@@ -428,17 +428,26 @@ def test_conditioned_nca_default_arguments_c20():
     _inject(md, us[:4])
     xd = x0.to(DEV).requires_grad_(True)
     (md.grow(xd, 4, goal.to(DEV)) * cot.to(DEV)).sum().backward()
-    # 2 x 64 x 64 cells x 128 hidden units x 4 steps through library GEMMs (~1e-6 from the CPU convolutions): a few ReLU gates
-    # resolve differently (util.grad_close); the weight gradients are heavily cancelling sums, so a few cells move them by ~3e-3
-    from functools import partial
-    from util import grad_close as _gc
-    grad_close = partial(_gc, l2=5e-3, cap=5e-2)
-    assert grad_close(xd.grad, xr.grad)
+    # 2 x 64 x 64 cells x 128 hidden units x 4 steps = 4e6 ReLU gates: the max-norm bound 2e-4 holds unless one of them lies
+    # within fp32 rounding of zero in the ORACLE's own evaluation, and that is proven, not assumed (tests/util.py): dL/dx0 may miss
+    # 2e-4 only inside the influence region of gates the oracle reports within GATE_K of zero; only then do the parameter
+    # gradients (sums over every cell) get the relative-L2 bound instead of the max-norm one.
+    from util import GATE_K, grad_close, grads_match_outside
+    gpad = O.cond_pad_goal(O.image_encoder(goal, prm), 20)
+    region, count = O.cond_gate_influence(x0, gpad, us[:4], prm, 3, GATE_K)
+    ok, n_out, n_in = grads_match_outside(xd.grad, xr.grad, region)
+    assert ok, (n_out, n_in, count.tolist())
+    excused = n_in > 0
+    assert not excused or int(count.sum()) > 0
+    assert float(region.float().mean()) < 0.25, float(region.float().mean())     # the excuse covers a small part of the grid
     checked = 0
     for n, w in md.named_parameters():
         if p[n].grad is None:
             continue
-        assert grad_close(w.grad, p[n].grad), n
+        if excused:
+            assert grad_close(w.grad, p[n].grad, l2=1e-3, cap=1e-2), n
+        else:
+            assert float((w.grad.cpu() - p[n].grad).abs().max()) < 2e-4 * max(float(p[n].grad.abs().max()), 1e-6), n
         checked += 1
     assert checked == 9
 

@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import nca_oracle as O
-from util import REL_TOL, T, load, rel_err, sd
+from util import REL_TOL, T, grad_close, load, rel_err, sd
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -764,9 +764,13 @@ def test_dynca_backward_shape_fuzz(ops):
     rng = np.random.RandomState(int(os.environ.get("NCAHIP_FUZZ_SEED", "888")))
     pads = ["replicate", "circular", "reflect", "constant"]
     ncases, ambiguous = int(os.environ.get("NCAHIP_FUZZ_CASES", "14")), 0
+    shapes = [(12, 96), (16, 128), (8, 64), (16, 96), (5, 40), (32, 256), (20, 100), (24, 192), (16, 320), (32, 128)]
     for case in range(ncases):
-        # (round 2: C up to 32 and hidden layers beyond 128 -- 128-wide slices -- through the C driver as well)
-        C, fc = [(12, 96), (16, 128), (8, 64), (16, 96), (5, 40), (32, 256), (20, 100), (24, 192), (16, 320), (32, 128)][int(rng.randint(0, 10))]
+        # (round 2: C up to 32 and hidden layers beyond 128 -- 128-wide slices -- through the C driver as well; the multi-slice
+        # shapes (32, 256), (16, 320), (24, 192) are always in the draw: cases 0..2)
+        C, fc = shapes[int(rng.randint(0, 10))]
+        if case < 3:
+            C, fc = ((32, 256), (16, 320), (24, 192))[case]
         cc = int(rng.choice([0, 2, 3]))
         B = int(rng.randint(1, 3)); H = int(rng.randint(2, 30)); W = int(rng.randint(2, 45))
         if rng.rand() < 0.5:
@@ -786,11 +790,17 @@ def test_dynca_backward_shape_fuzz(ops):
         tag = (case, C, fc, cc, B, H, W, pad)
         ok = (_grad_close(gr["x0"], dx0) and _grad_close(gr["w1"], grads["w1.weight"][:, :, 0, 0]) and _grad_close(gr["b1"], grads["w1.bias"])
               and _grad_close(gr["w2"], grads["w2.weight"][:, :, 0, 0]) and _grad_close(gr["b2"], grads["w2.bias"]))
-        if not ok and rel_err(states[-1].cpu(), xT) < 1e-5 and _dynca_gate_ambiguous(x0, cond, list(us), prm, pad):
-            ambiguous += 1      # a ReLU gate within rounding of zero: the two sides may legitimately differ (see the helper)
-            continue
-        assert ok, tag
-    assert 4 * ambiguous <= ncases, (ambiguous, ncases)
+        if not ok:
+            # Not skipped: a case that misses the max-norm bound must (i) agree in the forward, (ii) have a hidden
+            # pre-activation of an updated cell within rounding of zero in the ORACLE's own trajectory (the gate may then
+            # legitimately resolve differently: see the helper), and (iii) still meet the large-problem bound (relative L2 1e-3,
+            # largest single deviation 5e-2) on every gradient -- a wrong slice offset or tile mapping fails that by orders of magnitude
+            assert rel_err(states[-1].cpu(), xT) < 1e-5 and _dynca_gate_ambiguous(x0, cond, list(us), prm, pad), tag
+            for got, ref in ((gr["x0"], dx0), (gr["w1"], grads["w1.weight"][:, :, 0, 0]), (gr["b1"], grads["w1.bias"]),
+                             (gr["w2"], grads["w2.weight"][:, :, 0, 0]), (gr["b2"], grads["w2.bias"])):
+                assert grad_close(got, ref), tag
+            ambiguous += 1
+    assert 7 * ambiguous <= ncases, (ambiguous, ncases)      # five seeds x 64 cases in round 2 showed at most 1 in 16
 
 
 def test_dynca_step_shape_fuzz(ops):

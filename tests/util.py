@@ -39,3 +39,17 @@ def grad_close(got: torch.Tensor, ref: torch.Tensor, l2: float = 1e-3, cap: floa
     got, ref = got.detach().double().cpu().reshape(-1), ref.detach().double().cpu().reshape(-1)
     d = got - ref
     return float(d.norm() / ref.norm().clamp_min(1e-12)) < l2 and float(d.abs().max() / ref.abs().max().clamp_min(1e-12)) < cap
+
+
+# relative margin below which a ReLU gate may resolve differently under two fp32 summation orders: 16 ulp of the term-magnitude
+# bound (a 49..97-term fp32 dot product differs between orders by a few ulp of that bound)
+GATE_K = 1e-6
+
+
+def grads_match_outside(got: torch.Tensor, ref: torch.Tensor, region: torch.Tensor, tol: float = 2e-4):
+    """Proof hook for per-cell gradients [.., H, W]: every element OUTSIDE `region` (the influence region of the oracle's
+    near-zero ReLU gates, nca_oracle.cond_gate_influence) meets the max-norm bound `tol`; returns (ok, n_outside_fail, n_inside_fail)."""
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    bad = (got - ref).abs() > tol * max(float(ref.abs().max()), 1e-6)
+    reg = region.expand_as(bad)
+    return int((bad & ~reg).sum()) == 0, int((bad & ~reg).sum()), int((bad & reg).sum())

@@ -80,7 +80,7 @@ class NCATrainer:
         colour = x[:, :3]
         if not self.rgb:                                   # RGBA target: composite over white
             colour = 1.0 - self.to_alpha(x) + colour
-        return _unit_clamp(colour).detach().cpu().numpy()
+        return _unit_clamp(colour.float()).detach().cpu().numpy()      # (a bf16 pool: numpy has no bfloat16)
 
     # ---- default behaviour of the remaining hooks ------------------------------------------------------------------------
     def damage(self, batch):
