@@ -376,10 +376,11 @@ def main():
                                    "alive_fraction_at_end": float(ops.cond_alive(ops.cond_grow(xs, T, gd, None, w, ALIVE_CH, seed=42)[0], ALIVE_CH).float().mean())}
 
             # ---- the drop-in classes' DEFAULT mask source (mask_rng='torch': one torch.rand_like per step, the reference's RNG
-            # contract, nca.py:172) -- T extra launches and a [T,B,1,H,W] fp32 tensor per grow; informational
-            ms_t = event_ms(lambda: ops.cond_grow(xd, T, gd, torch.stack([torch.rand_like(xd[:, 0:1]) for _ in range(T)]), w, ALIVE_CH), 5) / T
+            # contract, nca.py:172) -- T extra launches per grow, kept as [T, B*H*W/32] words; informational
+            ms_t = event_ms(lambda: ops.cond_grow(xd, T, gd, ops.draw_fire_masks(B, H, W, T, 0.5, "cond", dev), w, ALIVE_CH), 5) / T
             result["mask_rng_torch"] = {"value": cells / (ms_t * 1e-3), "unit": "cell-updates/s", "launch_ms": ms_t,
-                                        "note": "explicit uniforms drawn with torch.rand_like per step (drop-in default)"}
+                                        "note": "the drop-in classes' default mask source: one torch uniform draw per step (the reference's "
+                                                "generator calls, nca.py:172), evaluated to bit-packed fire masks (ncahip_pack_fire_mask_u32)"}
             # ---- the recompute-based backward of the same loop at the same shape (ncahip_cond_grow_bwd_f32 / _bf16: 16 steps with
             # history, cotangent of the final state; fp32 history with exact-f32 products, bf16 history with bf16-MFMA products):
             # informational -- the kernels the `train` leg spends its time in, without the trainer around them

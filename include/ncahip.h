@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NCAHIP_VERSION 200 /* major*10000 + minor*100 + patch : 0.2.0 */
+#define NCAHIP_VERSION 300 /* major*10000 + minor*100 + patch : 0.3.0 */
 
 /* argument errors */
 #define NCAHIP_EINVAL (-1)   /* null pointer / non-positive size / bad enum            */
@@ -374,6 +374,20 @@ int ncahip_cond_grow_bwd_bf16(const uint16_t *states, const uint8_t *pre, int T,
                               const float *g_final, float *g_x0, float *g_goal,
                               float *g_wp, float *g_w1, float *g_b1, float *g_w2, float *g_b2, float *g_w3,
                               void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
+
+/* ---- fire masks as bits --------------------------------------------------------------------------------------------
+ * Every entry point above that takes `u` (the per-step uniform draws of nca.py:172 / dynca.py:131) also accepts the fire
+ * masks ALREADY EVALUATED and bit-packed: pass a non-NULL `u` that points at uint32_t words together with
+ * seed == NCAHIP_SEED_U_IS_BITS (seed is otherwise unused when u != NULL).  Layout: per step ceil(B*H*W / 32) words, cell
+ * i = (b*H + y)*W + x  <->  bit (i & 31) of word (i >> 5); the multi-step drivers advance by that many words per step.  A
+ * set bit = the cell updates (ConditionedNCA: clamp(u,0,1) < fire_rate; DyNCA: floor(u + update_rate) = 1, which needs
+ * 0 <= update_rate < 1).  32x smaller than the float draws: what the drop-in classes keep for the backward pass (BASELINE
+ * configs[2]: 805 MB of uniforms -> 25 MB).  Needs B*H*W < 2^32.  ncahip_pack_fire_mask_u32 evaluates T steps of float
+ * draws u [T][B*H*W] into bits [T][ceil(B*H*W/32)] with exactly the kernels' predicates: mode 0 = ConditionedNCA
+ * (nca.py:171-174), mode 1 = DyNCA (dynca.py:131). */
+#define NCAHIP_SEED_U_IS_BITS 0x5354494255ull
+int ncahip_pack_fire_mask_u32(const float *u, uint32_t *bits, int T, int B, int H, int W, float rate, int mode,
+                              ncahip_stream_t stream);
 
 /* The [B,1,H,W] uniforms the kernels draw for (seed, step) when u == NULL (for tests/tools). */
 int ncahip_philox_uniform_f32(float *u, int B, int H, int W, uint64_t seed, uint64_t step,

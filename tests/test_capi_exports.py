@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol():
         assert name in _capi.SIGNATURES, f"{name} missing from the ctypes table"
         assert len(_capi.SIGNATURES[name]) == nargs, (name, len(_capi.SIGNATURES[name]), nargs)
     assert set(_capi.SIGNATURES) == set(protos)
-    assert _capi.version() == 200
+    assert _capi.version() == 300
     assert _capi.limits()[0] >= 16
 
 

@@ -102,13 +102,13 @@ def test_dynca_module_matches_golden():
             for k in ("w1.weight", "w1.bias", "w2.weight", "w2.bias"):
                 dict(d.named_parameters())[k].copy_(T(g[f"{t}.{k}"]))
         us = [u for u in T(g[f"{t}.us"], DEV)]
-        d._draw = lambda x, steps, it=iter(us): torch.stack([next(it) for _ in range(steps)])
+        d._draw = lambda x, steps, rate=None, it=iter(us): torch.stack([next(it) for _ in range(steps)])
         cimg = T(g[f"{t}.cond_img"], DEV) if f"{t}.cond_img" in g else None
         with torch.no_grad():
             x, rgb = d(T(g[f"{t}.x0"], DEV), update_rate=0.5, cond_img=cimg)
             assert rel_err(x, T(g[f"{t}.state_first"])) < REL_TOL, c
             assert torch.equal(rgb, 2 * x[:, :3])
-            d._draw = lambda x, steps, it=iter(us): torch.stack([next(it) for _ in range(steps)])
+            d._draw = lambda x, steps, rate=None, it=iter(us): torch.stack([next(it) for _ in range(steps)])
             xT, rgbT, mids = d.forward_nsteps(T(g[f"{t}.x0"], DEV), c["T"], cond_img=cimg, return_middle_feature=True)
             assert rel_err(xT, T(g[f"{t}.state_last"])) < REL_TOL, c
             assert len(mids) == c["T"] and torch.equal(mids[-1], rgbT)
@@ -123,7 +123,7 @@ def test_dynca_extra_channels_module():
         for k in ("w1.weight", "w1.bias", "w2.weight", "w2.bias"):
             dict(d.named_parameters())[k].copy_(T(g[k]))
     us = [u for u in T(g["us"], DEV)]
-    d._draw = lambda x, steps, it=iter(us): torch.stack([next(it) for _ in range(steps)])
+    d._draw = lambda x, steps, rate=None, it=iter(us): torch.stack([next(it) for _ in range(steps)])
     with torch.no_grad():
         xT, _ = d.forward_nsteps(T(g["x0"], DEV), 5)
     assert rel_err(xT, T(g["states"])[-1]) < REL_TOL
@@ -247,7 +247,7 @@ def test_dynca_autograd_through_module():
     for u in us:
         x = O.dynca_step(x, cond, u, p, "circular", 0.5); xs.append(x)
     ((O.dynca_to_rgb(xs[-1], 3) * c1).sum() + (O.dynca_to_rgb(xs[0], 3) * c2).sum()).backward()
-    d._draw = lambda x, steps, it=iter(us): torch.stack([next(it).to(x.device) for _ in range(steps)])
+    d._draw = lambda x, steps, rate=None, it=iter(us): torch.stack([next(it).to(x.device) for _ in range(steps)])
     xd = x0.to(DEV).requires_grad_(True)
     out, rgb, mids = d.forward_nsteps(xd, 3, cond_img=cimg.to(DEV), return_middle_feature=True)
     ((rgb * c1.to(DEV)).sum() + (mids[0] * c2.to(DEV)).sum()).backward()
@@ -513,7 +513,7 @@ def test_two_scale_fused_step_golden_g10():
     m = webgl.load_dynca({"layers": layers, "n_perception_scales": 2}, padding_mode="circular", device=DEV)
     assert list(m.perception_scales) == [0, 1] and m.conditioning == "pos_emb"
     it = iter(us)
-    m._draw = lambda x, steps: torch.stack([next(it) for _ in range(steps)])
+    m._draw = lambda x, steps, rate=None: torch.stack([next(it) for _ in range(steps)])
     with torch.no_grad():
         assert m._two_scale_fused(x0) and not m._composed(x0)
         xT, rgb, mids = m.forward_nsteps(x0, 24, return_middle_feature=True)
@@ -615,7 +615,7 @@ def test_two_scale_backward_vs_oracle_autograd(C, fc, cond, pad, shape):
     cnd = O.edge_extractor(cimg, "tanh") if cond == "edges" else O.cpe2d(B, H, W)
     xT, gx, gw = O.dynca_nsteps_loss_grads(x0, cnd, us, prm, pad, 0.5, cot, scales=(0, 1))
     it = iter(us)
-    m._draw = lambda x, steps: torch.stack([next(it).to(DEV) for _ in range(steps)])
+    m._draw = lambda x, steps, rate=None: torch.stack([next(it).to(DEV) for _ in range(steps)])
     xd = x0.to(DEV).requires_grad_(True)
     assert m._two_scale_fused(xd) and not m._composed(xd)
     out, rgb = m.forward_nsteps(xd, 3, cond_img=cimg.to(DEV) if cond == "edges" else None)

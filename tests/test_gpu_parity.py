@@ -844,3 +844,90 @@ def test_device_error_word_plumbing(ops):
     ops.check_errors()
     out, _, _ = ops.cond_grow(x, 2, None, None, w, 3)
     assert bool(torch.isfinite(out).all())
+
+
+# ------------------------------------------------------------------ fire masks as bits (include/ncahip.h: NCAHIP_SEED_U_IS_BITS)
+def test_pack_fire_mask_matches_the_step_predicates(ops):
+    """ncahip_pack_fire_mask_u32 evaluates exactly nca.py:171-174 / dynca.py:131 (odd cell counts: partial last word, rates at
+    and beyond the interval ends) and unpack_fire_mask inverts it."""
+    gen = torch.Generator().manual_seed(5)
+    for (Tn, B, H, W) in ((3, 2, 7, 9), (1, 1, 1, 1), (2, 3, 16, 32), (1, 1, 5, 13)):
+        u = torch.rand(Tn, B, 1, H, W, generator=gen)
+        u[0, 0, 0, 0, 0] = 0.0
+        u.view(-1)[-1] = 0.99999994
+        for mode, rates in (("cond", (0.5, 0.0, 1.0, 0.25, 1.5, -0.5)), ("dynca", (0.5, 0.0, 0.25, 0.9))):
+            for rate in rates:
+                ref = (u.clamp(0, 1) < rate).float() if mode == "cond" else (u + rate).floor()
+                bits = ops.pack_fire_mask(u.to(DEV), rate, mode)
+                assert bits.shape == (Tn, (B * H * W + 31) // 32)
+                assert torch.equal(ops.unpack_fire_mask(bits, B, H, W).cpu(), ref), (mode, rate, Tn, B, H, W)
+                pad_bits = B * H * W % 32          # bits past the last cell are zero
+                if pad_bits:
+                    assert int((bits[:, -1].cpu().to(torch.int64) & 0xFFFFFFFF).max()) < (1 << pad_bits)
+
+
+def test_draw_fire_masks_follows_the_rand_like_stream(ops):
+    """The drop-in classes' mask source: per step ONE [B,1,H,W] float32 draw from the device's global generator, exactly the
+    reference's call (nca.py:172), evaluated to bits.  Same values and same generator position as T rand_like calls."""
+    x = torch.zeros(3, 16, 20, 28, device=DEV)
+    for steps in (1, 5, 37):
+        torch.manual_seed(1234)
+        ref = torch.stack([torch.rand_like(x[:, 0:1]) for _ in range(steps)])
+        st_ref = torch.cuda.get_rng_state()
+        torch.manual_seed(1234)
+        bits = ops.draw_fire_masks(3, 20, 28, steps, 0.5, "cond", x.device)
+        assert torch.equal(torch.cuda.get_rng_state(), st_ref)
+        assert torch.equal(ops.unpack_fire_mask(bits, 3, 20, 28), (ref.clamp(0, 1) < 0.5).float())
+        torch.manual_seed(1234)
+        ref2 = torch.stack([torch.rand(3, 1, 20, 28, device=DEV) for _ in range(steps)])      # dynca.py:131's call
+        assert torch.equal(ref2, ref)
+
+
+@pytest.mark.parametrize("C,shape,dt", [(16, (2, 32, 48), torch.float32), (12, (1, 19, 36), torch.float32), (16, (2, 16, 64), torch.bfloat16),
+                                        (20, (1, 24, 40), torch.float32)])
+def test_cond_grow_with_bit_masks_equals_float_uniforms(ops, C, shape, dt):
+    """Forward and backward of the grow loop: bit-packed masks in place of the float draws give bit-identical results, every
+    kernel family (tile kernels, generic kernels, the backward's front kernel)."""
+    B, H, W = shape
+    if dt == torch.bfloat16 and getattr(ops, "_test_mode", 0) & 1:
+        pytest.skip("bf16 storage: tile kernels only")
+    gen = torch.Generator().manual_seed(C + W)
+    prm = rand_cond_prm(C, seed=C, out_scale=1.5)
+    x0 = torch.rand(B, C, H, W, generator=gen).to(DEV, dt)
+    goal = torch.randn(B, C - 4, H, W, generator=gen).to(DEV, dt)
+    Tn = 3
+    us = torch.rand(Tn, B, 1, H, W, generator=gen).to(DEV)
+    cot = torch.randn(B, C, H, W, generator=gen).to(DEV)
+    w = cond_w(ops, prm, x0)
+    for rate in (0.5, 0.2):
+        bits = ops.pack_fire_mask(us, rate, "cond")
+        o1, s1, p1 = ops.cond_grow(x0, Tn, goal, us, w, 3, fire_rate=rate, keep_history=True)
+        o2, s2, p2 = ops.cond_grow(x0, Tn, goal, bits, w, 3, fire_rate=rate, keep_history=True)
+        assert torch.equal(o1, o2) and torch.equal(s1, s2) and torch.equal(p1[1:], p2[1:])      # (pre[0] is never written: the input is a true state)
+        if W % 4 == 0:
+            g1 = ops.cond_grow_backward(s1, p1, goal, us, w, cot, Tn, 3, fire_rate=rate)
+            g2 = ops.cond_grow_backward(s2, p2, goal, bits, w, cot, Tn, 3, fire_rate=rate)
+            for k in g1:
+                assert torch.equal(g1[k], g2[k]), k
+
+
+@pytest.mark.parametrize("C,fc,shape,two", [(12, 96, (2, 20, 28), False), (16, 128, (1, 16, 32), True), (32, 256, (1, 9, 13), False)])
+def test_dynca_nsteps_with_bit_masks_equals_float_uniforms(ops, C, fc, shape, two):
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(C + H)
+    prm = rand_dynca_prm(C, fc, 3, seed=C, scale=2.0)
+    x0 = (torch.rand(B, C, H, W, generator=gen) - 0.5).to(DEV)
+    cond = torch.rand(B, 3, H, W, generator=gen).to(DEV)
+    Tn = 3
+    us = torch.rand(Tn, B, 1, H, W, generator=gen).to(DEV)
+    cot = torch.randn(B, C, H, W, generator=gen).to(DEV)
+    w = dyn_w(ops, prm, x0)
+    for rate in (0.5, 0.3):
+        bits = ops.pack_fire_mask(us, rate, "dynca")
+        o1, s1 = ops.dynca_nsteps(x0, Tn, cond, us, w, "circular", rate, keep_history=True, two_scale=two)
+        o2, s2 = ops.dynca_nsteps(x0, Tn, cond, bits, w, "circular", rate, keep_history=True, two_scale=two)
+        assert torch.equal(s1, s2)
+        g1 = ops.dynca_nsteps_backward(s1, cond, us, w, cot, None, Tn, "circular", rate, two_scale=two)
+        g2 = ops.dynca_nsteps_backward(s2, cond, bits, w, cot, None, Tn, "circular", rate, two_scale=two)
+        for k in g1:
+            assert torch.equal(g1[k], g2[k]), k

@@ -27,6 +27,20 @@ int hip_result(hipError_t e, const char* what) {
     return (int)e;
 }
 
+// `u` holds bit-packed fire masks instead of uniforms (include/ncahip.h: NCAHIP_SEED_U_IS_BITS)
+bool u_is_bits(const void* u, uint64_t seed) { return u != nullptr && seed == NCAHIP_SEED_U_IS_BITS; }
+// u of step t: floats are [T][B*H*W]; bits are [T][ceil(B*H*W / 32)] words
+const float* u_at(const float* u, bool bits, int t, size_t cells) {
+    if (!u) return nullptr;
+    return bits ? reinterpret_cast<const float*>(reinterpret_cast<const uint32_t*>(u) + (size_t)t * ((cells + 31) / 32)) : u + (size_t)t * cells;
+}
+int check_bits(bool bits, int B, int H, int W, float rate, bool dynca) {
+    if (!bits) return 0;
+    if ((size_t)B * H * W >= (((size_t)1 << 32) - 64)) return fail(NCAHIP_ERANGE, "bit-packed fire masks: B*H*W must stay below 2^32");
+    if (dynca && !(rate >= 0.0f && rate < 1.0f)) return fail(NCAHIP_ERANGE, "bit-packed fire masks (DyNCA): 0 <= update_rate < 1 required (floor(u + rate) must be 0 or 1)");
+    return 0;
+}
+
 bool dims_ok(int B, int C, int H, int W) {
     return B > 0 && C > 0 && H > 0 && W > 0 && (size_t)B * C * H * W < ((size_t)1 << 40);
 }
@@ -183,7 +197,9 @@ int ncahip_dynca_step_fwd_f32(const float* x_in, float* x_out, const float* cond
                               int c_cond, int pad_mode, float update_rate, uint64_t seed, uint64_t step,
                               ncahip_stream_t stream) {
     if (int rc = check_dynca(x_in, x_out, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, kMaxFcFwd)) return rc;
+    if (int rc = check_bits(u_is_bits(u, seed), B, H, W, update_rate, true)) return rc;
     NcaDyncaArgs a{x_in, x_out, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step};
+    a.u_bits = u_is_bits(u, seed);
     return hip_result(nca_launch_dynca_step_fwd(a, (hipStream_t)stream), "dynca_step_fwd");
 }
 
@@ -193,11 +209,14 @@ int ncahip_dynca_nsteps_fwd_f32(float* states, int ring, int T, const float* con
                                 ncahip_stream_t stream) {
     if (ring < 2 || T < 0) return fail(NCAHIP_EINVAL, "dynca nsteps: ring >= 2 and T >= 0 required");
     if (int rc = check_dynca(states, states + 1, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, kMaxFcFwd)) return rc;
+    const bool ubits = u_is_bits(u, seed);
+    if (int rc = check_bits(ubits, B, H, W, update_rate, true)) return rc;
     const size_t slot = (size_t)B * C * H * W, uslot = (size_t)B * H * W;
     for (int t = 0; t < T; ++t) {
         NcaDyncaArgs a{states + (size_t)(t % ring) * slot, states + (size_t)((t + 1) % ring) * slot, cond,
-                       u ? u + (size_t)t * uslot : nullptr, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode,
+                       u_at(u, ubits, t, uslot), w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode,
                        update_rate, seed, step0 + (uint64_t)t};
+        a.u_bits = ubits;
         if (int rc = hip_result(nca_launch_dynca_step_fwd(a, (hipStream_t)stream), "dynca_nsteps_fwd")) return rc;
     }
     return 0;
@@ -234,8 +253,10 @@ int ncahip_dynca_step_fwd_ms_f32(const float* x_in, float* x_out, const float* c
     if (int rc = check_ms(C, H, W, fc, pc_scratch)) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (int rc = hip_result(nca_launch_dynca_coarse_perceive(x_in, pc_scratch, B, C, H, W, pad_mode, st), "dynca coarse perceive")) return rc;
+    if (int rc = check_bits(u_is_bits(u, seed), B, H, W, update_rate, true)) return rc;
     NcaDyncaArgs a{x_in, x_out, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step};
     a.pc = pc_scratch;
+    a.u_bits = u_is_bits(u, seed);
     return hip_result(nca_launch_dynca_step_fwd(a, st), "dynca_step_fwd_ms");
 }
 
@@ -247,13 +268,16 @@ int ncahip_dynca_nsteps_fwd_ms_f32(float* states, int ring, int T, const float* 
     if (int rc = check_dynca(states, states + 1, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
     if (int rc = check_ms(C, H, W, fc, pc_scratch)) return rc;
     hipStream_t st = (hipStream_t)stream;
+    const bool ubits = u_is_bits(u, seed);
+    if (int rc = check_bits(ubits, B, H, W, update_rate, true)) return rc;
     const size_t slot = (size_t)B * C * H * W, uslot = (size_t)B * H * W;
     for (int t = 0; t < T; ++t) {
         const float* const xi = states + (size_t)(t % ring) * slot;
         if (int rc = hip_result(nca_launch_dynca_coarse_perceive(xi, pc_scratch, B, C, H, W, pad_mode, st), "dynca coarse perceive")) return rc;
-        NcaDyncaArgs a{xi, states + (size_t)((t + 1) % ring) * slot, cond, u ? u + (size_t)t * uslot : nullptr, w1, b1, w2, b2, B, C, H,
+        NcaDyncaArgs a{xi, states + (size_t)((t + 1) % ring) * slot, cond, u_at(u, ubits, t, uslot), w1, b1, w2, b2, B, C, H,
                        W, fc, c_cond, pad_mode, update_rate, seed, step0 + (uint64_t)t};
         a.pc = pc_scratch;
+        a.u_bits = ubits;
         if (int rc = hip_result(nca_launch_dynca_step_fwd(a, st), "dynca_nsteps_fwd_ms")) return rc;
     }
     return 0;
@@ -269,6 +293,8 @@ int ncahip_cond_step_fwd_f32(const float* x_in, const uint8_t* pre_in, float* x_
     if (pre_in && pre_in == pre_out) return fail(NCAHIP_EINVAL, "cond step: pre_in and pre_out must not alias");
     NcaCondArgs a{x_in, pre_in, x_out, pre_out, goal, u, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch,
                   alive_ch, alive_thr, fire_rate, clamp_lo, clamp_hi, seed, step};
+    if (int rc = check_bits(u_is_bits(u, seed), B, H, W, fire_rate, false)) return rc;
+    a.u_bits = u_is_bits(u, seed);
     return hip_result(nca_launch_cond_step_fwd(a, (hipStream_t)stream), "cond_step_fwd");
 }
 
@@ -301,6 +327,8 @@ int ncahip_cond_step_fwd_bf16(const uint16_t* x_in, const uint8_t* pre_in, uint1
     NcaCondArgs a{reinterpret_cast<const float*>(x_in), pre_in, reinterpret_cast<float*>(x_out), pre_out,
                   reinterpret_cast<const float*>(goal), u, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch,
                   alive_ch, alive_thr, fire_rate, clamp_lo, clamp_hi, seed, step};
+    if (int rc = check_bits(u_is_bits(u, seed), B, H, W, fire_rate, false)) return rc;
+    a.u_bits = u_is_bits(u, seed);
     return hip_result(nca_launch_cond_step_fwd_bf16(a, (hipStream_t)stream), "cond_step_fwd_bf16");
 }
 
@@ -323,6 +351,8 @@ int ncahip_cond_grow_fwd_bf16(uint16_t* states, uint8_t* pre, int ring, int T, u
         return rc;
     if (int rc = check_bf16_shape(states, states, goal, H, W)) return rc;
     if (int rc = device_error_rc("cond grow (bf16)")) return rc;
+    const bool ubits = u_is_bits(u, seed);
+    if (int rc = check_bits(ubits, B, H, W, fire_rate, false)) return rc;
     const size_t slot = (size_t)B * C * H * W, pslot = (size_t)B * H * W;
     if ((slot * sizeof(uint16_t)) % 8 != 0) return fail(NCAHIP_ERANGE, "bf16 cond grow: state slots must stay 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -333,8 +363,9 @@ int ncahip_cond_grow_fwd_bf16(uint16_t* states, uint8_t* pre, int ring, int T, u
         const int si = t % ring, so = (t + 1) % ring;
         NcaCondArgs a{reinterpret_cast<const float*>(states + (size_t)si * slot), t == 0 ? nullptr : pre + (size_t)si * pslot,
                       reinterpret_cast<float*>(states + (size_t)so * slot), pre + (size_t)so * pslot,
-                      reinterpret_cast<const float*>(goal), u ? u + (size_t)t * pslot : nullptr, wp, w1, b1, w2, b2, w3, B, C, H,
+                      reinterpret_cast<const float*>(goal), u_at(u, ubits, t, pslot), wp, w1, b1, w2, b2, w3, B, C, H,
                       W, hidden, goal_ch, alive_ch, alive_thr, fire_rate, clamp_lo, clamp_hi, seed, step0 + (uint64_t)t};
+        a.u_bits = ubits;
         if (int rc = hip_result(nca_launch_cond_step_fwd_bf16(a, st), "cond_grow_fwd_bf16")) return rc;
     }
     return hip_result(nca_launch_cond_finalize_bf16(states + (size_t)sl * slot, pre + (size_t)sl * pslot, x_final, B, C, H, W,
@@ -357,6 +388,8 @@ int ncahip_cond_grow_fwd_f32(float* states, uint8_t* pre, int ring, int T, float
     if (int rc = check_cond(states, states + 1, pre, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch, kMaxCCondFwd))
         return rc;
     if (int rc = device_error_rc("cond grow")) return rc;
+    const bool ubits = u_is_bits(u, seed);
+    if (int rc = check_bits(ubits, B, H, W, fire_rate, false)) return rc;
     const size_t slot = (size_t)B * C * H * W, pslot = (size_t)B * H * W;
     hipStream_t st = (hipStream_t)stream;
     const int sl = T % ring;
@@ -366,8 +399,9 @@ int ncahip_cond_grow_fwd_f32(float* states, uint8_t* pre, int ring, int T, float
         const int si = t % ring, so = (t + 1) % ring;
         NcaCondArgs a{states + (size_t)si * slot, t == 0 ? nullptr : pre + (size_t)si * pslot,
                       states + (size_t)so * slot, pre + (size_t)so * pslot, goal,
-                      u ? u + (size_t)t * pslot : nullptr, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch,
+                      u_at(u, ubits, t, pslot), wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch,
                       alive_ch, alive_thr, fire_rate, clamp_lo, clamp_hi, seed, step0 + (uint64_t)t};
+        a.u_bits = ubits;
         if (int rc = hip_result(nca_launch_cond_step_fwd(a, st), "cond_grow_fwd")) return rc;
     }
     return hip_result(nca_launch_cond_finalize(states + (size_t)sl * slot, pre + (size_t)sl * pslot, x_final, B, C, H, W,
@@ -382,6 +416,8 @@ int ncahip_dynca_step_fwd_bf16(const uint16_t* x_in, uint16_t* x_out, const floa
     if (int rc = check_dynca(x_in, x_out, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
     NcaDyncaArgs a{reinterpret_cast<const float*>(x_in), reinterpret_cast<float*>(x_out), cond, u, w1, b1, w2, b2, B, C, H, W,
                    fc, c_cond, pad_mode, update_rate, seed, step};
+    if (int rc = check_bits(u_is_bits(u, seed), B, H, W, update_rate, true)) return rc;
+    a.u_bits = u_is_bits(u, seed);
     return hip_result(nca_launch_dynca_step_fwd_bf16(a, (hipStream_t)stream), "dynca_step_fwd_bf16");
 }
 
@@ -391,12 +427,15 @@ int ncahip_dynca_nsteps_fwd_bf16(uint16_t* states, int ring, int T, const float*
                                  ncahip_stream_t stream) {
     if (ring < 2 || T < 0) return fail(NCAHIP_EINVAL, "dynca nsteps: ring >= 2 and T >= 0 required");
     if (int rc = check_dynca(states, states + 1, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
+    const bool ubits = u_is_bits(u, seed);
+    if (int rc = check_bits(ubits, B, H, W, update_rate, true)) return rc;
     const size_t slot = (size_t)B * C * H * W, uslot = (size_t)B * H * W;
     for (int t = 0; t < T; ++t) {
         NcaDyncaArgs a{reinterpret_cast<const float*>(states + (size_t)(t % ring) * slot),
                        reinterpret_cast<float*>(states + (size_t)((t + 1) % ring) * slot), cond,
-                       u ? u + (size_t)t * uslot : nullptr, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode,
+                       u_at(u, ubits, t, uslot), w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode,
                        update_rate, seed, step0 + (uint64_t)t};
+        a.u_bits = ubits;
         if (int rc = hip_result(nca_launch_dynca_step_fwd_bf16(a, (hipStream_t)stream), "dynca_nsteps_fwd_bf16")) return rc;
     }
     return 0;
@@ -413,6 +452,8 @@ int ncahip_dynca_step_bwd_f32(const float* x_t, const float* cond, const float* 
         return fail(NCAHIP_ERANGE, "dynca step bwd: fc*H*W*4 must stay below 4 GiB (32-bit store offsets inside a batch item)");
     NcaDyncaArgs a{x_t, nullptr, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step,
                    g_next, h_out, dh_out, dy_scratch, g_x};
+    if (int rc = check_bits(u_is_bits(u, seed), B, H, W, update_rate, true)) return rc;
+    a.u_bits = u_is_bits(u, seed);
     return hip_result(nca_launch_dynca_step_bwd(a, (hipStream_t)stream), "dynca_step_bwd");
 }
 
@@ -436,6 +477,8 @@ int ncahip_dynca_step_bwd_w2_f32(const float* x_t, const float* cond, const floa
     NcaDyncaArgs a{x_t, nullptr, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step,
                    g_next, nullptr, dh_out, dy_scratch, g_x};
     a.gw2_ws = (float*)workspace;
+    if (int rc = check_bits(u_is_bits(u, seed), B, H, W, update_rate, true)) return rc;
+    a.u_bits = u_is_bits(u, seed);
     if (int rc = hip_result(nca_launch_dynca_step_bwd(a, (hipStream_t)stream), "dynca_step_bwd_w2")) return rc;
     return hip_result(nca_launch_reduce_rows((const float*)workspace, gw2_out, nca_dynca_bwd_grid_c(B, C, H, W), C * fc + C,
                                              (hipStream_t)stream, accumulate != 0), "dynca_step_bwd_w2 reduce");
@@ -504,6 +547,8 @@ static int dynca_nsteps_bwd_impl(bool two_scale, const void* states_v, int sb, i
     if (two_scale) {
         if (int rc = check_ms(C, H, W, fc, workspace)) return rc;
     }
+    const bool ubits = u_is_bits(u, seed);
+    if (int rc = check_bits(ubits, B, H, W, update_rate, true)) return rc;
     const DyncaBwdPlan p = dynca_bwd_plan(B, C, H, W, fc, c_cond, two_scale, bf16);
     if (workspace_bytes < p.total) return fail(NCAHIP_EINVAL, "dynca nsteps bwd: workspace too small");
     if (((uintptr_t)workspace & 15) != 0) return fail(NCAHIP_ERANGE, "dynca nsteps bwd: workspace must be 16-byte aligned");
@@ -540,9 +585,10 @@ static int dynca_nsteps_bwd_impl(bool two_scale, const void* states_v, int sb, i
         }
         for (int sl = 0; sl < p.nsl; ++sl) {
             const int h0 = sl * 128, fs = fc - h0 < 128 ? fc - h0 : 128;
-            NcaDyncaArgs a{x_t, nullptr, cond, u ? u + (size_t)t * uslot : nullptr, w1 + (size_t)h0 * p.K1, b1 + h0, w2 + h0, b2, B, C, H, W,
+            NcaDyncaArgs a{x_t, nullptr, cond, u_at(u, ubits, t, uslot), w1 + (size_t)h0 * p.K1, b1 + h0, w2 + h0, b2, B, C, H, W,
                            fs, c_cond, pad_mode, update_rate, seed, step0 + (uint64_t)t, gcur, nullptr, dh, dy, g_out};
             a.w2_ld = fc;
+            a.u_bits = ubits;
             a.gw2_ws = ws2;
             a.pc = pcb;
             a.ybuf = sl == 0 ? y : nullptr;
@@ -665,6 +711,8 @@ static int cond_grow_bwd_impl(const void* states_v, int sb, const uint8_t* pre, 
         return fail(NCAHIP_ERANGE, "cond grow bwd: grid too large for the tile kernels' 32-bit addressing (H*W < 2^24)");
     if (workspace_bytes < ncahip_cond_grow_bwd_workspace(B, C, H, W, hidden))
         return fail(NCAHIP_EINVAL, "cond grow bwd: workspace too small");
+    const bool ubits = u_is_bits(u, seed);
+    if (int rc = check_bits(ubits, B, H, W, fire_rate, false)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const size_t slot = (size_t)B * C * H * W, pslot = (size_t)B * H * W, nb = slot * sizeof(float);
     if (bf16 && (slot * 2) % 8 != 0) return fail(NCAHIP_ERANGE, "cond grow bwd (bf16): state slots must stay 8-byte aligned");
@@ -690,8 +738,9 @@ static int cond_grow_bwd_impl(const void* states_v, int sb, const uint8_t* pre, 
         NcaCondBwdArgs ba{};
         ba.f = NcaCondArgs{reinterpret_cast<const float*>(states + (size_t)t * slot * sb), t == 0 ? nullptr : pre + (size_t)t * pslot,
                            nullptr, nullptr, reinterpret_cast<const float*>(goal_v),
-                           u ? u + (size_t)t * pslot : nullptr, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch,
+                           u_at(u, ubits, t, pslot), wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch,
                            alive_ch, alive_thr, fire_rate, clamp_lo, clamp_hi, seed, step0 + (uint64_t)t, nullptr};
+        ba.f.u_bits = ubits;
         ba.x_next = reinterpret_cast<const float*>(states + (size_t)(t + 1) * slot * sb);
         ba.pre_t = pre + (size_t)(t + 1) * pslot;
         ba.g_next = gcur;
@@ -736,6 +785,12 @@ int ncahip_cond_grow_bwd_bf16(const uint16_t* states, const uint8_t* pre, int T,
     return cond_grow_bwd_impl(states, 2, pre, T, goal, goal_ch, u, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, alive_ch, alive_thr,
                               fire_rate, clamp_lo, clamp_hi, seed, step0, g_final, g_x0, g_goal, g_wp, g_w1, g_b1, g_w2, g_b2,
                               g_w3, workspace, workspace_bytes, stream);
+}
+
+int ncahip_pack_fire_mask_u32(const float* u, uint32_t* bits, int T, int B, int H, int W, float rate, int mode, ncahip_stream_t stream) {
+    if (!u || !bits || T <= 0 || B <= 0 || H <= 0 || W <= 0 || (mode != 0 && mode != 1)) return fail(NCAHIP_EINVAL, "pack_fire_mask: bad argument");
+    if (int rc = check_bits(true, B, H, W, rate, mode == 1)) return rc;
+    return hip_result(nca_launch_pack_fire_mask(u, bits, T, (size_t)B * H * W, rate, mode, (hipStream_t)stream), "pack_fire_mask");
 }
 
 int ncahip_philox_uniform_f32(float* u, int B, int H, int W, uint64_t seed, uint64_t step, ncahip_stream_t stream) {

@@ -316,7 +316,9 @@ __device__ __forceinline__ void issue_loads(const NcaCondArgs& a, const WTile& t
         const unsigned pix = cin ? (unsigned)(__mul24(cgy, W) + cgx) : 0u;
         // both sources are produced without touching the loaded value (a select here would wait for every load issued
         // so far); stage_tile picks one
-        R.uu = StF32::ld1<0>(nca_rsrc(a.u ? (const void*)(a.u + cell0) : (const void*)xb), a.u ? pix * 4u : 0u, 0u);
+        // explicit uniforms: the cell's float; bit-packed masks (a.u_bits): the 32-bit word that holds the cell's bit
+        R.uu = StF32::ld1<0>(nca_rsrc(a.u ? (a.u_bits ? (const void*)a.u : (const void*)(a.u + cell0)) : (const void*)xb),
+                             a.u ? (a.u_bits ? (((unsigned)cell0 + pix) >> 5) * 4u : pix * 4u) : 0u, 0u);
         R.up = a.u ? 0.0f : nca_philox_cell(a.seed, a.step, cell0 + pix);
     }
     const __amdgpu_buffer_rsrc_t rg = nca_rsrc(has_goal ? reinterpret_cast<const char*>(a.goal) + (size_t)t.b * a.goal_ch * plane * SB : xb);
@@ -450,7 +452,11 @@ __device__ __forceinline__ void stage_tile(const NcaCondArgs& a, const WTile& t,
         // produce the two values, share one register, and force a vmcnt(0) in front of the Philox rounds
         unsigned um = a.u ? 0xFFFFFFFFu : 0u;
         asm volatile("" : "+v"(um));
-        const float uf = __uint_as_float(__float_as_uint(R.up) | (__float_as_uint(R.uu) & um));
+        float uf = __uint_as_float(__float_as_uint(R.up) | (__float_as_uint(R.uu) & um));
+        if (a.u_bits) {   // the cell's bit of the loaded word: 1 -> fires (0 < rate), 0 -> never (clamp(2) = 1 < rate is false)
+            const unsigned cellg = (unsigned)((size_t)t.b * plane) + (cin ? (unsigned)(__mul24(cgy, W) + cgx) : 0u);
+            uf = ((__float_as_uint(R.uu) >> (cellg & 31u)) & 1u) ? 0.0f : 2.0f;
+        }
         MK[lane] = (cin && wclamp(uf, 0.0f, 1.0f) < a.fire_rate) ? 1.0f : 0.0f;  // nca.py:171-174
         wave_sync();
         if (cin && a.pre_out)

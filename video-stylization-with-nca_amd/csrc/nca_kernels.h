@@ -67,6 +67,7 @@ struct NcaDyncaArgs {
     int dy_half;              // backward stencil, two-scale: the fine level carries 0.5 * dL/dy
     float* ybuf;              // backward MLP kernel: if set, the recomputed perception y (two-scale: the combined one) is written here,
                               // [B,4C,H,W] in perceive_torch's row order -- the B rows of the layer-1 weight-gradient product
+    int u_bits;               // u points at bit-packed fire masks (uint32 words, cell i -> bit i & 31 of word i >> 5; B*H*W < 2^32)
 };
 
 struct NcaCondArgs {
@@ -82,6 +83,7 @@ struct NcaCondArgs {
     uint64_t seed, step;
     unsigned long long* dbg;  // diagnostic builds (-DNCA_STAMPS) only: per-wave phase time stamps
     unsigned* err;            // sticky error word (nca_error_word_device()), or null
+    int u_bits;               // u points at bit-packed fire masks (uint32 words, cell i -> bit i & 31 of word i >> 5; B*H*W < 2^32)
 };
 
 // One backward step of the ConditionedNCA grow loop (nca_cond_bwd.hip).  f describes forward step t exactly as
@@ -161,4 +163,6 @@ hipError_t nca_launch_cond_finalize(const float* x, const uint8_t* pre, float* o
 hipError_t nca_launch_cond_alive(const float* x, uint8_t* out, int B, int C, int H, int W, int alive_ch, float thr,
                                  hipStream_t st);
 hipError_t nca_launch_philox_uniform(float* u, int B, int H, int W, uint64_t seed, uint64_t step, hipStream_t st);
+// fire masks of T steps, bit-packed: mode 0 = clamp(u,0,1) < rate (nca.py:171-174), 1 = floorf(u + rate) >= 1 (dynca.py:131)
+hipError_t nca_launch_pack_fire_mask(const float* u, uint32_t* bits, int T, size_t cells, float rate, int mode, hipStream_t st);
 hipError_t nca_launch_selftest(int* result, hipStream_t st);

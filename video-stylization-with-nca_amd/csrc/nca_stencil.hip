@@ -360,6 +360,21 @@ __global__ __launch_bounds__(256) void philox_uniform_kernel(float* __restrict__
     if (id < n) u[id] = nca_philox_cell(seed, step, id);
 }
 
+// Fire masks as bits: one wave evaluates 64 cells, the ballot IS two packed words.  Step t's words start at t * ceil(cells/32).
+__global__ __launch_bounds__(256) void pack_fire_mask_kernel(const float* __restrict__ u, uint32_t* __restrict__ bits, size_t cells,
+                                                            size_t words, float rate, int mode) {
+    const size_t t = blockIdx.y, id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool fire = false;
+    if (id < cells) {
+        const float v = u[t * cells + id];
+        fire = mode == 0 ? (fminf(fmaxf(v, 0.0f), 1.0f) < rate) : (floorf(v + rate) >= 1.0f);
+    }
+    const unsigned long long m = __ballot(fire);
+    const int lane = threadIdx.x & 63;
+    const size_t w0 = id >> 5;          // lanes 0 and 32 of a wave write its two words
+    if ((lane & 31) == 0 && w0 < words) bits[t * words + w0] = (uint32_t)(lane ? (m >> 32) : m);
+}
+
 // MFMA lane-map check with exact integers and an ASYMMETRIC B: D = A*B, A[i][k] = i + 16k + 1,
 // B[k][j] = 3j + 7k + 2 (k = 0..3).  Every lane verifies its 4 accumulator values.
 __global__ void selftest_kernel(int* result) {
@@ -458,6 +473,12 @@ hipError_t nca_launch_cond_alive(const float* x, uint8_t* out, int B, int C, int
 hipError_t nca_launch_philox_uniform(float* u, int B, int H, int W, uint64_t seed, uint64_t step, hipStream_t st) {
     const size_t n = (size_t)B * H * W;
     hipLaunchKernelGGL(philox_uniform_kernel, dim3(blocks_for(n)), dim3(256), 0, st, u, n, seed, step);
+    return hipGetLastError();
+}
+
+hipError_t nca_launch_pack_fire_mask(const float* u, uint32_t* bits, int T, size_t cells, float rate, int mode, hipStream_t st) {
+    const size_t words = (cells + 31) / 32, cover = words * 32;      // every word is written: the grid covers words * 32 lanes
+    hipLaunchKernelGGL(pack_fire_mask_kernel, dim3((unsigned)((cover + 255) / 256), (unsigned)T), dim3(256), 0, st, u, bits, cells, words, rate, mode);
     return hipGetLastError();
 }
 

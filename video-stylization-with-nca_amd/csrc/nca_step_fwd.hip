@@ -333,7 +333,10 @@ __global__ __launch_bounds__(kThreads, ((BWD && CP > 16) || MS) ? 1 : 2) void dy
         const bool cin = cgy < H && cgx < W;
         const size_t cell = (size_t)b * plane + (cin ? (size_t)cgy * W + cgx : 0);
         float uu = 0.0f, cnv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (a.u) uu = a.u[cell];
+        if (a.u) {   // explicit uniforms, or bit-packed masks: bit 1 -> floor(1 + rate) = 1, bit 0 -> floor(0 + rate) = 0 (0 <= rate < 1)
+            if (a.u_bits) uu = ((reinterpret_cast<const uint32_t*>(a.u)[cell >> 5] >> (unsigned)(cell & 31)) & 1u) ? 1.0f : 0.0f;
+            else uu = a.u[cell];
+        }
         if (HAS_COND && !BWD) {
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc)
@@ -900,7 +903,10 @@ __global__ __launch_bounds__(kThreads, CP > 16 ? 1 : 2) void cond_step_fwd_kerne
         const bool cin = cgy < H && cgx < W;
         const size_t cell = (size_t)b * plane + (cin ? (size_t)cgy * W + cgx : 0);
         float uu = 0.0f;
-        if (a.u) uu = a.u[cell];
+        if (a.u) {   // explicit uniforms, or bit-packed masks: bit 1 -> clamp(0) < rate, bit 0 -> clamp(2) = 1 < rate never (rate <= 1)
+            if (a.u_bits) uu = ((reinterpret_cast<const uint32_t*>(a.u)[cell >> 5] >> (unsigned)(cell & 31)) & 1u) ? 0.0f : 2.0f;
+            else uu = a.u[cell];
+        }
         // state tile + goal encoding (halo 1): one position per thread, channels split over the two halves
         Pos ps;
         ps.template init<VEC>(st, ty0, tx0, H, W, NCA_PAD_ZERO);

@@ -45,6 +45,7 @@ SIGNATURES = {
     "ncahip_cond_grow_fwd_bf16": [_P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F,
                                   _F, _F, _F, _U64, _U64, _P],
     "ncahip_philox_uniform_f32": [_P, _I, _I, _I, _U64, _U64, _P],
+    "ncahip_pack_fire_mask_u32": [_P, _P, _I, _I, _I, _I, _F, _I, _P],
     "ncahip_dynca_step_bwd_w2_workspace": [_I, _I, _I, _I, _I],
     "ncahip_dynca_step_bwd_w2_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P, _P, _P, _P, _P, _I, _P,
                                      ctypes.c_size_t, _P],
@@ -75,6 +76,9 @@ _lib = None
 
 class NcaHipError(RuntimeError):
     pass
+
+
+SEED_U_IS_BITS = 0x5354494255     # include/ncahip.h NCAHIP_SEED_U_IS_BITS: `u` holds bit-packed fire masks
 
 
 def lib():

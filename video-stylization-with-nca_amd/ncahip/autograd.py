@@ -70,14 +70,16 @@ def _cond_grow_composed(model, x, goal, T, us):
         gpad = torch.nn.functional.pad(goal.float(), (0, 0, 0, 0, C - goal.shape[1], 0))
     alive = (lambda t: ops.cond_alive(t.detach().contiguous(), a, thr).float()) if a >= 0 else (lambda t: torch.ones_like(t[:, :1]))
     for t in range(T):
-        if us is not None:
-            u = us[t]
+        if us is not None and us.dtype == torch.int32:      # bit-packed masks (ConditionedNCA._draw on a device)
+            fire = ops.unpack_fire_mask(us[t:t + 1], x.shape[0], x.shape[2], x.shape[3])[0]
         else:
-            u = ops.philox_uniform(x.shape[0], x.shape[2], x.shape[3], model.mask_seed, model._mask_step - T + t, x.device)
+            u = us[t] if us is not None else ops.philox_uniform(x.shape[0], x.shape[2], x.shape[3], model.mask_seed,
+                                                                model._mask_step - T + t, x.device)
+            fire = (u.clamp(0.0, 1.0) < model.cell_fire_rate).float()
         pre = alive(x)
         z = x if gpad is None else x + gpad * pre
         out = model.update_net.out(_HipCondPerceive.apply(z.contiguous(), model.perception_net.weight))
-        x1 = x + (u.clamp(0.0, 1.0) < model.cell_fire_rate).float() * out
+        x1 = x + fire * out
         x = torch.clamp(x1 * (pre * alive(x1)), -10.0, 10.0)
     return x
 
@@ -137,7 +139,7 @@ def dynca_nsteps_autograd(model, x, cond, T, update_rate, want_states=False, two
     bf16 = x.dtype == torch.bfloat16      # bf16 pool: bf16-storage entry points (storage format only), forward and backward
     x = x.contiguous() if bf16 else x.float().contiguous()
     params = (model.w1.weight, model.w1.bias, model.w2.weight, model.w2.bias)
-    us = model._draw(x, T)
+    us = model._draw(x, T, update_rate)
     cfg = dict(T=T, us=us, pad=model.padding_mode, rate=float(update_rate), seed=model.mask_seed, step0=model._mask_step,
                want_states=want_states, two_scale=two_scale)
     model._mask_step += T

@@ -102,10 +102,13 @@ class DyNCA(nn.Module):
         self.mask_rng, self.mask_seed, self._mask_step = "torch", 0, 0
 
     # ------------------------------------------------------------------ helpers
-    def _draw(self, x, steps):
+    def _draw(self, x, steps, update_rate=None):
         if self.mask_rng == "philox":
             return None
         b, _, h, w = x.shape
+        if x.is_cuda and update_rate is not None and 0.0 <= float(update_rate) < 1.0:
+            # dynca.py:131's draw per step, evaluated to floor(u + rate) right away and kept as bits (ops.draw_fire_masks)
+            return ops.draw_fire_masks(b, h, w, steps, float(update_rate), "dynca", x.device)
         return torch.stack([torch.rand(b, 1, h, w, device=x.device) for _ in range(steps)])  # dynca.py:131, per step
 
     def _cond(self, x, cond_img):

@@ -73,7 +73,10 @@ class ConditionedNCA(nn.Module):
         if self.mask_rng == "philox":
             return None
         # one draw per step, as nca.py:207-208 (always float32: identical to the reference for float32 states)
-        return torch.stack([torch.rand_like(x[:, 0:1], dtype=torch.float32) for _ in range(steps)])
+        if not x.is_cuda:
+            return torch.stack([torch.rand_like(x[:, 0:1], dtype=torch.float32) for _ in range(steps)])
+        # ... evaluated to the fire mask right away and kept as BITS (what the backward re-reads: 1/32 of the float draws)
+        return ops.draw_fire_masks(x.shape[0], x.shape[2], x.shape[3], steps, self.cell_fire_rate, "cond", x.device)
 
     def _split_goal(self, goal_encoding: torch.Tensor) -> torch.Tensor:
         """The kernels take the UNPADDED encoding; nca.py:199-203 pads zeros in front -- strip them."""

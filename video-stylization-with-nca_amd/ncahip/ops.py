@@ -125,6 +125,61 @@ def edge_extractor(img: torch.Tensor, k3: torch.Tensor, apply_tanh: bool) -> tor
     return out
 
 
+# ------------------------------------------------------------------------------------ fire masks as bits
+def mask_words(B: int, H: int, W: int) -> int:
+    return (B * H * W + 31) // 32
+
+
+def pack_fire_mask(u: torch.Tensor, rate: float, mode: str, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """u [T,B,1,H,W] float32 draws -> int32 [T, ceil(B*H*W/32)] bit-packed fire masks with the kernels' own predicate
+    (mode 'cond': clamp(u,0,1) < rate, nca.py:171-174; 'dynca': floor(u + rate) = 1, dynca.py:131; include/ncahip.h)."""
+    u = _dev(u, "u")
+    T, B, _, H, W = u.shape
+    bits = torch.empty(T, mask_words(B, H, W), device=u.device, dtype=torch.int32) if out is None else out
+    assert bits.shape == (T, mask_words(B, H, W)) and bits.dtype == torch.int32 and bits.is_contiguous()
+    check(lib().ncahip_pack_fire_mask_u32(_p(u), _p(bits), T, B, H, W, float(rate), {"cond": 0, "dynca": 1}[mode], _stream()),
+          "pack_fire_mask")
+    return bits
+
+
+def draw_fire_masks(B: int, H: int, W: int, steps: int, rate: float, mode: str, device, chunk: int = 16) -> torch.Tensor:
+    """The reference's per-step uniform draws (nca.py:172 / dynca.py:131: one [B,1,H,W] float32 draw from the device's global
+    torch generator per step, nothing in between) evaluated to bit-packed fire masks int32 [steps, ceil(B*H*W/32)].  The
+    draws are the same generator calls in the same order as `torch.rand_like(x[:, 0:1])` per step -- `uniform_()` on a
+    [B,1,H,W] float32 tensor IS what rand_like runs -- made into a reused chunk buffer (no [T,B,1,H,W] tensor, no stack
+    copy) and packed by ncahip_pack_fire_mask_u32 with the kernels' own predicate."""
+    bits = torch.empty(steps, mask_words(B, H, W), device=device, dtype=torch.int32)
+    buf = torch.empty(min(chunk, steps), B, 1, H, W, device=device, dtype=torch.float32)
+    for t0 in range(0, steps, chunk):
+        k = min(chunk, steps - t0)
+        for j in range(k):
+            buf[j].uniform_()
+        pack_fire_mask(buf[:k], rate, mode, out=bits[t0:t0 + k])
+    return bits
+
+
+def unpack_fire_mask(bits: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
+    """int32 [T, words] -> float32 {0,1} masks [T,B,1,H,W] (torch ops; the composed passes and tests)."""
+    T = bits.shape[0]
+    idx = torch.arange(B * H * W, device=bits.device)
+    m = (bits[:, idx >> 5] >> (idx & 31)) & 1
+    return m.view(T, B, 1, H, W).float()
+
+
+def _u_args(us: Optional[torch.Tensor], T: int, B: int, H: int, W: int, seed: int):
+    """(tensor, seed) for the C ABI: float32 uniforms [T,B,1,H,W] as they are; int32 bit-packed masks [T, words] with the seed
+    that announces them (NCAHIP_SEED_U_IS_BITS); None: in-kernel Philox keyed by `seed`."""
+    if us is None:
+        return None, seed
+    if us.dtype == torch.int32:
+        us = _dev(us, "us", torch.int32)
+        assert us.numel() == T * mask_words(B, H, W), (tuple(us.shape), T, B, H, W)
+        return us, _capi.SEED_U_IS_BITS
+    us = _dev(us, "us")
+    assert us.numel() == T * B * H * W
+    return us, seed
+
+
 def philox_uniform(B: int, H: int, W: int, seed: int, step: int, device="cuda") -> torch.Tensor:
     u = torch.empty(B, 1, H, W, device=device, dtype=torch.float32)
     check(lib().ncahip_philox_uniform_f32(_p(u), B, H, W, seed, step, _stream()), "philox_uniform")
@@ -180,9 +235,7 @@ def dynca_nsteps(x: torch.Tensor, T: int, cond: Optional[torch.Tensor], us: Opti
     c_cond = 0 if cond is None else cond.shape[1]
     if cond is not None:
         cond = _dev(cond, "cond")
-    if us is not None:
-        us = _dev(us, "us")
-        assert us.numel() == T * B * H * W
+    us, seed = _u_args(us, T, B, H, W, seed)
     assert w.c == C and w.k1 == 4 * C + c_cond, (w.c, w.k1, C, c_cond)
     ring = T + 1 if keep_history else 2
     states = torch.empty(ring, B, C, H, W, device=x.device, dtype=dt)
@@ -278,9 +331,7 @@ def cond_grow(x: torch.Tensor, T: int, goal: Optional[torch.Tensor], us: Optiona
     if T == 0:
         return x.clone(), None, None
     goal, gch = _goal_args(goal, B, C, H, W, dt)
-    if us is not None:
-        us = _dev(us, "us")
-        assert us.numel() == T * B * H * W
+    us, seed = _u_args(us, T, B, H, W, seed)
     assert w.c == C
     ring = T + 1 if keep_history else 2
     states = torch.empty(ring, B, C, H, W, device=x.device, dtype=dt)
@@ -305,8 +356,7 @@ def cond_grow_backward(states: torch.Tensor, pre: torch.Tensor, goal: Optional[t
     assert states.shape[0] == T + 1 and pre.shape[0] == T + 1
     _, B, C, H, W = states.shape
     goal, gch = _goal_args(goal, B, C, H, W, dt)
-    if us is not None:
-        us = _dev(us, "us")
+    us, seed = _u_args(us, T, B, H, W, seed)
     dev, f32 = states.device, torch.float32
     hid = w.hidden
     g = {"x0": torch.empty(B, C, H, W, device=dev, dtype=f32),
@@ -366,8 +416,7 @@ def dynca_nsteps_backward(states: torch.Tensor, cond: Optional[torch.Tensor], us
     c_cond = 0 if cond is None else cond.shape[1]
     if cond is not None:
         cond = _dev(cond, "cond")
-    if us is not None:
-        us = _dev(us, "us")
+    us, seed = _u_args(us, T, B, H, W, seed)
     if g_states is not None:
         g_states = _dev(g_states.float(), "g_states")
         assert g_states.shape == states.shape
