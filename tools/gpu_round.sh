@@ -40,8 +40,17 @@ timeout -k 10 500 python tools/bench_paths.py > $out/${tag}_paths.jsonl 2> $out/
 cat $out/${tag}_paths.jsonl
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/${tag}_trainprof -o stats --output-format csv -- python tools/bench_paths.py cond_train > $out/${tag}_trainprof.log 2>&1 || { tail -20 $out/${tag}_trainprof.log; exit 1; }
 stats $out/${tag}_trainprof $out/${tag}_train_kernel_stats.txt 10
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/${tag}_c20prof -o stats --output-format csv -- python tools/bench_paths.py cond_c20 > $out/${tag}_c20prof.log 2>&1 || { tail -20 $out/${tag}_c20prof.log; exit 1; }
+stats $out/${tag}_c20prof $out/${tag}_c20_kernel_stats.txt 10
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/${tag}_dyprof -o stats --output-format csv -- python tools/bench_paths.py dynca_train > $out/${tag}_dyprof.log 2>&1 || { tail -20 $out/${tag}_dyprof.log; exit 1; }
 stats $out/${tag}_dyprof $out/${tag}_dynca_train_kernel_stats.txt 14
+# HBM traffic of the backward kernels (separate FETCH / WRITE passes per leg) -> <tag>_bwd_hbm.json / <tag>_dynca_bwd_hbm.json
+for leg in cond_train dynca_train; do
+  name=bwd_hbm; [ $leg = dynca_train ] && name=dynca_bwd_hbm
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $out/${tag}_pmc_${leg}/f -o f --output-format csv -- python tools/bench_paths.py $leg > $out/${tag}_pmc_${leg}_f.log 2>&1 || { tail -20 $out/${tag}_pmc_${leg}_f.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $out/${tag}_pmc_${leg}/w -o w --output-format csv -- python tools/bench_paths.py $leg > $out/${tag}_pmc_${leg}_w.log 2>&1 || { tail -20 $out/${tag}_pmc_${leg}_w.log; exit 1; }
+  python tools/collect_traffic.py $out/${tag}_pmc_${leg} $out/${tag}_${name}.json > /dev/null
+done
 if [ -f video-stylization-with-nca_amd/libncahip_stamps.so ]; then   # diagnostic build (make stamps): cycles per phase of backward kernel A
   timeout -k 10 200 python tools/stamp_bwd.py > $out/${tag}_bwd_phases.txt 2>&1 || { tail -20 $out/${tag}_bwd_phases.txt; exit 1; }
   timeout -k 10 200 python tools/stamp_bwd.py bf16 > $out/${tag}_bwd_phases_bf16.txt 2>&1 || { tail -20 $out/${tag}_bwd_phases_bf16.txt; exit 1; }
