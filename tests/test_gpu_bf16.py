@@ -265,7 +265,7 @@ def test_dynca_module_bf16(ops):
     prm = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if k.startswith(("w1", "w2"))}
     us = torch.rand(3, 2, 1, 32, 32, device=DEV)
     it = iter(us)
-    m._draw = lambda x_, steps: torch.stack([next(it) for _ in range(steps)])
+    m._draw = lambda x_, steps, rate=None: torch.stack([next(it) for _ in range(steps)])
     xg = x.clone().requires_grad_(True)
     cot = torch.randn(2, 12, 32, 32, device=DEV)
     out, _ = m.forward_nsteps(xg, 3, cond_img=img)

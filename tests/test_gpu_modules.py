@@ -29,7 +29,7 @@ def _cond_model(size=32, hidden=8, seed=0, out_scale=3.0):
 def _inject(model, us):
     """Use known uniforms instead of the device RNG so the CPU oracle can replay the masks."""
     it = iter(us)
-    model._draw = lambda x, steps: torch.stack([next(it).to(x.device) for _ in range(steps)])
+    model._draw = lambda x, steps, rate=None: torch.stack([next(it).to(x.device) for _ in range(steps)])
 
 
 def test_conditioned_nca_grow_and_forward_match_oracle():
