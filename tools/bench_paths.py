@@ -177,9 +177,18 @@ def video_leg():
             x = (torch.rand(1, C, 256, 256, generator=gen) - 0.5).to(DEV)
             cond = (torch.rand(1, 2, 256, 256, generator=gen) * 2 - 1).to(DEV)
             T = 32
-            (ms,), (mn,) = timed([lambda: ops.dynca_nsteps(x, T, cond, None, w, "circular", 0.5, seed=1, two_scale=two)], iters=20)
+            res = {}
+            for persist in ((True, False) if not two else (False,)):     # single-scale: the one-launch persistent kernel vs one launch per step
+                ops.persistent_steps = persist
+                (ms,), (mn,) = timed([lambda: ops.dynca_nsteps(x, T, cond, None, w, "circular", 0.5, seed=1, two_scale=two)], iters=20)
+                res["persistent" if persist else "per_step"] = (ms, mn)
+            ops.persistent_steps = True
+            ops.check_errors()
+            ms, mn = res.get("persistent", res["per_step"])
+            flops = 2 * (27 * C + fc * (5 * C + 2))
             emit(path="video_B1", C=C, fc=fc, two_scale=two, HW=[256, 256], us_per_step=ms / T * 1e3, min_us_per_step=mn / T * 1e3,
-                 frames_per_s_at_32_steps=1e3 / ms)
+                 frames_per_s_at_32_steps=1e3 / ms, kernel="persistent (one launch for T steps)" if "persistent" in res else "per-step launches",
+                 per_step_launch_us_per_step=res["per_step"][0] / T * 1e3, frac_f32_mfma=256 * 256 * T * flops / ms / 1e9 / 157.3)
 
 
 def main(names):

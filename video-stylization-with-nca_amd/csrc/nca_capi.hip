@@ -41,6 +41,8 @@ int check_bits(bool bits, int B, int H, int W, float rate, bool dynca) {
     return 0;
 }
 
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
 bool dims_ok(int B, int C, int H, int W) {
     return B > 0 && C > 0 && H > 0 && W > 0 && (size_t)B * C * H * W < ((size_t)1 << 40);
 }
@@ -118,7 +120,8 @@ static int device_error_rc(const char* where) {
     const unsigned v = nca_error_word_read(false);
     if (!v) return 0;
     return fail(NCAHIP_EDEVICE, "%s: a device-side failure was recorded earlier on this device (error word 0x%x: bit 0 = "
-                "producer/consumer hand-off poll expired); results since the last ncahip_check_errors are not valid", where, v);
+                "producer/consumer hand-off poll expired, bit 1 = neighbour poll of the persistent DyNCA kernel expired); results since "
+                "the last ncahip_check_errors are not valid", where, v);
 }
 
 extern "C" {
@@ -129,7 +132,7 @@ int ncahip_check_errors(ncahip_stream_t stream, int clear) {
     const unsigned v = nca_error_word_read(clear != 0);
     if (!v) return 0;
     return fail(NCAHIP_EDEVICE, "device error word 0x%x (bit 0: a producer/consumer hand-off poll expired -- the affected launch "
-                "produced stale tiles)", v);
+                "produced stale tiles; bit 1: a neighbour poll of the persistent DyNCA kernel expired -- that launch stopped early)", v);
 }
 
 int ncahip_debug_inject_error(unsigned bits) {   // test hook: what a kernel does when a poll expires
@@ -220,6 +223,36 @@ int ncahip_dynca_nsteps_fwd_f32(float* states, int ring, int T, const float* con
         if (int rc = hip_result(nca_launch_dynca_step_fwd(a, (hipStream_t)stream), "dynca_nsteps_fwd")) return rc;
     }
     return 0;
+}
+
+// ---- T steps in ONE launch for small grids (B = 1 video inference), nca_dynca_persist.hip -------------------------------------
+size_t ncahip_dynca_nsteps_persist_workspace(int B, int C, int H, int W, int fc, int c_cond) {
+    if (!dims_ok(B, C, H, W) || !nca_dynca_persist_shape_ok(B, C, H, W, fc, c_cond)) return 0;
+    return align256((size_t)(nca_dynca_persist_tiles(B, H, W) + 1) * sizeof(int));      // step counters + the abort word
+}
+
+int ncahip_dynca_nsteps_fwd_persist_f32(float* states, int T, const float* cond, const float* u, const float* w1, const float* b1,
+                                        const float* w2, const float* b2, int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                                        float update_rate, uint64_t seed, uint64_t step0, void* workspace, size_t workspace_bytes,
+                                        ncahip_stream_t stream) {
+    if (T < 1 || !workspace) return fail(NCAHIP_EINVAL, "dynca nsteps persist: T >= 1 and a workspace required");
+    if (int rc = check_dynca(states, states + 1, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
+    const size_t need = ncahip_dynca_nsteps_persist_workspace(B, C, H, W, fc, c_cond);
+    if (need == 0) return fail(NCAHIP_ERANGE, "dynca nsteps persist: shape not covered (C <= 16, fc <= 128, H %% 8 == 0, W %% 32 == 0); use ncahip_dynca_nsteps_fwd_f32");
+    if (workspace_bytes < need) return fail(NCAHIP_EINVAL, "dynca nsteps persist: workspace too small");
+    if (((uintptr_t)states & 15) != 0) return fail(NCAHIP_ERANGE, "dynca nsteps persist: 16-byte aligned states required");
+    const bool ubits = u_is_bits(u, seed);
+    if (int rc = check_bits(ubits, B, H, W, update_rate, true)) return rc;
+    if (int rc = device_error_rc("dynca nsteps persist")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    NcaDyncaPersistArgs a{states, T, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step0,
+                          (int*)workspace, nullptr, ubits ? 1 : 0};
+    bool fits = false;
+    if (int rc = hip_result(nca_launch_dynca_persist(a, st, true, &fits), "dynca nsteps persist (occupancy)")) return rc;
+    if (!fits) return fail(NCAHIP_ERANGE, "dynca nsteps persist: %d tiles cannot all be resident on this device; use ncahip_dynca_nsteps_fwd_f32",
+                           nca_dynca_persist_tiles(B, H, W));
+    if (int rc = hip_result(hipMemsetAsync(workspace, 0, need, st), "dynca nsteps persist memset")) return rc;
+    return hip_result(nca_launch_dynca_persist(a, st, false, &fits), "dynca_nsteps_fwd_persist");
 }
 
 // ---- conditioning front ends (fixed-filter part of the encoders) ---------------------------------------------------------
@@ -676,8 +709,6 @@ int ncahip_gram_rows_f32(const float* a, int ma, const float* b1, int nb1, const
     return hip_result(nca_launch_gram_rows(a, ma, b1, nb1, b2, nb2, B, HW, out, (float*)workspace, (hipStream_t)stream,
                                            accumulate != 0), "gram_rows");
 }
-
-static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 size_t ncahip_cond_grow_bwd_workspace(int B, int C, int H, int W, int hidden) {
     if (!dims_ok(B, C, H, W) || hidden <= 0) return 0;

@@ -70,6 +70,25 @@ struct NcaDyncaArgs {
     int u_bits;               // u points at bit-packed fire masks (uint32 words, cell i -> bit i & 31 of word i >> 5; B*H*W < 2^32)
 };
 
+// T DyNCA steps in one launch (nca_dynca_persist.hip): one workgroup per 8 x 32 tile for all steps, neighbour counters in `flags`
+struct NcaDyncaPersistArgs {
+    float* states;       // two slots of B*C*H*W floats: slot 0 = input state, step t reads slot t % 2 and writes slot (t + 1) % 2
+    int T;
+    const float* cond;   // [B,c_cond,H,W] or null
+    const float* u;      // [T][B*H*W] uniforms / [T][ceil(B*H*W/32)] mask words (u_bits) / null: Philox (seed, step0 + t)
+    const float *w1, *b1, *w2, *b2;
+    int B, C, H, W, fc, c_cond, pad_mode;
+    float rate;
+    uint64_t seed, step0;
+    int* flags;          // one step counter per tile, zero at launch
+    unsigned* err;       // sticky error word (bit 1: a neighbour poll expired)
+    int u_bits;
+};
+bool nca_dynca_persist_shape_ok(int B, int C, int H, int W, int fc, int c_cond);
+int nca_dynca_persist_tiles(int B, int H, int W);
+// query_only: only decide whether every workgroup can be co-resident on the current device (*fits)
+hipError_t nca_launch_dynca_persist(const NcaDyncaPersistArgs& a, hipStream_t st, bool query_only, bool* fits);
+
 struct NcaCondArgs {
     const float* x_in;
     const uint8_t* pre_in;  // null: x_in is a true state; else x_in is pending with this pre mask

@@ -50,6 +50,8 @@ SIGNATURES = {
     "ncahip_dynca_step_bwd_w2_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P, _P, _P, _P, _P, _I, _P,
                                      ctypes.c_size_t, _P],
     "ncahip_dynca_nsteps_bwd_workspace": [_I, _I, _I, _I, _I, _I],
+    "ncahip_dynca_nsteps_persist_workspace": [_I, _I, _I, _I, _I, _I],
+    "ncahip_dynca_nsteps_fwd_persist_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P, ctypes.c_size_t, _P],
     "ncahip_dynca_nsteps_bwd_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P, _P, _P, _P, _P, _P, _P,
                                     _P, ctypes.c_size_t, _P],
     "ncahip_dynca_nsteps_bwd_bf16_workspace": [_I, _I, _I, _I, _I, _I],
@@ -69,7 +71,7 @@ SIGNATURES = {
 _RESTYPES = {"ncahip_last_error": c_char_p, "ncahip_cond_grow_bwd_workspace": ctypes.c_size_t,
              "ncahip_gram_rows_workspace": ctypes.c_size_t, "ncahip_dynca_step_bwd_w2_workspace": ctypes.c_size_t,
              "ncahip_dynca_nsteps_bwd_workspace": ctypes.c_size_t, "ncahip_dynca_nsteps_bwd_ms_workspace": ctypes.c_size_t,
-             "ncahip_dynca_nsteps_bwd_bf16_workspace": ctypes.c_size_t}
+             "ncahip_dynca_nsteps_bwd_bf16_workspace": ctypes.c_size_t, "ncahip_dynca_nsteps_persist_workspace": ctypes.c_size_t}
 
 _lib = None
 
@@ -78,6 +80,7 @@ class NcaHipError(RuntimeError):
     pass
 
 
+EINVAL, ERANGE, EDEVICE = -1, -2, 100001     # include/ncahip.h return codes
 SEED_U_IS_BITS = 0x5354494255     # include/ncahip.h NCAHIP_SEED_U_IS_BITS: `u` holds bit-packed fire masks
 
 

@@ -217,6 +217,9 @@ def dynca_step(x: torch.Tensor, cond: Optional[torch.Tensor], u: Optional[torch.
     return out
 
 
+persistent_steps = True     # dynca_nsteps: use the one-launch persistent kernel where it applies (tests / A-B timing switch it off)
+
+
 def two_scale_fused_ok(C: int, H: int, W: int, fc: int) -> bool:
     """Shapes ncahip_dynca_*_fwd_ms_f32 covers (perception_scales = [0, 1] fused): even sizes, C <= 16, fc <= 128."""
     return H % 2 == 0 and W % 2 == 0 and C <= 16 and fc <= 128
@@ -240,6 +243,19 @@ def dynca_nsteps(x: torch.Tensor, T: int, cond: Optional[torch.Tensor], us: Opti
     ring = T + 1 if keep_history else 2
     states = torch.empty(ring, B, C, H, W, device=x.device, dtype=dt)
     states[0].copy_(x)
+    if not keep_history and not two_scale and sfx == "f32" and T >= 2 and persistent_steps:
+        # small grids (B = 1 video inference): all T steps in ONE launch, one workgroup per tile (ncahip_dynca_nsteps_fwd_persist_f32);
+        # NCAHIP_ERANGE = shape not covered or not every tile resident on this device -> the per-step kernels below
+        nbytes = lib().ncahip_dynca_nsteps_persist_workspace(B, C, H, W, w.fc, c_cond)
+        if nbytes:
+            ws = _workspace(nbytes, x.device)
+            rc = lib().ncahip_dynca_nsteps_fwd_persist_f32(_p(states), T, _p(cond), _p(us), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C,
+                                                            H, W, w.fc, c_cond, PAD_MODES[pad_mode], update_rate, seed, step0, _p(ws),
+                                                            nbytes, _stream())
+            if rc == 0:
+                return states[T % 2], states
+            if rc != _capi.ERANGE:
+                check(rc, "dynca_nsteps_fwd_persist")
     if two_scale:
         assert sfx == "f32", "the two-scale step is an fp32 kernel"
         pc = torch.empty(B, 4 * C, H // 2, W // 2, device=x.device, dtype=torch.float32)
