@@ -378,10 +378,10 @@ int ncahip_cond_grow_bwd_bf16(const uint16_t *states, const uint8_t *pre, int T,
 /* ---- T DyNCA steps in ONE launch (B = 1 video inference) --------------------------------------------------------------
  * ConditioneDyNCA/utils/misc/video_utils.py:50-82 (forward_nsteps(h, step_n, cond_img=frame) per frame; WebGL twin
  * docs/dynca.js:1057-1132).  Same result, bit for bit, as ncahip_dynca_nsteps_fwd_f32 with ring = 2 (slot 0 = input, the
- * final state ends in slot T % 2), but every 8 x 32 tile is owned by one workgroup for all T steps: weights and conditioning
+ * final state ends in slot T % 2), but every 16 x 16 tile is owned by one workgroup for all T steps: weights and conditioning
  * staged once, the tile's state kept in LDS, only the one-cell halo re-read per step, neighbours synchronised through per-tile
- * step counters (in `workspace`) with bounded polls.  Covered: C <= 16, fc <= 128, H % 8 == 0, W % 32 == 0, and every tile's
- * workgroup resident at once (occupancy x CUs >= B * H/8 * W/32: 1 x 256 x 256 is exactly one per CU of an MI355X);
+ * step counters (in `workspace`) with bounded polls.  Covered: C <= 16, fc <= 128, H % 16 == 0, W % 16 == 0, and every tile's
+ * workgroup resident at once (occupancy x CUs >= B * H/16 * W/16: 1 x 256 x 256 is exactly one per CU of an MI355X);
  * NCAHIP_ERANGE otherwise -- the caller then runs ncahip_dynca_nsteps_fwd_f32.  ncahip_dynca_nsteps_persist_workspace returns
  * 0 for shapes that are never covered.  A neighbour that never becomes resident (another process holding CUs) makes a poll
  * expire: the launch still drains, bit 1 of the sticky device error word is set and ncahip_check_errors / the next driver call

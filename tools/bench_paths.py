@@ -176,7 +176,7 @@ def video_leg():
             w = dyn_weights(C, fc, 2, gen)
             x = (torch.rand(1, C, 256, 256, generator=gen) - 0.5).to(DEV)
             cond = (torch.rand(1, 2, 256, 256, generator=gen) * 2 - 1).to(DEV)
-            T = 32
+            T = int(os.environ.get("NCAHIP_VIDEO_T", "32"))      # steps per frame (one forward_nsteps call)
             res = {}
             for persist in ((True, False) if not two else (False,)):     # single-scale: the one-launch persistent kernel vs one launch per step
                 ops.persistent_steps = persist
@@ -187,7 +187,7 @@ def video_leg():
             ms, mn = res.get("persistent", res["per_step"])
             flops = 2 * (27 * C + fc * (5 * C + 2))
             emit(path="video_B1", C=C, fc=fc, two_scale=two, HW=[256, 256], us_per_step=ms / T * 1e3, min_us_per_step=mn / T * 1e3,
-                 frames_per_s_at_32_steps=1e3 / ms, kernel="persistent (one launch for T steps)" if "persistent" in res else "per-step launches",
+                 steps_per_call=T, frames_per_s_at_32_steps=1e3 / (ms * 32 / T), kernel="persistent (one launch for T steps)" if "persistent" in res else "per-step launches",
                  per_step_launch_us_per_step=res["per_step"][0] / T * 1e3, frac_f32_mfma=256 * 256 * T * flops / ms / 1e9 / 157.3)
 
 

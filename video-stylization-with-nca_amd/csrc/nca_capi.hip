@@ -228,7 +228,8 @@ int ncahip_dynca_nsteps_fwd_f32(float* states, int ring, int T, const float* con
 // ---- T steps in ONE launch for small grids (B = 1 video inference), nca_dynca_persist.hip -------------------------------------
 size_t ncahip_dynca_nsteps_persist_workspace(int B, int C, int H, int W, int fc, int c_cond) {
     if (!dims_ok(B, C, H, W) || !nca_dynca_persist_shape_ok(B, C, H, W, fc, c_cond)) return 0;
-    return align256((size_t)(nca_dynca_persist_tiles(B, H, W) + 1) * sizeof(int));      // step counters + the abort word
+    // abort word + the ring exchange: 2 parities x tiles x C x 60 ring cells of (value, step) pairs
+    return 256 + align256((size_t)2 * nca_dynca_persist_tiles(B, H, W) * C * 60 * sizeof(unsigned long long));
 }
 
 int ncahip_dynca_nsteps_fwd_persist_f32(float* states, int T, const float* cond, const float* u, const float* w1, const float* b1,
@@ -238,15 +239,17 @@ int ncahip_dynca_nsteps_fwd_persist_f32(float* states, int T, const float* cond,
     if (T < 1 || !workspace) return fail(NCAHIP_EINVAL, "dynca nsteps persist: T >= 1 and a workspace required");
     if (int rc = check_dynca(states, states + 1, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
     const size_t need = ncahip_dynca_nsteps_persist_workspace(B, C, H, W, fc, c_cond);
-    if (need == 0) return fail(NCAHIP_ERANGE, "dynca nsteps persist: shape not covered (C <= 16, fc <= 128, H %% 8 == 0, W %% 32 == 0); use ncahip_dynca_nsteps_fwd_f32");
+    if (need == 0) return fail(NCAHIP_ERANGE, "dynca nsteps persist: shape not covered (C <= 16, fc <= 128, H %% 16 == 0, W %% 16 == 0); use ncahip_dynca_nsteps_fwd_f32");
     if (workspace_bytes < need) return fail(NCAHIP_EINVAL, "dynca nsteps persist: workspace too small");
     if (((uintptr_t)states & 15) != 0) return fail(NCAHIP_ERANGE, "dynca nsteps persist: 16-byte aligned states required");
     const bool ubits = u_is_bits(u, seed);
     if (int rc = check_bits(ubits, B, H, W, update_rate, true)) return rc;
     if (int rc = device_error_rc("dynca nsteps persist")) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (((uintptr_t)workspace & 255) != 0) return fail(NCAHIP_ERANGE, "dynca nsteps persist: 256-byte aligned workspace required");
     NcaDyncaPersistArgs a{states, T, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step0,
-                          (int*)workspace, nullptr, ubits ? 1 : 0};
+                          (int*)workspace, (unsigned long long*)((char*)workspace + 256), (size_t)nca_dynca_persist_tiles(B, H, W) * C * 60,
+                          nullptr, ubits ? 1 : 0};
     bool fits = false;
     if (int rc = hip_result(nca_launch_dynca_persist(a, st, true, &fits), "dynca nsteps persist (occupancy)")) return rc;
     if (!fits) return fail(NCAHIP_ERANGE, "dynca nsteps persist: %d tiles cannot all be resident on this device; use ncahip_dynca_nsteps_fwd_f32",

@@ -1,32 +1,42 @@
 // nca_dynca_persist.hip -- T DyNCA steps in ONE launch for small grids (B = 1 video inference: ConditioneDyNCA/utils/misc/
 // video_utils.py:50-82 runs forward_nsteps(h, step_n, cond_img=frame) per frame; WebGL twin docs/dynca.js:1057-1132), gfx950, fp32.
 //
-// At 1 x 256 x 256 one step is ONE 8 x 32 tile per CU and one wave per SIMD: 408 exact-f32 MFMAs per wave = 5.4 us, and the
-// per-step launch adds ~13 us of launch gap, weight-image fill, cold first touch and tail to it (18.7 us per step, C = 12 /
-// fc = 96).  Here a workgroup OWNS its tile for all T steps:
+// At 1 x 256 x 256 one step is 256 cells per CU and one wave per SIMD: 408 exact-f32 MFMAs per wave = 5.4 us, and the per-step
+// launch adds ~13 us of launch gap, weight-image fill, cold first touch and tail to it (18.5 us per step, C = 12 / fc = 96).
+// Here a workgroup OWNS one 16 x 16 tile for all T steps:
 //   * weight images and the conditioning tile are built once; the tile's state stays in LDS (two buffers, ping-pong) and only the
-//     one-cell halo ring (84 cells x C) is re-read per step;
+//     one-cell halo (68 cells x C) is re-read per step;
 //   * neighbours synchronise through per-tile monotonic step counters in global memory (tools/micro/neighbour_sync.hip measured
-//     the protocol: 6 us per step for publish + poll + ring read): step t starts when the <= 8 neighbours have published step t,
-//     i.e. their state t is in memory -- and, because a workgroup reads its ring BEFORE it computes and publishes, that also
-//     means they are done READING my state t-1, so the ping-pong buffer holding it may be overwritten with state t+1;
-//   * tiles live in different XCDs' L2s: state stores are write-through and ring loads coherent at agent scope (sc1), the
-//     counter is stored relaxed after s_waitcnt vmcnt(0) + workgroup barrier (every lane's stores acknowledged);
-//   * every poll is BOUNDED: an expired poll (a neighbour that never became resident) sets bit 1 of the sticky device error word
-//     and every workgroup leaves its step loop at the next step -- the launch always drains, the host sees NCAHIP_EDEVICE.
-// The host side launches this only when every workgroup can be co-resident (occupancy x CUs >= tiles), H % 8 == 0, W % 32 == 0,
-// C <= 16, fc <= 128; anything else runs the per-step kernels (nca_step_fwd.hip).  Same arithmetic in the same order as the
+//     the protocol): step t may read its halo once the <= 8 neighbours have published step t, i.e. their state t is in memory --
+//     and, because a workgroup reads its halo BEFORE it publishes, that also means they are done READING my state t-1, so the
+//     ping-pong buffer holding it may be overwritten with state t+1;
+//   * the exchange runs UNDER the compute: a fifth wave (the sync wave) polls the counters, loads the halo (coherent loads: the
+//     tiles sit in other XCDs' L2s) and writes it into the LDS tile while the four compute waves work on the 12 groups of 16
+//     INTERIOR cells (rows / columns 1..14: no halo needed); the tile's own border ring (60 cells + 4 left-over interior cells =
+//     4 groups) comes last, and only the ring is stored to memory every step (write-through) -- the interior stays in LDS until the
+//     final step.  16 groups exactly: no extra MFMA work for the split;
+//   * the counter is published by the sync wave after every compute wave's stores are acknowledged (s_waitcnt vmcnt(0) + workgroup
+//     barrier); the next step's interior groups start right behind that barrier, not behind the neighbours;
+//   * every poll is BOUNDED: an expired poll (a neighbour that never became resident) sets bit 1 of the sticky device error word and
+//     an abort word in device memory; every workgroup leaves its step loop at its next step -- the launch always drains, the host
+//     sees NCAHIP_EDEVICE.
+// The host side launches this only when every workgroup can be co-resident (occupancy x CUs >= tiles), H % 16 == 0, W % 16 == 0,
+// C <= 16, fc <= 128; anything else runs the per-step kernels (nca_step_fwd.hip).  Same arithmetic per cell in the same order as the
 // per-step kernel (perception from the LDS tile, exact-f32 MFMA chains with the same k order): bit-identical results.
 #include "nca_common.h"
+#include <cstdlib>
+#include <type_traits>
+
 #include "nca_kernels.h"
 
 namespace {
 
-constexpr int kPT = 256;                     // threads per workgroup
-constexpr int PTH = 8, PTW = 32;             // tile
-constexpr int PROWS = PTH + 2, PRS = PTW + 8, PCS = 400;   // Z[ch][row 0..9][col: image col tx0-1+q at index q+3]; 400 % 32 == 16
-static_assert(PROWS * PRS <= PCS && PCS % 32 == 16, "tile carve");
-constexpr int kRing = 2 * (PTW + 2) + 2 * PTH;             // 84 halo cells
+constexpr int kPT = 320;                     // 4 compute waves + 1 sync wave
+constexpr int PTH = 16, PTW = 16;            // tile
+constexpr int PROWS = PTH + 2, PRS = 24, PCS = PROWS * PRS;   // Z[ch][row 0..17][col: image col tx0-1+q at index q+3]
+static_assert(PCS % 32 == 16 && PTW + 2 + 3 <= PRS, "tile carve");
+constexpr int kHalo = 2 * (PTW + 2) + 2 * PTH;             // 68 halo cells
+constexpr int kIW = PTW - 2;                               // interior width (14)
 
 template <int CP, int FC, bool HAS_COND>
 struct PersistCfg {
@@ -37,10 +47,11 @@ struct PersistCfg {
     static constexpr int OFF_B1 = OFF_W2 + K2S * 64;
     static constexpr int OFF_B2 = OFF_B1 + FC;
     static constexpr int OFF_Z = OFF_B2 + 16;
-    static constexpr int OFF_MK = OFF_Z + 2 * CP * PCS;
-    static constexpr int OFF_CN = OFF_MK + PTH * PTW;
-    static constexpr int LDS_FLOATS = OFF_CN + (HAS_COND ? 4 * PTH * PTW : 0);
-    static constexpr int NLD = (kRing * CP + kPT - 1) / kPT;   // ring loads per thread and step
+    static constexpr int OFF_MK = OFF_Z + 2 * CP * PCS;               // fire masks of two steps, [2][256]
+    static constexpr int OFF_CN = OFF_MK + 2 * PTH * PTW;
+    static constexpr int OFF_FLAG = OFF_CN + (HAS_COND ? 4 * PTH * PTW : 0);   // [0] halo of step t staged (t + 1), [1] abort
+    static constexpr int LDS_FLOATS = OFF_FLAG + 4;
+    static constexpr int NLD = (kHalo * CP + 63) / 64;       // halo loads per sync-wave lane and step
     static_assert(CP % 4 == 0 && CP <= 16 && FC % 16 == 0 && OFF_Z % 4 == 0, "shape");
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
@@ -50,6 +61,40 @@ __device__ __forceinline__ float ld_coherent(const float* p) {
 }
 __device__ __forceinline__ void st_through(float* p, float v) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ring exchange: a cell value travels WITH the step it belongs to, as one 64-bit word (single-copy atomic): the reader needs no
+// separate counter -- and the writer no acknowledgement round trip -- to know that what it loaded is state `step`
+__device__ __forceinline__ void st_pair(unsigned long long* p, float v, int step) {
+    __hip_atomic_store(p, ((unsigned long long)(unsigned)step << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_pair(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr int kRingCells = 2 * PTW + 2 * (PTH - 2);        // 60 cells of a tile that neighbours read
+// position of tile cell (r, q) in the ring enumeration (group_cell): top row, bottom row, left column, right column
+__device__ __forceinline__ int ring_index(int r, int q) {
+    if (r == 0) return q;
+    if (r == PTH - 1) return PTW + q;
+    return q == 0 ? r + 31 : r + 45;
+}
+// cell (r, q) of the tile that lane ci of group j works on: groups 0..11 = interior cells 16 j + ci of the 14 x 14 interior
+// (row-major), groups 12..15 = 15 ring cells each + one of the four left-over interior cells
+__device__ __forceinline__ void group_cell(int j, int ci, int& r, int& q) {
+    int idx = 16 * j + ci;                       // interior enumeration
+    if (j >= 12) {
+        const int jb = j - 12;
+        if (ci < 15) {
+            const int k = 15 * jb + ci;          // ring enumeration: top row, bottom row, left column, right column
+            if (k < 16) { r = 0; q = k; }
+            else if (k < 32) { r = PTH - 1; q = k - 16; }
+            else if (k < 46) { r = k - 31; q = 0; }
+            else { r = k - 45; q = PTW - 1; }
+            return;
+        }
+        idx = 192 + jb;
+    }
+    r = 1 + idx / kIW;
+    q = 1 + idx % kIW;
 }
 
 template <int CP, int FC, bool HAS_COND>
@@ -62,71 +107,78 @@ __global__ __launch_bounds__(kPT, 1) void dynca_persist_kernel(const NcaDyncaPer
     float* const B2L = smem + K::OFF_B2;
     float* const MK = smem + K::OFF_MK;
     float* const CN = smem + K::OFF_CN;
+    int* const lflag = reinterpret_cast<int*>(smem + K::OFF_FLAG);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ci = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, ci = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C = a.C, H = a.H, W = a.W, fc = a.fc, CC = a.c_cond, K1 = 4 * C + CC;
     const size_t plane = (size_t)H * W, slot = (size_t)a.B * C * plane;
     const int tiles_x = W / PTW, tiles_y = H / PTH;
     const int tile = blockIdx.x, txi = tile % tiles_x, tyi = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int ty0 = tyi * PTH, tx0 = txi * PTW;
+    const size_t cell0 = (size_t)b * plane + (size_t)ty0 * W + tx0;     // linear index of the tile's first cell
 
-    // ---- once per launch: A-operand weight images (same layouts and k order as dynca_step_fwd_kernel) ---------------------
-    for (int idx = tid; idx < K::M1T * K::K1S * 64; idx += kPT) {
-        const int l = idx & 63, s = (idx >> 6) % K::K1S, m = (idx >> 6) / K::K1S;
-        const int gg = l >> 4, o = 16 * m + (l & 15);
-        long src = -1;
-        if (o < fc) {
-            if (s < CP) {   // k-step s = 4c'+f: channel 4c'+g, filter f (0 id, 1 sobel_x, 2 sobel_y, 3 lap); blocked [x|Sx|Sy|L], dynca.py:92-95
-                const int ch = (s & ~3) + gg;
-                if (ch < C) src = (long)o * K1 + (s & 3) * C + ch;
-            } else if (gg < CC) src = (long)o * K1 + 4 * C + gg;
+    // ---- once per launch: A-operand weight images (same layouts and k order as dynca_step_fwd_kernel).  Two-phase gather: every
+    //      load of both images is requested before the first LDS write (one cold round trip for the prologue, not one per element)
+    {
+        constexpr int N1 = K::M1T * K::K1S * 64, N2 = K::K2S * 64, U1 = (N1 + kPT - 1) / kPT, U2 = (N2 + kPT - 1) / kPT;
+        float v1[U1], v2[U2];
+#pragma unroll
+        for (int u = 0; u < U1; ++u) {
+            const int idx = tid + kPT * u;
+            const int l = idx & 63, s_ = (idx >> 6) % K::K1S, m = (idx >> 6) / K::K1S;
+            const int gg = l >> 4, o = 16 * m + (l & 15);
+            long src = -1;
+            if (idx < N1 && o < fc) {
+                if (s_ < CP) {   // k-step s = 4c'+f: channel 4c'+g, filter f (0 id, 1 sobel_x, 2 sobel_y, 3 lap); blocked [x|Sx|Sy|L], dynca.py:92-95
+                    const int ch = (s_ & ~3) + gg;
+                    if (ch < C) src = (long)o * K1 + (s_ & 3) * C + ch;
+                } else if (gg < CC) src = (long)o * K1 + 4 * C + gg;
+            }
+            const float w = a.w1[src >= 0 ? src : 0];
+            v1[u] = src >= 0 ? w : 0.0f;
         }
-        W1L[idx] = src >= 0 ? a.w1[src] : 0.0f;
-    }
-    for (int idx = tid; idx < K::K2S * 64; idx += kPT) {
-        const int l = idx & 63, s = idx >> 6;
-        const int gg = l >> 4, o = l & 15, k = 16 * (s >> 2) + 4 * gg + (s & 3);
-        W2L[idx] = (o < C && k < fc) ? a.w2[(long)o * fc + k] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const int idx = tid + kPT * u;
+            const int l = idx & 63, s_ = idx >> 6;
+            const int gg = l >> 4, o = l & 15, k = 16 * (s_ >> 2) + 4 * gg + (s_ & 3);
+            const bool ok = idx < N2 && o < C && k < fc;
+            const float w = a.w2[ok ? (long)o * fc + k : 0];
+            v2[u] = ok ? w : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U1; ++u)
+            if (tid + kPT * u < N1) W1L[tid + kPT * u] = v1[u];
+#pragma unroll
+        for (int u = 0; u < U2; ++u)
+            if (tid + kPT * u < N2) W2L[tid + kPT * u] = v2[u];
     }
     for (int idx = tid; idx < FC; idx += kPT) B1L[idx] = idx < fc ? a.b1[idx] : 0.0f;
     if (tid < 16) B2L[tid] = tid < C ? a.b2[tid] : 0.0f;
-
-    // this thread's cell (mask, conditioning): one cell per thread
-    const int cr = tid / PTW, cq = tid % PTW;
-    const size_t cell = (size_t)b * plane + (size_t)(ty0 + cr) * W + tx0 + cq;
+    if (tid < 4) lflag[tid] = 0;
     if (HAS_COND) {
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
-            CN[cc * PTH * PTW + tid] = cc < CC ? a.cond[((size_t)b * CC + cc) * plane + (cell - (size_t)b * plane)] : 0.0f;
-    }
-    // neighbours whose step counters gate this tile (circular padding wraps; the other modes have no tile beyond the border)
-    int nb = -1;
-    if (tid < 8) {
-        const int k = tid < 4 ? tid : tid + 1, dy = k / 3 - 1, dx = k % 3 - 1;
-        int ny = tyi + dy, nx = txi + dx;
-        if (a.pad_mode == NCA_PAD_CIRCULAR) {
-            ny = (ny + tiles_y) % tiles_y;
-            nx = (nx + tiles_x) % tiles_x;
+        for (int i = tid; i < 4 * PTH * PTW; i += kPT) {
+            const int cc = i / (PTH * PTW), c = i % (PTH * PTW);
+            CN[i] = cc < CC ? a.cond[((size_t)b * CC + cc) * plane + (size_t)(ty0 + c / PTW) * W + tx0 + c % PTW] : 0.0f;
         }
-        if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) nb = (b * tiles_y + ny) * tiles_x + nx;
     }
-    // ring items of this thread: item j = tid + 256 k  <->  halo cell j % 84 of channel j / 84; source offset once (pad resolved)
-    int rz[K::NLD];        // LDS offset inside a Z buffer, or -1
-    unsigned rsrc[K::NLD]; // element offset inside a batch item's state, or ~0u: contributes zero
-#pragma unroll
-    for (int k = 0; k < K::NLD; ++k) {
-        const int j = tid + kPT * k, hc = j % kRing, ch = j / kRing;
-        int r, q;
-        if (hc < PTW + 2) { r = 0; q = hc; }
-        else if (hc < 2 * (PTW + 2)) { r = PROWS - 1; q = hc - (PTW + 2); }
-        else if (hc < 2 * (PTW + 2) + PTH) { r = hc - 2 * (PTW + 2) + 1; q = 0; }
-        else { r = hc - 2 * (PTW + 2) - PTH + 1; q = PTW + 1; }
-        const bool live = j < kRing * CP;
-        rz[k] = live ? ch * PCS + r * PRS + q + 3 : -1;
-        const int sy = nca_pad_index(ty0 - 1 + r, H, a.pad_mode), sx = nca_pad_index(tx0 - 1 + q, W, a.pad_mode);
-        rsrc[k] = (live && ch < C && sy >= 0 && sx >= 0) ? (unsigned)((size_t)ch * plane + (size_t)sy * W + sx) : ~0u;
-    }
-    // the tile's interior at step 0 (plain loads: written before the launch)
+    // fire mask of step t for the tile's 256 cells into MK[t & 1] (dynca.py:131): explicit uniforms, bit-packed masks, or Philox
+    auto fill_mask = [&](int t, int first, int stride) {
+        float* const mk = MK + (t & 1) * (PTH * PTW);
+        const size_t cells = (size_t)a.B * plane;
+        for (int c = first; c < PTH * PTW; c += stride) {
+            const size_t cell = cell0 + (size_t)(c / PTW) * W + c % PTW;
+            float uu;
+            if (a.u) {
+                if (a.u_bits) uu = ((reinterpret_cast<const uint32_t*>(a.u)[(size_t)t * ((cells + 31) / 32) + (cell >> 5)] >> (unsigned)(cell & 31)) & 1u) ? 1.0f : 0.0f;
+                else uu = a.u[(size_t)t * cells + cell];
+            } else uu = nca_philox_cell(a.seed, a.step0 + (uint64_t)t, cell);
+            mk[c] = floorf(uu + a.rate);
+        }
+    };
+    fill_mask(0, tid, kPT);
+    // the tile's cells at step 0 (plain loads: written before the launch)
     {
         float* const Z0 = smem + K::OFF_Z;
         const float* const xb = a.states + (size_t)b * C * plane;
@@ -137,142 +189,241 @@ __global__ __launch_bounds__(kPT, 1) void dynca_persist_kernel(const NcaDyncaPer
             *reinterpret_cast<f32x4*>(Z0 + ch * PCS + (r + 1) * PRS + 4 + 4 * f4) = v;
         }
     }
+    __syncthreads();
+    int* const abort_w = a.flags;   // device-memory abort word (the sticky error word itself is host-mapped: polling THAT is a PCIe read storm)
 
-    // abort word: flags[ntiles] (device memory; the sticky error word itself is host-mapped -- polling THAT from every workgroup and
-    // step is a PCIe read storm: 180 us per step).  Lane 8 reads it while lanes 0..7 poll the neighbours; one LDS word tells the rest.
-    __shared__ int s_abort;
-    int* const abort_w = a.flags + gridDim.x;
-    if (tid == 0) s_abort = 0;
-    for (int t = 0; t < a.T; ++t) {
-        const float* const src = a.states + (size_t)(t & 1) * slot + (size_t)b * C * plane;
-        float* const dst = a.states + (size_t)((t + 1) & 1) * slot + (size_t)b * C * plane;
-        float* const Zc = smem + K::OFF_Z + (t & 1) * (CP * PCS);
-        float* const Zn = smem + K::OFF_Z + ((t + 1) & 1) * (CP * PCS);
-        // fire mask of this step (dynca.py:131): explicit uniforms, bit-packed masks, or in-kernel Philox
-        {
-            float uu;
-            if (a.u) {
-                const size_t cells = (size_t)a.B * plane;
-                if (a.u_bits) uu = ((reinterpret_cast<const uint32_t*>(a.u)[(size_t)t * ((cells + 31) / 32) + (cell >> 5)] >> (unsigned)(cell & 31)) & 1u) ? 1.0f : 0.0f;
-                else uu = a.u[(size_t)t * cells + cell];
-            } else uu = nca_philox_cell(a.seed, a.step0 + (uint64_t)t, cell);
-            MK[tid] = floorf(uu + a.rate);
-        }
-        // ---- neighbours have published state t (bounded poll) ----------------------------------------------------------------
-        if (t > 0 && nb >= 0) {
-            int spins = 0;
-            while (__hip_atomic_load(a.flags + nb, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < t && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(2);
-            if (spins >= (1 << 16)) {   // the neighbour never published (not resident?): record it, tell every workgroup to drain
-                if (a.err) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_abort = 1;
+    if (wave == 4) {
+        // =================================== sync wave: counters, halo, masks ================================================
+        // halo items of this lane: item j = lane + 64 k  <->  halo cell j % 68 of channel j / 68; source offset once (pad resolved)
+        int rz[K::NLD];
+        unsigned rsrc[K::NLD], rxch[K::NLD];
+#pragma unroll
+        for (int k = 0; k < K::NLD; ++k) {
+            const int j = lane + 64 * k, hc = j % kHalo, ch = j / kHalo;
+            int r, q;
+            if (hc < PTW + 2) { r = 0; q = hc; }
+            else if (hc < 2 * (PTW + 2)) { r = PROWS - 1; q = hc - (PTW + 2); }
+            else if (hc < 2 * (PTW + 2) + PTH) { r = hc - 2 * (PTW + 2) + 1; q = 0; }
+            else { r = hc - 2 * (PTW + 2) - PTH + 1; q = PTW + 1; }
+            const bool live = j < kHalo * CP;
+            rz[k] = live ? ch * PCS + r * PRS + q + 3 : -1;
+            const int sy = nca_pad_index(ty0 - 1 + r, H, a.pad_mode), sx = nca_pad_index(tx0 - 1 + q, W, a.pad_mode);
+            rsrc[k] = (live && ch < C && sy >= 0 && sx >= 0) ? (unsigned)((size_t)ch * plane + (size_t)sy * W + sx) : ~0u;
+            // a pad-resolved source inside this tile (reflect / replicate at the image border: row 1, row 0 ...) is read from the LDS
+            // tile itself -- interior cells are not in memory between the first and the last step (high bit = LDS offset)
+            if (rsrc[k] != ~0u && sy >= ty0 && sy < ty0 + PTH && sx >= tx0 && sx < tx0 + PTW)
+                rsrc[k] = 0x80000000u | (unsigned)(ch * PCS + (sy - ty0 + 1) * PRS + (sx - tx0) + 4);
+            // the same source in the ring-exchange buffer (steps >= 1): [tile][channel][ring cell] pairs
+            rxch[k] = ~0u;
+            if (rsrc[k] != ~0u && !(rsrc[k] & 0x80000000u)) {
+                const int st_ = (b * tiles_y + sy / PTH) * tiles_x + sx / PTW;
+                rxch[k] = (unsigned)((st_ * C + ch) * kRingCells + ring_index(sy % PTH, sx % PTW));
             }
         }
-        if (t > 0 && tid == 8 && __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) s_abort = 1;
-        __syncthreads();
-        if (s_abort) break;      // (uniform: written before the barrier, never cleared)
-        // ---- halo ring of state t: coherent loads (the neighbours' tiles sit in other XCDs' L2s), all requested together ------
-        {
+        // the halo of state tt into LDS buffer tt & 1: `global` = the items that come from memory (neighbours' ring cells, coherent
+        // loads), else the items whose pad-resolved source is a cell of this tile (read from the LDS tile: needs it complete)
+        // the halo of state tt into LDS buffer tt & 1.  global = the items that come from the neighbours: at tt = 0 plain loads of the
+        // input state; later the ring-exchange pairs, re-read until every one carries step tt (bounded; false = gave up).
+        // !global = the items whose pad-resolved source is a cell of this tile (read from the LDS tile: needs it complete).
+        auto stage_halo = [&](int tt, bool global) -> bool {
+            float* const Zt = smem + K::OFF_Z + (tt & 1) * (CP * PCS);
             float hv[K::NLD];
+            if (!global) {
 #pragma unroll
-            for (int k = 0; k < K::NLD; ++k) hv[k] = rsrc[k] != ~0u ? ld_coherent(src + rsrc[k]) : 0.0f;
+                for (int k = 0; k < K::NLD; ++k) {
+                    const bool own = rsrc[k] != ~0u && (rsrc[k] & 0x80000000u);
+                    if (own) hv[k] = Zt[rsrc[k] & 0x7fffffffu];
+                }
 #pragma unroll
-            for (int k = 0; k < K::NLD; ++k)
-                if (rz[k] >= 0) Zc[rz[k]] = hv[k];
-        }
-        __syncthreads();
-        // ---- the step for this wave's four 16-cell groups: perception -> MLP on MFMA -> residual ------------------------------
-        constexpr int NT = 4;
-        int r0[NT], q0[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int j = wave * NT + n;
-            r0[n] = j / (PTW / 16);
-            q0[n] = (j % (PTW / 16)) * 16 + ci;
-        }
-        float P[NT][K::K1S];
-#pragma unroll
-        for (int cq4 = 0; cq4 < CP / 4; ++cq4) {
-            const float* const zc = Zc + (4 * cq4 + g) * PCS + 3;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                float nbv[3][3];
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) nbv[dy][dx] = zc[(r0[n] + dy) * PRS + q0[n] + dx];
-                P[n][4 * cq4 + 0] = nbv[1][1];
-                P[n][4 * cq4 + 1] = nca_sobel_x(nbv);
-                P[n][4 * cq4 + 2] = nca_sobel_y(nbv);
-                P[n][4 * cq4 + 3] = nca_laplacian(nbv);
+                for (int k = 0; k < K::NLD; ++k) {
+                    const bool own = rsrc[k] != ~0u && (rsrc[k] & 0x80000000u);
+                    if (rz[k] >= 0 && own) Zt[rz[k]] = hv[k];
+                }
+                return true;
             }
-        }
-        if (HAS_COND) {
+            if (tt == 0) {
+                const float* const src = a.states + (size_t)b * C * plane;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) P[n][CP] = CN[g * PTH * PTW + r0[n] * PTW + q0[n]];
-        }
-        f32x4 acc2[NT];
-        {
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(B2L + 4 * g);
+                for (int k = 0; k < K::NLD; ++k) hv[k] = rxch[k] != ~0u ? src[rsrc[k]] : 0.0f;
+            } else {
+                const unsigned long long* const xs = a.xch + (size_t)(tt & 1) * a.xch_words;
+                for (int spins = 0;;) {
+                    bool stale = false;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc2[n] = bias;
-        }
-        float wa1[K::K1S], wa2[4];
-        f32x4 bias1;
-        auto fetch = [&](int m) {
-            const float* const w1m = W1L + m * K::K1S * 64 + lane;
-#pragma unroll
-            for (int s = 0; s < K::K1S; ++s) wa1[s] = w1m[s * 64];
-            const float* const w2m = W2L + (4 * m) * 64 + lane;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) wa2[r] = w2m[r * 64];
-            bias1 = *reinterpret_cast<const f32x4*>(B1L + 16 * m + 4 * g);
-        };
-        fetch(0);
-#pragma unroll 1
-        for (int m = 0; m < K::M1T; ++m) {
-            f32x4 acc1[NT];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc1[n] = bias1;
-#pragma unroll
-            for (int s = 0; s < K::K1S; ++s)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc1[n] = nca_mfma(wa1[s], P[n][s], acc1[n]);
-            float w2c[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) w2c[r] = wa2[r];
-            __builtin_amdgcn_sched_barrier(0);
-            if (m + 1 < K::M1T) fetch(m + 1);        // in flight across this tile's layer-2 MFMAs and the next chain
-            float h[NT][4];
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h[n][r] = __int_as_float(max(__float_as_int(acc1[n][r]), 0));   // relu
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc2[n] = nca_mfma(w2c[r], h[n][r], acc2[n]);
-        }
-        // residual + stochastic mask (dynca.py:131-133): state t+1 -> memory (write-through) and -> the next step's LDS tile
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const float mk = MK[r0[n] * PTW + q0[n]];
-            const size_t o0 = (size_t)(ty0 + r0[n]) * W + tx0 + q0[n];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ch = 4 * g + r;
-                if (ch < CP) {
-                    const int zo = ch * PCS + (r0[n] + 1) * PRS + q0[n] + 4;
-                    const float xn = Zc[zo] + acc2[n][r] * mk;
-                    Zn[zo] = ch < C ? xn : 0.0f;
-                    if (ch < C) st_through(dst + (size_t)ch * plane + o0, xn);
+                    for (int k = 0; k < K::NLD; ++k) {
+                        unsigned long long w = (unsigned long long)(unsigned)tt << 32;
+                        if (rxch[k] != ~0u) w = ld_pair(xs + rxch[k]);
+                        hv[k] = __uint_as_float((unsigned)w);
+                        stale = stale || (int)(w >> 32) != tt;
+                    }
+                    if (!__any(stale)) break;
+                    bool give_up = ++spins >= (1 << 15);      // (uniform: every lane counts every round)
+                    if ((spins & 31) == 0) give_up = give_up || __any(lane == 8 && __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+                    if (give_up) return false;
+                    __builtin_amdgcn_s_sleep(1);
                 }
             }
+#pragma unroll
+            for (int k = 0; k < K::NLD; ++k) {
+                const bool own = rsrc[k] != ~0u && (rsrc[k] & 0x80000000u);
+                if (rz[k] >= 0 && !own) Zt[rz[k]] = hv[k];
+            }
+            return true;
+        };
+        auto post_halo = [&](int value, bool stop_) {   // LDS operations of a wave execute in order: data, then the counter
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (lane == 0) {
+                if (stop_) __hip_atomic_store(lflag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(lflag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        // state 0: everything is in memory / the LDS tile already
+        stage_halo(0, true);
+        stage_halo(0, false);
+        post_halo(1, false);
+        bool stop = false;
+        for (int t = 0; t < a.T; ++t) {
+            // the compute waves are in step t: ring first (its pairs go out early), then the interior.  Meanwhile: the neighbours'
+            // rings of state t + 1 as soon as they arrive, into the OTHER LDS buffer's halo cells (nobody touches those in step t)
+            if (t + 1 < a.T) {
+                if (!(a.dbg & 1)) {
+                    stop = !stage_halo(t + 1, true);
+                    if (stop) {   // a neighbour never delivered (not resident?): record it, tell every workgroup to drain
+                        if (lane == 0) {
+                            if (a.err) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            }
+            __syncthreads();      // step t's LDS tile (state t + 1) is complete
+            if (t + 1 < a.T) {
+                if (!stop && !(a.dbg & 1)) stage_halo(t + 1, false);
+                post_halo(t + 2, stop);
+            }
+            if (stop) break;
         }
-        __builtin_amdgcn_s_waitcnt(0);      // this lane's stores have been acknowledged
-        __syncthreads();                    // ... and every lane's; Zn complete, Zc free
-        if (tid == 0) __hip_atomic_store(a.flags + tile, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        // =================================== compute waves ==================================================================
+        for (int t = 0; t < a.T; ++t) {
+            float* const dst = a.states + (size_t)((t + 1) & 1) * slot + (size_t)b * C * plane;
+            const float* const Zc = smem + K::OFF_Z + (t & 1) * (CP * PCS);
+            float* const Zn = smem + K::OFF_Z + ((t + 1) & 1) * (CP * PCS);
+            const float* const mkc = MK + (t & 1) * (PTH * PTW);
+            const bool last = t + 1 == a.T;
+            // one phase = NTP groups of 16 cells: perception -> MLP on MFMA -> residual
+            auto phase = [&](auto ntp_tag, int j0, bool ack) {
+                constexpr int NTP = decltype(ntp_tag)::value;
+                int rr[NTP], qq[NTP];
+#pragma unroll
+                for (int n = 0; n < NTP; ++n) group_cell(j0 + n, ci, rr[n], qq[n]);
+                float P[NTP][K::K1S];
+#pragma unroll
+                for (int cq4 = 0; cq4 < CP / 4; ++cq4) {
+                    const float* const zc = Zc + (4 * cq4 + g) * PCS + 3;
+#pragma unroll
+                    for (int n = 0; n < NTP; ++n) {
+                        float nbv[3][3];
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 3; ++dx) nbv[dy][dx] = zc[(rr[n] + dy) * PRS + qq[n] + dx];
+                        P[n][4 * cq4 + 0] = nbv[1][1];
+                        P[n][4 * cq4 + 1] = nca_sobel_x(nbv);
+                        P[n][4 * cq4 + 2] = nca_sobel_y(nbv);
+                        P[n][4 * cq4 + 3] = nca_laplacian(nbv);
+                    }
+                }
+                if (HAS_COND) {
+#pragma unroll
+                    for (int n = 0; n < NTP; ++n) P[n][CP] = CN[g * PTH * PTW + rr[n] * PTW + qq[n]];
+                }
+                f32x4 acc2[NTP];
+                {
+                    const f32x4 bias = *reinterpret_cast<const f32x4*>(B2L + 4 * g);
+#pragma unroll
+                    for (int n = 0; n < NTP; ++n) acc2[n] = bias;
+                }
+                float wa1[K::K1S], wa2[4];
+                f32x4 bias1;
+                auto fetch = [&](int m) {
+                    const float* const w1m = W1L + m * K::K1S * 64 + lane;
+#pragma unroll
+                    for (int s = 0; s < K::K1S; ++s) wa1[s] = w1m[s * 64];
+                    const float* const w2m = W2L + (4 * m) * 64 + lane;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) wa2[r] = w2m[r * 64];
+                    bias1 = *reinterpret_cast<const f32x4*>(B1L + 16 * m + 4 * g);
+                };
+                fetch(0);
+#pragma unroll 1
+                for (int m = 0; m < ((a.dbg & 16) ? 0 : K::M1T); ++m) {
+                    f32x4 acc1[NTP];
+#pragma unroll
+                    for (int n = 0; n < NTP; ++n) acc1[n] = bias1;
+#pragma unroll
+                    for (int s = 0; s < K::K1S; ++s)
+#pragma unroll
+                        for (int n = 0; n < NTP; ++n) acc1[n] = nca_mfma(wa1[s], P[n][s], acc1[n]);
+                    float w2c[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w2c[r] = wa2[r];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m + 1 < K::M1T) fetch(m + 1);        // in flight across this tile's layer-2 MFMAs and the next chain
+                    float h[NTP][4];
+#pragma unroll
+                    for (int n = 0; n < NTP; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h[n][r] = __int_as_float(max(__float_as_int(acc1[n][r]), 0));   // relu
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int n = 0; n < NTP; ++n) acc2[n] = nca_mfma(w2c[r], h[n][r], acc2[n]);
+                }
+                // residual + stochastic mask (dynca.py:131-133): state t+1 -> the next step's LDS tile; ring cells (what the
+                // neighbours read) -> memory every step, write-through; everything -> memory at the final step
+#pragma unroll
+                for (int n = 0; n < NTP; ++n) {
+                    const float mk = mkc[rr[n] * PTW + qq[n]];
+                    const bool ring = rr[n] == 0 || rr[n] == PTH - 1 || qq[n] == 0 || qq[n] == PTW - 1;
+                    const size_t o0 = (size_t)(ty0 + rr[n]) * W + tx0 + qq[n];
+                    unsigned long long* const xd = a.xch + (size_t)((t + 1) & 1) * a.xch_words + (size_t)tile * C * kRingCells +
+                                                   (ring ? ring_index(rr[n], qq[n]) : 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ch = 4 * g + r;
+                        if (ch < CP) {
+                            const int zo = ch * PCS + (rr[n] + 1) * PRS + qq[n] + 4;
+                            const float xn = Zc[zo] + acc2[n][r] * mk;
+                            Zn[zo] = ch < C ? xn : 0.0f;
+                            if (ch < C && !(a.dbg & 2)) {
+                                if (last) dst[(size_t)ch * plane + o0] = xn;
+                                else if (ring) st_pair(xd + ch * kRingCells, xn, t + 1);
+                            }
+                        }
+                    }
+                }
+            };
+            bool stop;
+            {   // the halo of state t is in the LDS tile (bounded poll of the sync wave's LDS counter)
+                int spins = 0;
+                while (__hip_atomic_load(lflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                stop = __hip_atomic_load(lflag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+            }
+            if (stop) break;
+            // the tile's border ring first (+ 4 left-over interior cells): its stores are what the neighbours wait for
+            if (!(a.dbg & 4)) phase(std::integral_constant<int, 1>{}, 12 + wave, false);
+            // the next step's fire masks: one cell per compute thread (in the sync wave -- four Philox evaluations per lane -- they
+            // cost the SIMD it shares with compute wave 0 a microsecond per step)
+            if (!last && !(a.dbg & 8)) fill_mask(t + 1, tid, 256);
+            // the interior needs no halo and hides the exchange: ring pairs stored -> fetched by the neighbours
+            phase(std::integral_constant<int, 3>{}, 3 * wave, true);
+            __syncthreads();                    // Zn complete, Zc free
+        }
+        __builtin_amdgcn_s_waitcnt(0);   // the final step's stores (the whole tile)
     }
 }
 
@@ -280,12 +431,17 @@ template <int CP, int FC, bool HAS_COND>
 hipError_t launch_persist(const NcaDyncaPersistArgs& a, hipStream_t st, bool query_only, bool* fits) {
     using K = PersistCfg<CP, FC, HAS_COND>;
     auto kern = dynca_persist_kernel<CP, FC, HAS_COND>;
-    const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
+    // more than half a CU's LDS: ONE workgroup per CU (two tiles on one CU would share its matrix pipes while another CU idles)
+    const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float) > 81 * 1024 ? (size_t)K::LDS_FLOATS * sizeof(float) : (size_t)81 * 1024;
     static NcaLdsAttr attr;
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
     const int ntiles = a.B * (a.H / PTH) * (a.W / PTW);
-    int per_cu = 0;
-    if (hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kPT, lds); e != hipSuccess) return e;
+    static std::atomic<int> occ[kNcaMaxDevices];     // workgroups per CU of this instantiation (queried once per device)
+    int per_cu = occ[nca_device_index()].load(std::memory_order_relaxed);
+    if (per_cu == 0) {
+        if (hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kPT, lds); e != hipSuccess) return e;
+        occ[nca_device_index()].store(per_cu > 0 ? per_cu : -1, std::memory_order_relaxed);
+    }
     *fits = (long)per_cu * nca_cu_count() >= ntiles;      // every workgroup must be resident at once (neighbours wait for each other)
     if (!*fits || query_only) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(kPT), lds, st, a);
@@ -304,6 +460,8 @@ int nca_dynca_persist_tiles(int B, int H, int W) { return B * (H / PTH) * (W / P
 hipError_t nca_launch_dynca_persist(const NcaDyncaPersistArgs& a_in, hipStream_t st, bool query_only, bool* fits) {
     NcaDyncaPersistArgs a = a_in;
     a.err = nca_error_word_device();
+    static const int dbg = getenv("NCAHIP_PERSIST_DBG") ? atoi(getenv("NCAHIP_PERSIST_DBG")) : 0;
+    a.dbg = dbg;
     const bool small = a.C <= 12 && a.fc <= 96;
     if (a.c_cond > 0) return small ? launch_persist<12, 96, true>(a, st, query_only, fits) : launch_persist<16, 128, true>(a, st, query_only, fits);
     return small ? launch_persist<12, 96, false>(a, st, query_only, fits) : launch_persist<16, 128, false>(a, st, query_only, fits);

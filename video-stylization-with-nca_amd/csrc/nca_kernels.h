@@ -70,7 +70,7 @@ struct NcaDyncaArgs {
     int u_bits;               // u points at bit-packed fire masks (uint32 words, cell i -> bit i & 31 of word i >> 5; B*H*W < 2^32)
 };
 
-// T DyNCA steps in one launch (nca_dynca_persist.hip): one workgroup per 8 x 32 tile for all steps, neighbour counters in `flags`
+// T DyNCA steps in one launch (nca_dynca_persist.hip): one workgroup per 16 x 16 tile for all steps, neighbour counters in `flags`
 struct NcaDyncaPersistArgs {
     float* states;       // two slots of B*C*H*W floats: slot 0 = input state, step t reads slot t % 2 and writes slot (t + 1) % 2
     int T;
@@ -80,9 +80,13 @@ struct NcaDyncaPersistArgs {
     int B, C, H, W, fc, c_cond, pad_mode;
     float rate;
     uint64_t seed, step0;
-    int* flags;          // one step counter per tile, zero at launch
+    int* flags;          // [0] = abort word, zero at launch
+    unsigned long long* xch;   // ring exchange: [2 parities][tile][C][60 ring cells] (value, step) pairs, zero at launch
+    size_t xch_words;          // pairs per parity
     unsigned* err;       // sticky error word (bit 1: a neighbour poll expired)
     int u_bits;
+    int dbg;             // diagnostic knobs (NCAHIP_PERSIST_DBG, timing experiments only -- results are then NOT valid): bit 0 no neighbour
+                         // polls / halo loads, bit 1 no state stores, bit 2 no ring phase, bit 3 no mask refill, bit 4 no MFMA chains
 };
 bool nca_dynca_persist_shape_ok(int B, int C, int H, int W, int fc, int c_cond);
 int nca_dynca_persist_tiles(int B, int H, int W);
