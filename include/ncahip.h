@@ -387,6 +387,9 @@ int ncahip_cond_grow_bwd_bf16(const uint16_t *states, const uint8_t *pre, int T,
  * expire: the launch still drains, bit 1 of the sticky device error word is set and ncahip_check_errors / the next driver call
  * report NCAHIP_EDEVICE (the states are then not valid). */
 size_t ncahip_dynca_nsteps_persist_workspace(int B, int C, int H, int W, int fc, int c_cond);
+/* Test hook: the next persistent launches leave out their last n tiles -- what a workgroup that never becomes resident looks
+ * like to its neighbours (their bounded polls expire; the launch drains; NCAHIP_EDEVICE).  0 restores normal launches. */
+int ncahip_debug_persist_drop_tiles(int n);
 int ncahip_dynca_nsteps_fwd_persist_f32(float *states, int T, const float *cond, const float *u,
                                         const float *w1, const float *b1, const float *w2, const float *b2,
                                         int B, int C, int H, int W, int fc, int c_cond, int pad_mode,

@@ -143,3 +143,28 @@ def test_video_module_runs_the_persistent_kernel(ops):
         ops.persistent_steps = True
     assert seen == [0] and torch.equal(a, b) and rgb.shape == (1, 3, 256, 256)
     ops.check_errors()
+
+
+def test_missing_neighbour_drains_and_reports(ops):
+    """A workgroup that never runs (test hook: the launch leaves out its last tiles) must not hang the others: their bounded polls
+    expire, every workgroup leaves its step loop, the sticky error word carries bit 1, ncahip_check_errors raises and clears it,
+    and the next launch is healthy again."""
+    from ncahip._capi import NcaHipError
+    gen = torch.Generator().manual_seed(11)
+    prm = _prm(12, 96, 0, seed=3)
+    x = (torch.rand(1, 12, 64, 64, generator=gen) - 0.5).to(DEV)
+    w = ops.DyncaWeights(prm["w1.weight"], prm["w1.bias"], prm["w2.weight"], prm["w2.bias"], x)
+    ops.check_errors()
+    ops.persistent_steps = True
+    L = ops.lib()
+    assert L.ncahip_debug_persist_drop_tiles(3) == 0
+    try:
+        ops.dynca_nsteps(x, 6, None, None, w, "circular", 0.5, seed=1)
+        torch.cuda.synchronize()                       # returns: the launch drained
+        with pytest.raises(NcaHipError, match="neighbour poll"):
+            ops.check_errors()
+    finally:
+        L.ncahip_debug_persist_drop_tiles(0)
+    ops.check_errors()                                  # cleared
+    ref, got = _both(ops, x, 6, None, None, w, "circular", 0.5, seed=1)
+    assert torch.equal(ref, got)

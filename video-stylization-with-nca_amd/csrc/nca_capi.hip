@@ -142,6 +142,11 @@ int ncahip_debug_inject_error(unsigned bits) {   // test hook: what a kernel doe
     return 0;
 }
 
+int ncahip_debug_persist_drop_tiles(int n) {   // test hook: see nca_set_persist_drop_tiles
+    nca_set_persist_drop_tiles(n < 0 ? 0 : n);
+    return 0;
+}
+
 int ncahip_version(void) { return NCAHIP_VERSION; }
 const char* ncahip_last_error(void) { return g_err; }
 

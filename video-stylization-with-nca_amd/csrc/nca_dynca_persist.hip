@@ -29,6 +29,9 @@
 
 #include "nca_kernels.h"
 
+static int g_drop_tiles = 0;
+void nca_set_persist_drop_tiles(int n) { g_drop_tiles = n; }
+
 namespace {
 
 constexpr int kPT = 320;                     // 4 compute waves + 1 sync wave
@@ -444,7 +447,10 @@ hipError_t launch_persist(const NcaDyncaPersistArgs& a, hipStream_t st, bool que
     }
     *fits = (long)per_cu * nca_cu_count() >= ntiles;      // every workgroup must be resident at once (neighbours wait for each other)
     if (!*fits || query_only) return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(kPT), lds, st, a);
+    // test hook (ncahip_debug_persist_drop_tiles): launch only the first tiles -- the others' neighbours never hear from them, their
+    // bounded polls expire, the launch drains and the sticky error word carries bit 1: what a non-resident workgroup looks like
+    const int grid = g_drop_tiles > 0 && g_drop_tiles < ntiles ? ntiles - g_drop_tiles : ntiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPT), lds, st, a);
     return hipGetLastError();
 }
 

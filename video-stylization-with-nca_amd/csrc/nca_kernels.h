@@ -88,6 +88,7 @@ struct NcaDyncaPersistArgs {
     int dbg;             // diagnostic knobs (NCAHIP_PERSIST_DBG, timing experiments only -- results are then NOT valid): bit 0 no neighbour
                          // polls / halo loads, bit 1 no state stores, bit 2 no ring phase, bit 3 no mask refill, bit 4 no MFMA chains
 };
+void nca_set_persist_drop_tiles(int n);   // test hook: the persistent launch leaves out its last n tiles (their neighbours' polls expire)
 bool nca_dynca_persist_shape_ok(int B, int C, int H, int W, int fc, int c_cond);
 int nca_dynca_persist_tiles(int B, int H, int W);
 // query_only: only decide whether every workgroup can be co-resident on the current device (*fits)
