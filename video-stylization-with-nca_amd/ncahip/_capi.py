@@ -92,6 +92,10 @@ def lib():
             raise NcaHipError(
                 f"libncahip.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C video-stylization-with-nca_amd`).  There is no CPU fallback for the NCA step.")
+        # PyTorch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's).  The runtime that is loaded FIRST serves the whole
+        # process: if libncahip.so pulled in /opt/rocm's before torch loaded its own, there would be two runtimes and ours would see
+        # "no ROCm-capable device" once torch has initialised the GPU.  Importing torch first makes its runtime the one we bind to.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here == header and library out of sync
