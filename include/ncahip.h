@@ -376,25 +376,28 @@ int ncahip_cond_grow_bwd_bf16(const uint16_t *states, const uint8_t *pre, int T,
                               void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
 
 /* ---- T DyNCA steps in ONE launch (B = 1 video inference) --------------------------------------------------------------
- * ConditioneDyNCA/utils/misc/video_utils.py:50-82 (forward_nsteps(h, step_n, cond_img=frame) per frame; WebGL twin
- * docs/dynca.js:1057-1132).  Same result, bit for bit, as ncahip_dynca_nsteps_fwd_f32 with ring = 2 (slot 0 = input, the
- * final state ends in slot T % 2), but every 16 x 16 tile is owned by one workgroup for all T steps: weights and conditioning
- * staged once, the tile's state kept in LDS, only the one-cell halo re-read per step, neighbours synchronised through per-tile
- * step counters (in `workspace`) with bounded polls.  Covered: C <= 16, fc <= 128, H % 16 == 0, W % 16 == 0, and every tile's
- * workgroup resident at once (occupancy x CUs >= B * H/16 * W/16: 1 x 256 x 256 is exactly one per CU of an MI355X);
- * NCAHIP_ERANGE otherwise -- the caller then runs ncahip_dynca_nsteps_fwd_f32.  ncahip_dynca_nsteps_persist_workspace returns
- * 0 for shapes that are never covered.  A neighbour that never becomes resident (another process holding CUs) makes a poll
+ * ConditioneDyNCA/utils/misc/video_utils.py:50-82 (forward_nsteps(h, step_n, cond_img=frame) per frame, step_n = 8 by default;
+ * WebGL twin docs/dynca.js:1057-1132).  x_out = the state after T steps from x_in (x_in != x_out), bit for bit what
+ * ncahip_dynca_nsteps_fwd_f32 computes, but every 16 x 16 tile is owned by one workgroup for all T steps: weights and
+ * conditioning staged once, the tile's state kept in LDS, only the one-cell halo exchanged per step -- as (value, tag) pairs in
+ * `workspace`, tag = epoch * 4096 + step, so neighbours need no counters and the call is ONE launch (no copy, no memset).
+ * Workspace contract: ncahip_dynca_nsteps_persist_workspace bytes, 256-byte aligned, ZEROED ONCE by the caller when allocated;
+ * every call on it passes a strictly larger `epoch` than the one before (1, 2, ... < 2^20; zero it again and restart at 1 when
+ * that runs out) -- stale pairs of earlier launches then never match.  Covered: C <= 16, fc <= 128, H % 16 == 0, W % 16 == 0,
+ * T < 4096, and every tile's workgroup resident at once (occupancy x CUs >= B * H/16 * W/16: 1 x 256 x 256 is exactly one per CU
+ * of an MI355X); NCAHIP_ERANGE otherwise -- the caller then runs ncahip_dynca_nsteps_fwd_f32.  The workspace query returns 0 for
+ * shapes that are never covered.  A neighbour that never becomes resident (another process holding CUs) makes a bounded poll
  * expire: the launch still drains, bit 1 of the sticky device error word is set and ncahip_check_errors / the next driver call
- * report NCAHIP_EDEVICE (the states are then not valid). */
+ * report NCAHIP_EDEVICE (x_out is then not valid). */
 size_t ncahip_dynca_nsteps_persist_workspace(int B, int C, int H, int W, int fc, int c_cond);
-/* Test hook: the next persistent launches leave out their last n tiles -- what a workgroup that never becomes resident looks
- * like to its neighbours (their bounded polls expire; the launch drains; NCAHIP_EDEVICE).  0 restores normal launches. */
-int ncahip_debug_persist_drop_tiles(int n);
-int ncahip_dynca_nsteps_fwd_persist_f32(float *states, int T, const float *cond, const float *u,
+int ncahip_dynca_nsteps_fwd_persist_f32(const float *x_in, float *x_out, int T, const float *cond, const float *u,
                                         const float *w1, const float *b1, const float *w2, const float *b2,
                                         int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
                                         float update_rate, uint64_t seed, uint64_t step0,
-                                        void *workspace, size_t workspace_bytes, ncahip_stream_t stream);
+                                        void *workspace, size_t workspace_bytes, unsigned epoch, ncahip_stream_t stream);
+/* Test hook: the next persistent launches leave out their last n tiles -- what a workgroup that never becomes resident looks
+ * like to its neighbours (their bounded polls expire; the launch drains; NCAHIP_EDEVICE).  0 restores normal launches. */
+int ncahip_debug_persist_drop_tiles(int n);
 
 /* ---- fire masks as bits --------------------------------------------------------------------------------------------
  * Every entry point above that takes `u` (the per-step uniform draws of nca.py:172 / dynca.py:131) also accepts the fire

@@ -237,30 +237,31 @@ size_t ncahip_dynca_nsteps_persist_workspace(int B, int C, int H, int W, int fc,
     return 256 + align256((size_t)2 * nca_dynca_persist_tiles(B, H, W) * C * 60 * sizeof(unsigned long long));
 }
 
-int ncahip_dynca_nsteps_fwd_persist_f32(float* states, int T, const float* cond, const float* u, const float* w1, const float* b1,
-                                        const float* w2, const float* b2, int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
-                                        float update_rate, uint64_t seed, uint64_t step0, void* workspace, size_t workspace_bytes,
-                                        ncahip_stream_t stream) {
+int ncahip_dynca_nsteps_fwd_persist_f32(const float* x_in, float* x_out, int T, const float* cond, const float* u, const float* w1,
+                                        const float* b1, const float* w2, const float* b2, int B, int C, int H, int W, int fc, int c_cond,
+                                        int pad_mode, float update_rate, uint64_t seed, uint64_t step0, void* workspace,
+                                        size_t workspace_bytes, unsigned epoch, ncahip_stream_t stream) {
     if (T < 1 || !workspace) return fail(NCAHIP_EINVAL, "dynca nsteps persist: T >= 1 and a workspace required");
-    if (int rc = check_dynca(states, states + 1, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;
+    if (epoch < 1 || epoch >= (1u << 20)) return fail(NCAHIP_EINVAL, "dynca nsteps persist: epoch must be in [1, 2^20) (zero the workspace and restart at 1 when it runs out)");
+    if (int rc = check_dynca(x_in, x_out, cond, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode)) return rc;   // (refuses x_in == x_out)
     const size_t need = ncahip_dynca_nsteps_persist_workspace(B, C, H, W, fc, c_cond);
-    if (need == 0) return fail(NCAHIP_ERANGE, "dynca nsteps persist: shape not covered (C <= 16, fc <= 128, H %% 16 == 0, W %% 16 == 0); use ncahip_dynca_nsteps_fwd_f32");
+    if (need == 0 || T >= 4096)
+        return fail(NCAHIP_ERANGE, "dynca nsteps persist: shape not covered (C <= 16, fc <= 128, H %% 16 == 0, W %% 16 == 0, T < 4096); use ncahip_dynca_nsteps_fwd_f32");
     if (workspace_bytes < need) return fail(NCAHIP_EINVAL, "dynca nsteps persist: workspace too small");
-    if (((uintptr_t)states & 15) != 0) return fail(NCAHIP_ERANGE, "dynca nsteps persist: 16-byte aligned states required");
+    if ((((uintptr_t)x_in | (uintptr_t)x_out) & 15) != 0) return fail(NCAHIP_ERANGE, "dynca nsteps persist: 16-byte aligned states required");
+    if (((uintptr_t)workspace & 255) != 0) return fail(NCAHIP_ERANGE, "dynca nsteps persist: 256-byte aligned workspace required");
     const bool ubits = u_is_bits(u, seed);
     if (int rc = check_bits(ubits, B, H, W, update_rate, true)) return rc;
     if (int rc = device_error_rc("dynca nsteps persist")) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (((uintptr_t)workspace & 255) != 0) return fail(NCAHIP_ERANGE, "dynca nsteps persist: 256-byte aligned workspace required");
-    NcaDyncaPersistArgs a{states, T, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step0,
-                          (int*)workspace, (unsigned long long*)((char*)workspace + 256), (size_t)nca_dynca_persist_tiles(B, H, W) * C * 60,
-                          nullptr, ubits ? 1 : 0};
+    NcaDyncaPersistArgs a{x_in, x_out, T, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step0,
+                          (int*)workspace, epoch, (unsigned long long*)((char*)workspace + 256),
+                          (size_t)nca_dynca_persist_tiles(B, H, W) * C * 60, nullptr, ubits ? 1 : 0};
     bool fits = false;
     if (int rc = hip_result(nca_launch_dynca_persist(a, st, true, &fits), "dynca nsteps persist (occupancy)")) return rc;
     if (!fits) return fail(NCAHIP_ERANGE, "dynca nsteps persist: %d tiles cannot all be resident on this device; use ncahip_dynca_nsteps_fwd_f32",
                            nca_dynca_persist_tiles(B, H, W));
-    if (int rc = hip_result(hipMemsetAsync(workspace, 0, need, st), "dynca nsteps persist memset")) return rc;
-    return hip_result(nca_launch_dynca_persist(a, st, false, &fits), "dynca_nsteps_fwd_persist");
+    return hip_result(nca_launch_dynca_persist(a, st, false, &fits), "dynca_nsteps_fwd_persist");     // ONE launch: no copy, no memset
 }
 
 // ---- conditioning front ends (fixed-filter part of the encoders) ---------------------------------------------------------

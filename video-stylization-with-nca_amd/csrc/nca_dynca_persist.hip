@@ -115,7 +115,8 @@ __global__ __launch_bounds__(kPT, 1) void dynca_persist_kernel(const NcaDyncaPer
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, ci = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C = a.C, H = a.H, W = a.W, fc = a.fc, CC = a.c_cond, K1 = 4 * C + CC;
-    const size_t plane = (size_t)H * W, slot = (size_t)a.B * C * plane;
+    const size_t plane = (size_t)H * W;
+    const unsigned tag0 = a.epoch << 12;     // (value, tag) pairs: tag = epoch * 4096 + step: stale pairs of earlier launches never match
     const int tiles_x = W / PTW, tiles_y = H / PTH;
     const int tile = blockIdx.x, txi = tile % tiles_x, tyi = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int ty0 = tyi * PTH, tx0 = txi * PTW;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(kPT, 1) void dynca_persist_kernel(const NcaDyncaPer
     // the tile's cells at step 0 (plain loads: written before the launch)
     {
         float* const Z0 = smem + K::OFF_Z;
-        const float* const xb = a.states + (size_t)b * C * plane;
+        const float* const xb = a.x_in + (size_t)b * C * plane;
         for (int i = tid; i < CP * PTH * (PTW / 4); i += kPT) {
             const int f4 = i % (PTW / 4), r = (i / (PTW / 4)) % PTH, ch = i / (PTH * (PTW / 4));
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(kPT, 1) void dynca_persist_kernel(const NcaDyncaPer
                 return true;
             }
             if (tt == 0) {
-                const float* const src = a.states + (size_t)b * C * plane;
+                const float* const src = a.x_in + (size_t)b * C * plane;
 #pragma unroll
                 for (int k = 0; k < K::NLD; ++k) hv[k] = rxch[k] != ~0u ? src[rsrc[k]] : 0.0f;
             } else {
@@ -254,14 +255,14 @@ __global__ __launch_bounds__(kPT, 1) void dynca_persist_kernel(const NcaDyncaPer
                     bool stale = false;
 #pragma unroll
                     for (int k = 0; k < K::NLD; ++k) {
-                        unsigned long long w = (unsigned long long)(unsigned)tt << 32;
+                        unsigned long long w = (unsigned long long)(tag0 + (unsigned)tt) << 32;
                         if (rxch[k] != ~0u) w = ld_pair(xs + rxch[k]);
                         hv[k] = __uint_as_float((unsigned)w);
-                        stale = stale || (int)(w >> 32) != tt;
+                        stale = stale || (unsigned)(w >> 32) != tag0 + (unsigned)tt;
                     }
                     if (!__any(stale)) break;
                     bool give_up = ++spins >= (1 << 15);      // (uniform: every lane counts every round)
-                    if ((spins & 31) == 0) give_up = give_up || __any(lane == 8 && __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+                    if ((spins & 31) == 0) give_up = give_up || __any(lane == 8 && (unsigned)__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch);
                     if (give_up) return false;
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(kPT, 1) void dynca_persist_kernel(const NcaDyncaPer
                     if (stop) {   // a neighbour never delivered (not resident?): record it, tell every workgroup to drain
                         if (lane == 0) {
                             if (a.err) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(abort_w, (int)a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
                 }
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(kPT, 1) void dynca_persist_kernel(const NcaDyncaPer
     } else {
         // =================================== compute waves ==================================================================
         for (int t = 0; t < a.T; ++t) {
-            float* const dst = a.states + (size_t)((t + 1) & 1) * slot + (size_t)b * C * plane;
+            float* const dst = a.x_out + (size_t)b * C * plane;      // (written at the final step only)
             const float* const Zc = smem + K::OFF_Z + (t & 1) * (CP * PCS);
             float* const Zn = smem + K::OFF_Z + ((t + 1) & 1) * (CP * PCS);
             const float* const mkc = MK + (t & 1) * (PTH * PTW);
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(kPT, 1) void dynca_persist_kernel(const NcaDyncaPer
                             Zn[zo] = ch < C ? xn : 0.0f;
                             if (ch < C && !(a.dbg & 2)) {
                                 if (last) dst[(size_t)ch * plane + o0] = xn;
-                                else if (ring) st_pair(xd + ch * kRingCells, xn, t + 1);
+                                else if (ring) st_pair(xd + ch * kRingCells, xn, (int)(tag0 + (unsigned)(t + 1)));
                             }
                         }
                     }

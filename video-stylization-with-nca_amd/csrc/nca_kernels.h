@@ -72,16 +72,18 @@ struct NcaDyncaArgs {
 
 // T DyNCA steps in one launch (nca_dynca_persist.hip): one workgroup per 16 x 16 tile for all steps, neighbour counters in `flags`
 struct NcaDyncaPersistArgs {
-    float* states;       // two slots of B*C*H*W floats: slot 0 = input state, step t reads slot t % 2 and writes slot (t + 1) % 2
-    int T;
+    const float* x_in;   // [B,C,H,W] input state (read at step 0 only)
+    float* x_out;        // [B,C,H,W] state after T steps (written at the last step only; may alias x_in? no: tiles read neighbours' x_in cells)
+    int T;               // 1 <= T < 4096
     const float* cond;   // [B,c_cond,H,W] or null
     const float* u;      // [T][B*H*W] uniforms / [T][ceil(B*H*W/32)] mask words (u_bits) / null: Philox (seed, step0 + t)
     const float *w1, *b1, *w2, *b2;
     int B, C, H, W, fc, c_cond, pad_mode;
     float rate;
     uint64_t seed, step0;
-    int* flags;          // [0] = abort word, zero at launch
-    unsigned long long* xch;   // ring exchange: [2 parities][tile][C][60 ring cells] (value, step) pairs, zero at launch
+    int* flags;          // [0] = abort word: holds the epoch of a launch that gave up
+    unsigned epoch;            // strictly increasing per workspace (1 .. 2^20 - 1): tags of the exchanged pairs are epoch * 4096 + step
+    unsigned long long* xch;   // ring exchange: [2 parities][tile][C][60 ring cells] (value, tag) pairs; zero once, never cleared between launches
     size_t xch_words;          // pairs per parity
     unsigned* err;       // sticky error word (bit 1: a neighbour poll expired)
     int u_bits;

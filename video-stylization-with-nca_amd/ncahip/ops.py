@@ -42,9 +42,26 @@ def _workspace(nbytes: int, device: torch.device) -> torch.Tensor:
     return ws
 
 
+_PERSIST_WS = {}
+
+
+def _persist_workspace(nbytes: int, device: torch.device):
+    """(workspace, epoch) for ncahip_dynca_nsteps_fwd_persist_f32: a dedicated tensor per (device, stream, size), zeroed when it is
+    created and whenever its epoch counter runs out; every call gets the next epoch (the library never clears the workspace: the
+    exchanged pairs are tagged epoch * 4096 + step)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream(), nbytes)
+    ent = _PERSIST_WS.get(key)
+    if ent is None or ent[1] >= (1 << 20) - 2:
+        ent = [torch.zeros(nbytes, device=device, dtype=torch.uint8), 0]
+        _PERSIST_WS[key] = ent
+    ent[1] += 1
+    return ent[0], ent[1]
+
+
 def release_workspaces() -> None:
-    """Drop the cached backward workspaces (they are re-created on the next backward)."""
+    """Drop the cached workspaces (they are re-created on the next use)."""
     _WS_CACHE.clear()
+    _PERSIST_WS.clear()
 
 
 def _state_dtype(x: torch.Tensor):
@@ -240,22 +257,23 @@ def dynca_nsteps(x: torch.Tensor, T: int, cond: Optional[torch.Tensor], us: Opti
         cond = _dev(cond, "cond")
     us, seed = _u_args(us, T, B, H, W, seed)
     assert w.c == C and w.k1 == 4 * C + c_cond, (w.c, w.k1, C, c_cond)
-    ring = T + 1 if keep_history else 2
-    states = torch.empty(ring, B, C, H, W, device=x.device, dtype=dt)
-    states[0].copy_(x)
-    if not keep_history and not two_scale and sfx == "f32" and T >= 2 and persistent_steps:
+    if not keep_history and not two_scale and sfx == "f32" and persistent_steps:
         # small grids (B = 1 video inference): all T steps in ONE launch, one workgroup per tile (ncahip_dynca_nsteps_fwd_persist_f32);
         # NCAHIP_ERANGE = shape not covered or not every tile resident on this device -> the per-step kernels below
         nbytes = lib().ncahip_dynca_nsteps_persist_workspace(B, C, H, W, w.fc, c_cond)
         if nbytes:
-            ws = _workspace(nbytes, x.device)
-            rc = lib().ncahip_dynca_nsteps_fwd_persist_f32(_p(states), T, _p(cond), _p(us), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C,
+            ws, epoch = _persist_workspace(nbytes, x.device)
+            out = torch.empty_like(x)
+            rc = lib().ncahip_dynca_nsteps_fwd_persist_f32(_p(x), _p(out), T, _p(cond), _p(us), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C,
                                                             H, W, w.fc, c_cond, PAD_MODES[pad_mode], update_rate, seed, step0, _p(ws),
-                                                            nbytes, _stream())
+                                                            nbytes, epoch, _stream())
             if rc == 0:
-                return states[T % 2], states
+                return out, None
             if rc != _capi.ERANGE:
                 check(rc, "dynca_nsteps_fwd_persist")
+    ring = T + 1 if keep_history else 2
+    states = torch.empty(ring, B, C, H, W, device=x.device, dtype=dt)
+    states[0].copy_(x)
     if two_scale:
         assert sfx == "f32", "the two-scale step is an fp32 kernel"
         pc = torch.empty(B, 4 * C, H // 2, W // 2, device=x.device, dtype=torch.float32)
