@@ -395,6 +395,14 @@ int ncahip_dynca_nsteps_fwd_persist_f32(const float *x_in, float *x_out, int T, 
                                         int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
                                         float update_rate, uint64_t seed, uint64_t step0,
                                         void *workspace, size_t workspace_bytes, unsigned epoch, ncahip_stream_t stream);
+/* The same for perception_scales = [0, 1] (every shipped video model; dynca.py:75-115): bit for bit what
+ * ncahip_dynca_nsteps_fwd_ms_f32 computes.  Tiles additionally exchange the 2 x 2 means of their coarse cells within 2 of the
+ * border; same workspace, epoch and coverage rules. */
+int ncahip_dynca_nsteps_fwd_persist_ms_f32(const float *x_in, float *x_out, int T, const float *cond, const float *u,
+                                           const float *w1, const float *b1, const float *w2, const float *b2,
+                                           int B, int C, int H, int W, int fc, int c_cond, int pad_mode,
+                                           float update_rate, uint64_t seed, uint64_t step0,
+                                           void *workspace, size_t workspace_bytes, unsigned epoch, ncahip_stream_t stream);
 /* Test hook: the next persistent launches leave out their last n tiles -- what a workgroup that never becomes resident looks
  * like to its neighbours (their bounded polls expire; the launch drains; NCAHIP_EDEVICE).  0 restores normal launches. */
 int ncahip_debug_persist_drop_tiles(int n);

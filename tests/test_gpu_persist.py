@@ -60,6 +60,41 @@ def test_persistent_equals_per_step_bit_for_bit(ops, pad, C, fc, cc, shape):
         assert torch.equal(ref, got), (pad, C, fc, shape, Tn, mode, float((ref - got).abs().max()))
 
 
+@pytest.mark.parametrize("pad", ["replicate", "circular", "reflect", "constant"])
+@pytest.mark.parametrize("C,fc,cc,shape", [(12, 96, 2, (1, 64, 64)), (16, 128, 3, (2, 32, 48)), (8, 64, 0, (1, 16, 16)), (12, 96, 2, (1, 256, 256))])
+def test_persistent_two_scale_equals_per_step_bit_for_bit(ops, pad, C, fc, cc, shape):
+    """perception_scales = [0, 1] (every shipped video model): the one-launch kernel against coarse-perceive + fused step launches."""
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(C + H + len(pad) + 1)
+    prm = _prm(C, fc, cc, seed=C + cc + 1, scale=2.0)
+    x = (torch.rand(B, C, H, W, generator=gen) - 0.5).to(DEV)
+    cond = (torch.rand(B, cc, H, W, generator=gen) * 2 - 1).to(DEV) if cc else None
+    w = ops.DyncaWeights(prm["w1.weight"], prm["w1.bias"], prm["w2.weight"], prm["w2.bias"], x)
+    for Tn, mode in ((1, "u"), (6, "philox"), (2, "bits"), (19, "u")):
+        us = None
+        if mode != "philox":
+            us = torch.rand(Tn, B, 1, H, W, generator=gen).to(DEV)
+            if mode == "bits":
+                us = ops.pack_fire_mask(us, 0.5, "dynca")
+        ref, got = _both(ops, x, Tn, cond, us, w, pad, 0.5, seed=78, step0=3, two_scale=True)
+        assert torch.equal(ref, got), (pad, C, fc, shape, Tn, mode, float((ref - got).abs().max()))
+
+
+def test_persistent_two_scale_vs_oracle(ops):
+    gen = torch.Generator().manual_seed(13)
+    prm = _prm(12, 96, 2, seed=4, scale=2.0)
+    x = torch.rand(1, 12, 32, 48, generator=gen) - 0.5
+    cond = O.cpe2d(1, 32, 48)
+    us = torch.rand(7, 1, 1, 32, 48, generator=gen)
+    for pad in ("circular", "replicate"):
+        ref = O.dynca_nsteps(x, cond, list(us), prm, pad, 0.5, scales=(0, 1))
+        w = ops.DyncaWeights(prm["w1.weight"], prm["w1.bias"], prm["w2.weight"], prm["w2.bias"], x.to(DEV))
+        ops.persistent_steps = True
+        got, _ = ops.dynca_nsteps(x.to(DEV), 7, cond.to(DEV), us.to(DEV), w, pad, 0.5, two_scale=True)
+        ops.check_errors()
+        assert rel_err(got, ref) < REL_TOL, pad
+
+
 def test_persistent_vs_oracle_and_rates(ops):
     gen = torch.Generator().manual_seed(3)
     prm = _prm(12, 96, 3, seed=1, scale=2.0)

@@ -178,7 +178,7 @@ def video_leg():
             cond = (torch.rand(1, 2, 256, 256, generator=gen) * 2 - 1).to(DEV)
             T = int(os.environ.get("NCAHIP_VIDEO_T", "32"))      # steps per frame (one forward_nsteps call)
             res = {}
-            for persist in ((True, False) if not two else (False,)):     # single-scale: the one-launch persistent kernel vs one launch per step
+            for persist in (True, False):     # the one-launch persistent kernel vs one launch per step
                 ops.persistent_steps = persist
                 (ms,), (mn,) = timed([lambda: ops.dynca_nsteps(x, T, cond, None, w, "circular", 0.5, seed=1, two_scale=two)], iters=20)
                 res["persistent" if persist else "per_step"] = (ms, mn)

@@ -233,11 +233,11 @@ int ncahip_dynca_nsteps_fwd_f32(float* states, int ring, int T, const float* con
 // ---- T steps in ONE launch for small grids (B = 1 video inference), nca_dynca_persist.hip -------------------------------------
 size_t ncahip_dynca_nsteps_persist_workspace(int B, int C, int H, int W, int fc, int c_cond) {
     if (!dims_ok(B, C, H, W) || !nca_dynca_persist_shape_ok(B, C, H, W, fc, c_cond)) return 0;
-    // abort word + the ring exchange: 2 parities x tiles x C x 60 ring cells of (value, step) pairs
-    return 256 + align256((size_t)2 * nca_dynca_persist_tiles(B, H, W) * C * 60 * sizeof(unsigned long long));
+    // abort word + the exchange: 2 parities x tiles x C x (60 fine ring cells + 48 coarse means) (value, tag) pairs
+    return 256 + align256((size_t)2 * nca_dynca_persist_tiles(B, H, W) * C * 108 * sizeof(unsigned long long));      // (sized for the two-scale exchange)
 }
 
-int ncahip_dynca_nsteps_fwd_persist_f32(const float* x_in, float* x_out, int T, const float* cond, const float* u, const float* w1,
+static int dynca_persist_impl(bool two_scale, const float* x_in, float* x_out, int T, const float* cond, const float* u, const float* w1,
                                         const float* b1, const float* w2, const float* b2, int B, int C, int H, int W, int fc, int c_cond,
                                         int pad_mode, float update_rate, uint64_t seed, uint64_t step0, void* workspace,
                                         size_t workspace_bytes, unsigned epoch, ncahip_stream_t stream) {
@@ -256,12 +256,28 @@ int ncahip_dynca_nsteps_fwd_persist_f32(const float* x_in, float* x_out, int T, 
     hipStream_t st = (hipStream_t)stream;
     NcaDyncaPersistArgs a{x_in, x_out, T, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step0,
                           (int*)workspace, epoch, (unsigned long long*)((char*)workspace + 256),
-                          (size_t)nca_dynca_persist_tiles(B, H, W) * C * 60, nullptr, ubits ? 1 : 0};
+                          (size_t)nca_dynca_persist_tiles(B, H, W) * C * (two_scale ? 108 : 60), nullptr, ubits ? 1 : 0};
     bool fits = false;
-    if (int rc = hip_result(nca_launch_dynca_persist(a, st, true, &fits), "dynca nsteps persist (occupancy)")) return rc;
+    auto launch = two_scale ? nca_launch_dynca_persist_ms : nca_launch_dynca_persist;
+    if (int rc = hip_result(launch(a, st, true, &fits), "dynca nsteps persist (occupancy)")) return rc;
     if (!fits) return fail(NCAHIP_ERANGE, "dynca nsteps persist: %d tiles cannot all be resident on this device; use ncahip_dynca_nsteps_fwd_f32",
                            nca_dynca_persist_tiles(B, H, W));
-    return hip_result(nca_launch_dynca_persist(a, st, false, &fits), "dynca_nsteps_fwd_persist");     // ONE launch: no copy, no memset
+    return hip_result(launch(a, st, false, &fits), "dynca_nsteps_fwd_persist");     // ONE launch: no copy, no memset
+}
+
+int ncahip_dynca_nsteps_fwd_persist_f32(const float* x_in, float* x_out, int T, const float* cond, const float* u, const float* w1,
+                                        const float* b1, const float* w2, const float* b2, int B, int C, int H, int W, int fc, int c_cond,
+                                        int pad_mode, float update_rate, uint64_t seed, uint64_t step0, void* workspace,
+                                        size_t workspace_bytes, unsigned epoch, ncahip_stream_t stream) {
+    return dynca_persist_impl(false, x_in, x_out, T, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step0,
+                              workspace, workspace_bytes, epoch, stream);
+}
+int ncahip_dynca_nsteps_fwd_persist_ms_f32(const float* x_in, float* x_out, int T, const float* cond, const float* u, const float* w1,
+                                           const float* b1, const float* w2, const float* b2, int B, int C, int H, int W, int fc,
+                                           int c_cond, int pad_mode, float update_rate, uint64_t seed, uint64_t step0, void* workspace,
+                                           size_t workspace_bytes, unsigned epoch, ncahip_stream_t stream) {
+    return dynca_persist_impl(true, x_in, x_out, T, cond, u, w1, b1, w2, b2, B, C, H, W, fc, c_cond, pad_mode, update_rate, seed, step0,
+                              workspace, workspace_bytes, epoch, stream);
 }
 
 // ---- conditioning front ends (fixed-filter part of the encoders) ---------------------------------------------------------

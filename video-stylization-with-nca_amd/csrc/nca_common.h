@@ -44,6 +44,18 @@ __device__ __forceinline__ float nca_laplacian(const float (&a)[3][3]) {
            2.0f * ((a[0][1] + a[2][1]) + (a[1][0] + a[1][2])) - 12.0f * a[1][1];
 }
 
+// Two-scale perception (dynca.py:98, :105-110): bilinear x2 up-sampling (align_corners = False) of the coarse-level value from its
+// four taps, then the mean over the two scales.  ONE definition with floating-point contraction off: the per-step kernel and the
+// persistent kernel must produce the same bits, and left to the optimiser the same source expression was contracted into different
+// fma / mul+add sequences in the two kernels (1-ulp differences on odd rows).
+__device__ __forceinline__ float nca_up2_blend(float fine, float q00, float q01, float q10, float q11, float h0, float h1, float w0, float w1) {
+#pragma clang fp contract(off)
+    const float top = w0 * q00 + w1 * q01;
+    const float bot = w0 * q10 + w1 * q11;
+    const float up = h0 * top + h1 * bot;
+    return (fine + up) / 2.0f;
+}
+
 // ---- Philox4x32-10 fire-mask stream (framework contract, restated in oracle/nca_oracle.py):
 // key = (seed_lo, seed_hi), counter = (cell >> 2, step_lo, step_hi, 'NCA'), word = cell & 3,
 // u = (word >> 8) * 2^-24.

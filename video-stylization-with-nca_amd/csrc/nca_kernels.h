@@ -95,6 +95,8 @@ bool nca_dynca_persist_shape_ok(int B, int C, int H, int W, int fc, int c_cond);
 int nca_dynca_persist_tiles(int B, int H, int W);
 // query_only: only decide whether every workgroup can be co-resident on the current device (*fits)
 hipError_t nca_launch_dynca_persist(const NcaDyncaPersistArgs& a, hipStream_t st, bool query_only, bool* fits);
+// two-scale perception (perception_scales = [0, 1]): exchanges 108 pairs per channel and tile (60 fine ring cells + 48 coarse means)
+hipError_t nca_launch_dynca_persist_ms(const NcaDyncaPersistArgs& a, hipStream_t st, bool query_only, bool* fits);
 
 struct NcaCondArgs {
     const float* x_in;

@@ -418,8 +418,7 @@ __global__ __launch_bounds__(kThreads, ((BWD && CP > 16) || MS) ? 1 : 2) void dy
 #pragma unroll
                         for (int f = 0; f < 4; ++f) {
                             const float* const q = pcp + f * CP * K::PCS;
-                            const float up = h0 * (w0 * q[0] + w1 * q[1]) + h1 * (w0 * q[K::PCR] + w1 * q[K::PCR + 1]);
-                            P[n][4 * cq4 + f] = (P[n][4 * cq4 + f] + up) / 2.0f;
+                            P[n][4 * cq4 + f] = nca_up2_blend(P[n][4 * cq4 + f], q[0], q[1], q[K::PCR], q[K::PCR + 1], h0, h1, w0, w1);
                         }
                     }
                 }

@@ -52,6 +52,8 @@ SIGNATURES = {
     "ncahip_dynca_nsteps_bwd_workspace": [_I, _I, _I, _I, _I, _I],
     "ncahip_dynca_nsteps_persist_workspace": [_I, _I, _I, _I, _I, _I],
     "ncahip_debug_persist_drop_tiles": [_I],
+    "ncahip_dynca_nsteps_fwd_persist_ms_f32": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P, ctypes.c_size_t,
+                                               ctypes.c_uint, _P],
     "ncahip_dynca_nsteps_fwd_persist_f32": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P, ctypes.c_size_t,
                                             ctypes.c_uint, _P],
     "ncahip_dynca_nsteps_bwd_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _U64, _P, _P, _P, _P, _P, _P, _P,

@@ -257,14 +257,15 @@ def dynca_nsteps(x: torch.Tensor, T: int, cond: Optional[torch.Tensor], us: Opti
         cond = _dev(cond, "cond")
     us, seed = _u_args(us, T, B, H, W, seed)
     assert w.c == C and w.k1 == 4 * C + c_cond, (w.c, w.k1, C, c_cond)
-    if not keep_history and not two_scale and sfx == "f32" and persistent_steps:
+    if not keep_history and sfx == "f32" and persistent_steps:
         # small grids (B = 1 video inference): all T steps in ONE launch, one workgroup per tile (ncahip_dynca_nsteps_fwd_persist_f32);
         # NCAHIP_ERANGE = shape not covered or not every tile resident on this device -> the per-step kernels below
         nbytes = lib().ncahip_dynca_nsteps_persist_workspace(B, C, H, W, w.fc, c_cond)
         if nbytes:
             ws, epoch = _persist_workspace(nbytes, x.device)
             out = torch.empty_like(x)
-            rc = lib().ncahip_dynca_nsteps_fwd_persist_f32(_p(x), _p(out), T, _p(cond), _p(us), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C,
+            fn = lib().ncahip_dynca_nsteps_fwd_persist_ms_f32 if two_scale else lib().ncahip_dynca_nsteps_fwd_persist_f32
+            rc = fn(_p(x), _p(out), T, _p(cond), _p(us), _p(w.w1), _p(w.b1), _p(w.w2), _p(w.b2), B, C,
                                                             H, W, w.fc, c_cond, PAD_MODES[pad_mode], update_rate, seed, step0, _p(ws),
                                                             nbytes, epoch, _stream())
             if rc == 0:
