@@ -235,7 +235,7 @@ struct DyncaCfg {
 // (dW2 = (G*mask) h^T, dW1 = dh y^T, K = all cells) are plain library GEMMs on those buffers.
 template <int CP, int FC, bool HAS_COND, int TH, int TW, int NT, bool VEC, bool BWD = false, bool B16 = false, bool ACC = false, bool W2F = false,
           bool MS = false>
-__global__ __launch_bounds__(kThreads, ((BWD && CP > 16) || MS) ? 1 : 2) void dynca_step_fwd_kernel(const NcaDyncaArgs a) {
+__global__ __launch_bounds__(kThreads, (CP > 16 || MS) ? 1 : 2) void dynca_step_fwd_kernel(const NcaDyncaArgs a) {   // CP > 16: 140 KB of LDS -> one workgroup per CU anyway: 512 registers
     static_assert(!MS || (!B16 && !ACC && TH % 2 == 0 && TW % 2 == 0 && (!BWD || W2F)), "the two-scale step: fp32, one hidden slice");
     static_assert(!W2F || BWD, "fused dW2 is an option of the backward kernel");
     static_assert(!ACC || !B16, "accumulating passes (fc slices beyond the first) read fp32 partial results");
@@ -1138,7 +1138,7 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 template <int CP, int FC, bool HAS_COND, bool VEC, bool B16 = false, bool ACC = false>
 hipError_t launch_dynca_v(const NcaDyncaArgs& a, hipStream_t st) {
-    constexpr int TH = 8, TW = 32, NT = CP > 16 ? 2 : 4;   // C = 32: 33 perception values per cell row -> two rows per pass
+    constexpr int TH = 8, TW = 32, NT = 4;   // (C = 32 ran two rows per pass while it was compiled for 256 registers)
     using K = DyncaCfg<CP, FC, HAS_COND, TH, TW, NT>;
     auto kern = dynca_step_fwd_kernel<CP, FC, HAS_COND, TH, TW, NT, VEC, false, B16, ACC>;
     const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
@@ -1323,7 +1323,7 @@ __device__ __forceinline__ void dynca_bwd_vec_block(const NcaDyncaArgs& a, unsig
 
 template <int CP, bool VEC>
 hipError_t launch_cond_v(const NcaCondArgs& a, hipStream_t st) {
-    constexpr int TH = 8, TW = 32, NT = CP > 16 ? 2 : 4;   // C > 16: 3C/4 perception values per cell row -> two rows per pass
+    constexpr int TH = 8, TW = 32, NT = 4;   // (C > 16 ran two rows per pass while it was compiled for 256 registers; one workgroup per CU has 512)
     using K = CondCfg<CP, TH, TW, NT>;
     auto kern = cond_step_fwd_kernel<CP, TH, TW, NT, VEC>;
     const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
