@@ -354,6 +354,32 @@ def dynca_gate_margin(x0, cond, us, prm, pad_mode, update_rate=0.5, scales=(0,))
     return best
 
 
+def dynca_gate_influence(x0, cond, us, prm, pad_mode, k, update_rate=0.5, scales=(0,)):
+    """As cond_gate_influence for the DyNCA step: (region [B,1,H,W] of dL/dx0 that a hidden pre-activation of an UPDATED cell within
+    relative margin k of zero can move -- Chebyshev distance t + 1 of the cell for a gate at step t, one more ring per coarser
+    perception scale; circular padding wraps --, number of such gates per item)."""
+    x = x0
+    region = torch.zeros(x0.shape[0], 1, x0.shape[2], x0.shape[3], dtype=torch.bool)
+    count = torch.zeros(x0.shape[0], dtype=torch.long)
+    reach = 1 if tuple(scales) == (0,) else 2 ** max(scales) * 2
+    with torch.no_grad():
+        for t, u in enumerate(us):
+            r = dynca_step(x, cond, u, prm, pad_mode, update_rate, scales, return_all=True)
+            pre = F.conv2d(r["y"], prm["w1.weight"], prm["w1.bias"])
+            bnd = F.conv2d(r["y"].abs(), prm["w1.weight"].abs(), prm["w1.bias"].abs())
+            near = (pre.abs() < k * bnd) & (r["m"] > 0)
+            count += near.flatten(1).sum(1)
+            amb = near.any(1, keepdim=True).float()
+            rad = (t + 1) * reach
+            if pad_mode == "circular":
+                padded = F.pad(amb, (rad, rad, rad, rad), mode="circular") if min(amb.shape[2:]) > rad else amb.new_ones(amb.shape[0], 1, amb.shape[2] + 2 * rad, amb.shape[3] + 2 * rad) * amb.amax((2, 3), keepdim=True)
+                region |= F.max_pool2d(padded, 2 * rad + 1, 1, 0) > 0
+            else:
+                region |= F.max_pool2d(amb, 2 * rad + 1, 1, rad) > 0
+            x = r["x"]
+    return region, count
+
+
 def dynca_nsteps_loss_grads(x0, cond, us, prm, pad_mode, update_rate, cot, scales=(0,)):
     x0 = x0.clone().requires_grad_(True)
     p = {k: prm[k].clone().requires_grad_(True) for k in ("w1.weight", "w1.bias", "w2.weight", "w2.bias")}

@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import nca_oracle as O
-from util import REL_TOL, T, grad_close, load, rel_err, sd
+from util import REL_TOL, T, grad_close, grads_match_outside, load, rel_err, sd
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -793,12 +793,16 @@ def test_dynca_backward_shape_fuzz(ops):
         if not ok:
             # Not skipped: a case that misses the max-norm bound must (i) agree in the forward, (ii) have a hidden
             # pre-activation of an updated cell within rounding of zero in the ORACLE's own trajectory (the gate may then
-            # legitimately resolve differently: see the helper), and (iii) still meet the large-problem bound (relative L2 1e-3,
-            # largest single deviation 5e-2) on every gradient -- a wrong slice offset or tile mapping fails that by orders of magnitude
+            # legitimately resolve differently: see the helper), (iii) agree at 2e-4 in dL/dx0 everywhere OUTSIDE the influence
+            # region of those gates (a wrong slice offset or tile mapping shows up there), and (iv) keep every weight gradient
+            # within 5 % relative L2 (in these small problems one hidden unit of one cell weighs up to ~1e-1 of a gradient entry)
             assert rel_err(states[-1].cpu(), xT) < 1e-5 and _dynca_gate_ambiguous(x0, cond, list(us), prm, pad), tag
-            for got, ref in ((gr["x0"], dx0), (gr["w1"], grads["w1.weight"][:, :, 0, 0]), (gr["b1"], grads["w1.bias"]),
+            region, count = O.dynca_gate_influence(x0, cond, list(us), prm, pad, 4e-6)
+            ok_out, n_out, n_in = grads_match_outside(gr["x0"], dx0, region)
+            assert int(count.sum()) > 0 and ok_out, tag + (n_out, n_in)
+            for got, ref in ((gr["w1"], grads["w1.weight"][:, :, 0, 0]), (gr["b1"], grads["w1.bias"]),
                              (gr["w2"], grads["w2.weight"][:, :, 0, 0]), (gr["b2"], grads["w2.bias"])):
-                assert grad_close(got, ref), tag
+                assert grad_close(got, ref, l2=5e-2, cap=2e-1), tag
             ambiguous += 1
     assert 7 * ambiguous <= ncases, (ambiguous, ncases)      # five seeds x 64 cases in round 2 showed at most 1 in 16
 
