@@ -4,6 +4,7 @@ HIP events on the launch stream).  `python tools/bench_paths.py [names...]`; wit
 
   cond_train      ConditionedNCA grow with history + backward, B=8 T=16 (fp32 and bf16 history)
   cond_c20        the reference's DEFAULT ConditionedNCA (C = 20, 16 hidden channels): forward, forward with history + fused backward
+  cond_small      the reference's default training shape (train.py: C = 20, 64 x 64, batch 8) and C = 16 at that size: launch-bound regime
   cfg3            BASELINE configs[2] shape: B=32 C=16 256^2 T=96, forward with history + backward, fp32 and bf16
   dynca_fwd       DyNCA forward steps: C=16/fc=128, C=12/fc=96, C=32/fc=128 and C=32/fc=256 at 2x512^2 (configs[4])
   dynca_train     DyNCA forward with history + backward (the C driver): C=16/fc=128, C=12/fc=96, C=32/fc=256 at 2x512^2
@@ -70,8 +71,8 @@ def cond_case(B, H=256, W=256, C=16, dtype=torch.float32):
     return x, goal, cot, w
 
 
-def cond_train(B, T, dtype, name, iters=10, C=16):
-    x, goal, cot, w = cond_case(B, C=C, dtype=dtype)
+def cond_train(B, T, dtype, name, iters=10, C=16, HW=256):
+    x, goal, cot, w = cond_case(B, H=HW, W=HW, C=C, dtype=dtype)
     box = {}
 
     def fwd():
@@ -82,9 +83,9 @@ def cond_train(B, T, dtype, name, iters=10, C=16):
         ops.cond_grow_backward(states, pre, goal, None, w, cot, T, 3, seed=1, step0=0)
 
     (tf, tb), (mf, mb) = timed([fwd, bwd], iters=iters)
-    cells = B * 256 * 256 * T
+    cells = B * HW * HW * T
     flop = 2 * (27 * C + 256 * C + 4096)      # forward flop per cell-update; the backward is ~2.4x that on MFMA
-    emit(path=name, C=C, storage=str(dtype).split(".")[-1], B=B, T=T, fwd_frac_f32_mfma=cells * flop / tf / 1e9 / 157.3, fwd_ms=tf, bwd_ms=tb, fwd_us_per_step=tf / T * 1e3,
+    emit(path=name, C=C, HW=HW, storage=str(dtype).split(".")[-1], B=B, T=T, fwd_frac_f32_mfma=cells * flop / tf / 1e9 / 157.3, fwd_ms=tf, bwd_ms=tb, fwd_us_per_step=tf / T * 1e3,
          bwd_us_per_step=tb / T * 1e3, fwd_bwd_Gcells_s=cells / (tf + tb) / 1e6, bwd_over_fwd=tb / tf,
          history_GB=(T + 1) * x.numel() * x.element_size() / 1e9, min_fwd_ms=mf, min_bwd_ms=mb)
 
@@ -199,6 +200,11 @@ def main(names):
     if allp or "cond_c20" in names:
         cond_train(8, 16, torch.float32, "cond_c20", C=20)
         cond_train(8, 16, torch.float32, "cond_c32", C=32)
+    if allp or "cond_small" in names:
+        # the reference's own DEFAULT training shape (EncoderConditioning/train.py:36-43: 16 hidden channels -> C = 20, 64 x 64, batch 8)
+        cond_train(8, 64, torch.float32, "cond_small_default", C=20, HW=64)
+        cond_train(8, 64, torch.float32, "cond_small", C=16, HW=64)
+        cond_train(8, 64, torch.bfloat16, "cond_small", C=16, HW=64)
     if allp or "cfg3" in names:
         cond_train(32, 96, torch.float32, "cfg3", iters=10)
         cond_train(32, 96, torch.bfloat16, "cfg3", iters=10)
