@@ -324,7 +324,7 @@ def main():
         ms_st = event_ms(lambda: ops.check(L.ncahip_dynca_perceive_f32(xd.data_ptr(), y.data_ptr(), B, C, H, W, 1, st), "perceive"), 200)
         gbs = cells * STENCIL_BYTES_PER_CELL / (ms_st * 1e-3) / 1e9
         tr_step = pmc_traffic("cond_step_fwd_pc_kernel", "StF32, false")
-        tr_st = pmc_traffic("dynca_perceive_kernel")
+        tr_st = pmc_traffic("dynca_perceive_rows_kernel")
         result = {
             "metric": "NCA cell-updates/sec (B*H*W*steps/s) at 256^2 C=16", "value": value, "unit": "cell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -339,7 +339,7 @@ def main():
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS,
                          "traffic": tr_step[0], "traffic_provenance": tr_step[1], "launch_ms": ms_launch, "flops_per_cell": FLOPS_PER_CELL,
                          "algorithmic_bytes_per_cell": BYTES_PER_CELL_STEP, "cells_per_launch": cells},
-            "roofline_stencil": {"kernel": "dynca_perceive_kernel<vec4>", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
+            "roofline_stencil": {"kernel": "dynca_perceive_rows_kernel<8>", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
                                  "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": tr_st[0], "traffic_provenance": tr_st[1], "launch_ms": ms_st,
                                  "bytes_per_cell": STENCIL_BYTES_PER_CELL, "cells_per_launch": cells,
                                  "cells_per_s": cells / (ms_st * 1e-3)},

@@ -135,7 +135,26 @@ def big():
     (ms,), (mn,) = timed([st], iters=12)
     emit(path="stencil_B64", us=ms * 1e3, TBps=320.0 * B * H * W / ms / 1e9, frac_hbm=320.0 * B * H * W / ms / 1e9 / 8.0, min_us=mn * 1e3,
          working_set_MB=3 * (B * C * H * W * 4 * 5) / 1e6)
-    del xs
+    # calibration on the same buffers: what this box's HBM delivers for a write-only stream, for a 1:1 copy and for the stencil's own 1 read :
+    # 4 writes shape done by torch's elementwise kernel (a broadcast copy) -- the roof the 8 TB/s figure should be read against
+    ys = [torch.empty(B, 4, C, H, W, device=DEV) for _ in range(3)]
+
+    def fill():
+        ys[k[0] % 3].fill_(1.0)
+        k[0] += 1
+
+    def copy11():
+        ys[k[0] % 3].copy_(ys[(k[0] + 1) % 3])
+        k[0] += 1
+
+    def bcast():
+        ys[k[0] % 3].copy_(xs[k[0] % 3].unsqueeze(1))
+        k[0] += 1
+    (mf, mc, mb), _ = timed([fill, copy11, bcast], iters=12)
+    nb = B * C * H * W * 4
+    emit(path="hbm_calibration_B64", fill_TBps=4 * nb / mf / 1e9, copy_TBps=8 * nb / mc / 1e9, read1_write4_TBps=5 * nb / mb / 1e9,
+         stencil_over_read1_write4=mb / ms)
+    del xs, ys
     x, goal, cot, w = cond_case(B)
     T = 8
     (ms,), (mn,) = timed([lambda: ops.cond_grow(x, T, goal, None, w, 3, seed=1)], iters=10)

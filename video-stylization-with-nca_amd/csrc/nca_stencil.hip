@@ -1,12 +1,12 @@
 // nca_stencil.hip -- HBM-bound kernels: standalone perception stencils, pending-state finalize,
 // alive mask, Philox uniforms, MFMA lane-map self-test.  gfx950 only.
 //
-// Perception: one thread produces 4 W-contiguous cells of one (b, channel, row): three 16-byte row
-// loads (pad mode resolved per row), left/right neighbours taken from the adjacent lanes by
-// wavefront shuffle (the row edges and the wave edges fall back to one scalar load that hits
-// L1/L2), 16-byte stores of each output plane.  Algorithmic traffic: read C, write 4C (or 3C)
-// floats per cell -- 20*C (16*C) bytes/cell; that figure over the launch time is what bench.py
-// prices against the 8 TB/s HBM roof.
+// Perception: one thread produces 4 W-contiguous cells of one (b, channel) plane over R consecutive rows, marching down with a
+// three-row window in registers: one 16-byte row load per row (pad mode resolved per row), left/right neighbours taken from the
+// adjacent lanes by wavefront shuffle (the row edges and the wave edges fall back to one scalar load that hits L1/L2), 16-byte
+// NONTEMPORAL stores of each output plane (written once, never re-read by the kernel).  Algorithmic traffic: read C, write 4C (or
+// 3C) floats per cell -- 20*C (16*C) bytes/cell; that figure over the launch time is what bench.py prices against the 8 TB/s HBM
+// roof.
 #include "nca_common.h"
 #include "nca_kernels.h"
 
@@ -33,62 +33,98 @@ __device__ __forceinline__ void load_rows_vec(const float* plane, int H, int W, 
     }
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void dynca_perceive_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                             int B, int C, int H, int W, int pad) {
+// Scalar form (W not a multiple of 4, or unaligned pointers): one thread per cell.
+__global__ __launch_bounds__(256) void dynca_perceive_scalar_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C,
+                                                                    int H, int W, int pad) {
     const size_t plane = (size_t)H * W;
-    if (VEC) {
-        const int W4 = W >> 2;
-        const size_t total = (size_t)B * C * H * W4;
-        const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-        const bool active = gid < total;
-        const size_t id = active ? gid : total - 1;  // keep every lane in the shuffles
-        const int x4 = (int)(id % W4);
-        const int yy = (int)((id / W4) % H);
-        const int c = (int)((id / ((size_t)W4 * H)) % C);
-        const int b = (int)(id / ((size_t)W4 * H * C));
-        const int lane = threadIdx.x & 63;
-        float nb[3][6];
-        load_rows_vec(x + ((size_t)b * C + c) * plane, H, W, yy, x4, pad, x4 > 0 && lane > 0,
-                      x4 < W4 - 1 && lane < 63 && gid + 1 < total, nb);
-        if (!active) return;
-        float4 o[4];
-        float* op[4] = {&o[0].x, &o[1].x, &o[2].x, &o[3].x};
+    const size_t total = (size_t)B * C * plane;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    const int xx = (int)(id % W), yy = (int)((id / W) % H);
+    const int c = (int)((id / plane) % C), b = (int)(id / (plane * C));
+    const float* const p = x + ((size_t)b * C + c) * plane;
+    float a[3][3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float a[3][3];
+    for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) a[dy][dx] = nb[dy][j + dx];
-            op[0][j] = a[1][1];
-            op[1][j] = nca_sobel_x(a);
-            op[2][j] = nca_sobel_y(a);
-            op[3][j] = nca_laplacian(a);
+        for (int dx = 0; dx < 3; ++dx) {
+            const int sy = nca_pad_index(yy + dy - 1, H, pad), sx = nca_pad_index(xx + dx - 1, W, pad);
+            a[dy][dx] = (sy >= 0 && sx >= 0) ? p[(size_t)sy * W + sx] : 0.0f;
         }
-        float* const yb = y + (size_t)b * 4 * C * plane + (size_t)yy * W + 4 * x4;
+    float* const yb = y + (size_t)b * 4 * C * plane + (size_t)yy * W + xx;  // blocked order, dynca.py:92-95
+    __builtin_nontemporal_store(a[1][1], yb + (size_t)c * plane);
+    __builtin_nontemporal_store(nca_sobel_x(a), yb + (size_t)(C + c) * plane);
+    __builtin_nontemporal_store(nca_sobel_y(a), yb + (size_t)(2 * C + c) * plane);
+    __builtin_nontemporal_store(nca_laplacian(a), yb + (size_t)(3 * C + c) * plane);
+}
+
+// vec4 path, rolling rows: one thread owns 4 W-contiguous cells of R consecutive rows and marches down them with a
+// three-row window in registers, so each state row is loaded once per thread (R + 2 row loads per R rows produced instead of 3 R) and the
+// halo rows shared with the chunks above and below are the only re-reads (R = 1 is the plain one-row form, used when the launch is too
+// small for R = 8 to fill the chip).  The four output planes are written once and not read again by this kernel: nontemporal stores
+// keep them from displacing the state rows in L2 / MALL -- at B = 64 (537 MB written per launch) that alone is 5.6 -> 6.5 TB/s.
+typedef float nca_f4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void load_row6(const float* plane, int H, int W, int y, int x4, int xl, int xr, int pad, bool has_left,
+                                          bool has_right, float (&o)[6]) {
+    const int sy = nca_pad_index(y, H, pad);
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* row = plane + (size_t)(sy < 0 ? 0 : sy) * W;
+    if (sy >= 0) c = ld4(row + 4 * x4);
+    float l = __shfl_up(c.w, 1), r = __shfl_down(c.x, 1);
+    if (!has_left) l = (sy >= 0 && xl >= 0) ? row[xl] : 0.0f;
+    if (!has_right) r = (sy >= 0 && xr >= 0) ? row[xr] : 0.0f;
+    o[0] = l; o[1] = c.x; o[2] = c.y; o[3] = c.z; o[4] = c.w; o[5] = r;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void dynca_perceive_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C,
+                                                                  int H, int W, int pad) {
+    const size_t plane = (size_t)H * W;
+    const int W4 = W >> 2, HC = (H + R - 1) / R;
+    const size_t total = (size_t)B * C * HC * W4;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = gid < total;
+    const size_t id = active ? gid : total - 1;  // keep every lane in the shuffles
+    const int x4 = (int)(id % W4);
+    const int yc = (int)((id / W4) % HC);
+    const int c = (int)((id / ((size_t)W4 * HC)) % C);
+    const int b = (int)(id / ((size_t)W4 * HC * C));
+    const int lane = threadIdx.x & 63;
+    const bool hl = x4 > 0 && lane > 0, hr = x4 < W4 - 1 && lane < 63 && gid + 1 < total;
+    const int xl = nca_pad_index(4 * x4 - 1, W, pad), xr = nca_pad_index(4 * x4 + 4, W, pad);
+    const float* const p = x + ((size_t)b * C + c) * plane;
+    float* const yb = y + (size_t)b * 4 * C * plane + 4 * x4;
+    const int y0 = yc * R;
+    float nb[3][6];
+    load_row6(p, H, W, y0 - 1, x4, xl, xr, pad, hl, hr, nb[0]);
+    load_row6(p, H, W, y0, x4, xl, xr, pad, hl, hr, nb[1]);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) st4(yb + (size_t)(f * C + c) * plane, o[f]);  // blocked order, dynca.py:92-95
-    } else {
-        const size_t total = (size_t)B * C * plane;
-        const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (id >= total) return;
-        const int xx = (int)(id % W), yy = (int)((id / W) % H);
-        const int c = (int)((id / plane) % C), b = (int)(id / (plane * C));
-        const float* const p = x + ((size_t)b * C + c) * plane;
-        float a[3][3];
+    for (int r = 0; r < R; ++r) {
+        const int yy = y0 + r;
+        load_row6(p, H, W, yy + 1, x4, xl, xr, pad, hl, hr, nb[2]);
+        if (active && yy < H) {
+            nca_f4v o[4];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+            for (int j = 0; j < 4; ++j) {
+                float a[3][3];
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int sy = nca_pad_index(yy + dy - 1, H, pad), sx = nca_pad_index(xx + dx - 1, W, pad);
-                a[dy][dx] = (sy >= 0 && sx >= 0) ? p[(size_t)sy * W + sx] : 0.0f;
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) a[dy][dx] = nb[dy][j + dx];
+                o[0][j] = a[1][1];
+                o[1][j] = nca_sobel_x(a);
+                o[2][j] = nca_sobel_y(a);
+                o[3][j] = nca_laplacian(a);
             }
-        float* const yb = y + (size_t)b * 4 * C * plane + (size_t)yy * W + xx;
-        yb[(size_t)c * plane] = a[1][1];
-        yb[(size_t)(C + c) * plane] = nca_sobel_x(a);
-        yb[(size_t)(2 * C + c) * plane] = nca_sobel_y(a);
-        yb[(size_t)(3 * C + c) * plane] = nca_laplacian(a);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {  // blocked order, dynca.py:92-95
+                nca_f4v* const dst = reinterpret_cast<nca_f4v*>(yb + (size_t)(f * C + c) * plane + (size_t)yy * W);
+                __builtin_nontemporal_store(o[f], dst);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { nb[0][k] = nb[1][k]; nb[1][k] = nb[2][k]; }
     }
 }
 
@@ -313,8 +349,13 @@ __global__ __launch_bounds__(256) void cond_perceive_kernel(const float* __restr
                 for (int dx = 0; dx < 3; ++dx) acc = fmaf(w[9 * f + 3 * dy + dx], nb[dy][j + dx], acc);
             o[j] = acc;
         }
-        if (VEC) st4(yb + (size_t)f * plane, make_float4(o[0], o[V > 1 ? 1 : 0], o[V > 2 ? 2 : 0], o[V > 3 ? 3 : 0]));
-        else yb[(size_t)f * plane] = o[0];
+        // written once, not re-read here: nontemporal, as in the DyNCA stencil above
+        if (VEC) {
+            const nca_f4v v = {o[0], o[V > 1 ? 1 : 0], o[V > 2 ? 2 : 0], o[V > 3 ? 3 : 0]};
+            __builtin_nontemporal_store(v, reinterpret_cast<nca_f4v*>(yb + (size_t)f * plane));
+        } else {
+            __builtin_nontemporal_store(o[0], yb + (size_t)f * plane);
+        }
     }
 }
 
@@ -399,12 +440,15 @@ inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
 hipError_t nca_launch_dynca_perceive(const float* x, float* y, int B, int C, int H, int W, int pad, hipStream_t st) {
     const bool vec = (W % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
-    if (vec)
-        hipLaunchKernelGGL(dynca_perceive_kernel<true>, dim3(blocks_for((size_t)B * C * H * (W / 4))), dim3(256), 0, st,
-                           x, y, B, C, H, W, pad);
+    const size_t elems = (size_t)B * C * H * W;
+    if (vec && elems >= ((size_t)8 << 20))   // >= 4 waves of 8-row chunks per SIMD on 256 CUs
+        hipLaunchKernelGGL(dynca_perceive_rows_kernel<8>, dim3(blocks_for((size_t)B * C * ((H + 7) / 8) * (W / 4))), dim3(256), 0, st, x, y,
+                           B, C, H, W, pad);
+    else if (vec)
+        hipLaunchKernelGGL(dynca_perceive_rows_kernel<1>, dim3(blocks_for((size_t)B * C * H * (W / 4))), dim3(256), 0, st, x, y, B, C, H, W,
+                           pad);
     else
-        hipLaunchKernelGGL(dynca_perceive_kernel<false>, dim3(blocks_for((size_t)B * C * H * W)), dim3(256), 0, st, x,
-                           y, B, C, H, W, pad);
+        hipLaunchKernelGGL(dynca_perceive_scalar_kernel, dim3(blocks_for(elems)), dim3(256), 0, st, x, y, B, C, H, W, pad);
     return hipGetLastError();
 }
 
