@@ -58,7 +58,9 @@ int ncahip_debug_inject_error(unsigned bits);
 /* Largest shapes the fused step kernels accept (C <= max_c, fc <= max_fc, hidden <= 64).  The fp32 DyNCA *forward* entry
  * points and ncahip_dynca_nsteps_bwd_f32 additionally take 16 < C <= 32 (BASELINE configs[4]) and fc up to 1024 (one launch
  * per 128-wide slice of the hidden layer, the later ones accumulating); the single-step DyNCA backward entry points take
- * C <= 32 with fc <= max_fc; the ConditionedNCA tile kernels (forward fast paths, bf16, backward) cover C <= max_c.        */
+ * C <= 32 with fc <= max_fc; the ConditionedNCA bf16 backward covers C <= max_c, the ConditionedNCA forward fast paths (fp32 and
+ * bf16 storage) C <= 20 -- the reference's default model --, the fp32 forward any-shape kernels and the fused fp32 backward
+ * C <= 32.                                                                                                                  */
 int ncahip_limits(int *max_c, int *max_fc, int *max_hidden);
 
 /* Arithmetic of the UpdateNet products in ncahip_cond_step_fwd_f32 / ncahip_cond_grow_fwd_f32 (process-wide; C in {12,16},
@@ -294,8 +296,9 @@ int ncahip_dynca_nsteps_fwd_bf16(uint16_t *states, int ring, int T, const float 
  * points (restated by oracle.cond_step_bf16): perception in f32 from the widened state; the perception vector, both
  * hidden activations and the weights are rounded to bf16 (RNE) as matrix operands, accumulation in f32; x' = x + mask*out
  * in f32, rounded to bf16 on store.  Replaces the same reference code as the _f32 entry points (nca.py:181-195, :207-208)
- * for callers that keep the pool in bf16 (BASELINE configs[2]).  Needs W % 4 == 0 and 8-byte aligned tensors
- * (NCAHIP_ERANGE otherwise; there is no any-shape bf16 kernel).                                                      */
+ * for callers that keep the pool in bf16 (BASELINE configs[2]).  Needs W % 4 == 0, 8-byte aligned tensors and C <= 20 -- the
+ * reference's default model (nca.py:62-94) included; ncahip_cond_grow_bwd_bf16 stops at C <= 16 -- (NCAHIP_ERANGE otherwise;
+ * there is no any-shape bf16 kernel).                                                                                 */
 int ncahip_cond_step_fwd_bf16(const uint16_t *x_in, const uint8_t *pre_in, uint16_t *x_out, uint8_t *pre_out,
                               const uint16_t *goal, int goal_ch, const float *u,
                               const float *wp, const float *w1, const float *b1,

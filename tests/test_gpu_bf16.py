@@ -47,7 +47,9 @@ def ops():
 
 
 @pytest.mark.parametrize("C,shape,gch", [(16, (2, 32, 48), 12), (12, (2, 24, 32), 8), (16, (1, 8, 16), 12), (16, (1, 5, 20), 0),
-                                         (10, (2, 16, 16), 6)])
+                                         (10, (2, 16, 16), 6),
+                                         # the reference's default C = 20 and a width below the padded 20 (wide LDS carve, forward only)
+                                         (20, (2, 32, 48), 16), (20, (1, 40, 64), 16), (18, (1, 20, 24), 14)])
 def test_single_step_vs_bf16_oracle(ops, C, shape, gch):
     B, H, W = shape
     prm, x, goal, u = make_case(C, B, H, W, gch)
@@ -131,11 +133,17 @@ def test_refuses_unaligned_width(ops):
         ops.cond_step(xd, None, goal.to(DEV).bfloat16(), u.to(DEV), weights(ops, prm, xd), 3)
 
 
-def test_module_grow_bf16(ops):
-    """ConditionedNCA.grow on a bf16 state (no_grad): same class surface, bf16 in / bf16 out, close to the fp32 grow."""
+@pytest.mark.parametrize("hidden_ch", [12, 16])
+def test_module_grow_bf16(ops, hidden_ch, monkeypatch):
+    """ConditionedNCA.grow on a bf16 state (no_grad): same class surface, bf16 in / bf16 out, close to the fp32 grow.
+    hidden_ch = 16 is the reference's default model (C = 20): its no_grad grow runs the bf16-storage kernels too, with
+    gradients enabled it steps in fp32 and returns the pool's dtype."""
     from ncahip.nca import ConditionedNCA
     torch.manual_seed(0)
-    m = ConditionedNCA(target_shape=(3, 32, 32), num_hidden_channels=12, living_channel_dim=3).to(DEV)
+    m = ConditionedNCA(target_shape=(3, 32, 32), num_hidden_channels=hidden_ch, living_channel_dim=3).to(DEV)
+    seen = []
+    real = ops.cond_grow
+    monkeypatch.setattr(ops, "cond_grow", lambda x, *a, **k: (seen.append(x.dtype), real(x, *a, **k))[1])
     with torch.no_grad():
         for p_ in m.update_net.parameters():
             p_.add_(torch.randn_like(p_) * 0.05)
@@ -148,6 +156,7 @@ def test_module_grow_bf16(ops):
         m._mask_step = 0
         yf = m.grow(x.float(), 4, goal)
     assert yb.dtype == torch.bfloat16 and yb.shape == yf.shape
+    assert seen == [torch.bfloat16, torch.float32], seen          # the bf16 grow really ran on the bf16-storage kernels
     d = (yb.float() - yf).abs()
     assert float(d.mean()) < 2e-2, float(d.mean())
     # autograd through the bf16 path: bf16 history ring, fp32 gradients for every parameter (encoder included)

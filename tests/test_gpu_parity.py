@@ -596,13 +596,15 @@ def test_dynca_bwd_fused_w2_matches_buffers(ops, C, fc, cc, H, W):
     assert float((out[C * fc:].cpu().double() - rs).abs().max()) <= 2e-5 * max(1.0, float(rs.abs().max()))
 
 
-def test_cond_step_shape_fuzz(ops):
+@pytest.mark.parametrize("cset", [(5, 8, 12, 13, 16), (17, 18, 20, 20, 24)], ids=["narrow", "wide"])
+def test_cond_step_shape_fuzz(ops, cset):
     """Seeded random shapes / channel counts / goal widths / alive settings / fire rates, pending inputs included: one
     teacher-forced step each against the oracle (nca.py:181-195).  Covers tiles that straddle every image edge and the
-    aligned / unaligned dispatch boundary (W % 4)."""
-    rng = np.random.RandomState(int(os.environ.get("NCAHIP_FUZZ_SEED", "1234")))   # wider sweeps: NCAHIP_FUZZ_SEED / _CASES
+    aligned / unaligned dispatch boundary (W % 4).  `wide`: 16 < C <= 20 runs the producer/consumer kernel's wide LDS carve
+    (tile buffers on top of the dead weight images), C = 24 the generic kernel."""
+    rng = np.random.RandomState(int(os.environ.get("NCAHIP_FUZZ_SEED", "1234")) + (0 if cset[0] == 5 else 77))   # wider sweeps: NCAHIP_FUZZ_SEED / _CASES
     for case in range(int(os.environ.get("NCAHIP_FUZZ_CASES", "24"))):
-        C = int(rng.choice([5, 8, 12, 13, 16]))
+        C = int(rng.choice(cset))
         B = int(rng.randint(1, 4)); H = int(rng.randint(1, 41)); W = int(rng.randint(1, 53))
         if rng.rand() < 0.6:
             W = max(4, (W // 4) * 4)                               # exercise the aligned kernels more often
@@ -707,6 +709,32 @@ def test_cond_large_plane_tile_vs_generic(ops):
     finally:
         ops.force_generic(ops._test_mode)
     assert float((outs[0] - outs[1]).abs().max()) <= 1e-6 * max(1.0, float(outs[1].abs().max()))
+
+
+@pytest.mark.parametrize("C,hidden", [(20, 64), (18, 48)])
+def test_cond_default_model_tile_vs_generic(ops, C, hidden):
+    """The reference's default channel count C = 20 (nca.py:62-94) at the bench size 8 x C x 256^2, 6 free-running steps with the
+    in-kernel mask: every workgroup of the producer/consumer kernel walks several rounds, so the second tile buffers -- which
+    live on top of the W1 / W2 images once the consumers hold those in registers -- are reused many times.  Reference: the
+    any-shape kernel family (oracle-checked at every small shape; the CPU oracle needs minutes at this size)."""
+    if ops._test_mode != 0:
+        pytest.skip("compares the two kernel families itself; run once")
+    B, H, W = 8, 256, 256
+    gen = torch.Generator().manual_seed(20)
+    prm = rand_cond_prm(C, seed=20, hidden=hidden, out_scale=2.0)
+    x = torch.rand(B, C, H, W, generator=gen).to(DEV)
+    goal = (torch.randn(B, C - 4, H, W, generator=gen) * 0.5).to(DEV)
+    w = cond_w(ops, prm, x)
+    outs = []
+    try:
+        for force in (0, 1):
+            ops.force_generic(force)
+            o, _, _ = ops.cond_grow(x, 6, goal, None, w, 3, seed=11)
+            outs.append(o)
+    finally:
+        ops.force_generic(ops._test_mode)
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * max(1.0, float(outs[1].abs().max()))
+    assert float(outs[0].abs().max()) > 0.5 and bool(torch.isfinite(outs[0]).all())
 
 
 def test_cond_backward_shape_fuzz(ops):

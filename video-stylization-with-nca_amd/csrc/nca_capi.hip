@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int kMaxC = 16, kMaxCCondFwd = 32, kMaxCDynca = 32, kMaxFc = 128, kMaxFcFwd = 1024, kMaxHidden = 64, kMaxCond = 4;   // DyNCA forward: C <= 32 (configs[4]), fc in 128-wide slices
+constexpr int kMaxC = 16, kMaxCCondFwd = 32, kMaxCCondFwdBf16 = 20, kMaxCDynca = 32, kMaxFc = 128, kMaxFcFwd = 1024, kMaxHidden = 64, kMaxCond = 4;   // DyNCA forward: C <= 32 (configs[4]), fc in 128-wide slices
 
 thread_local char g_err[512] = "";
 
@@ -378,7 +378,7 @@ int ncahip_cond_step_fwd_bf16(const uint16_t* x_in, const uint8_t* pre_in, uint1
                               const float* b1, const float* w2, const float* b2, const float* w3, int B, int C, int H,
                               int W, int hidden, int alive_ch, float alive_thr, float fire_rate, float clamp_lo,
                               float clamp_hi, uint64_t seed, uint64_t step, ncahip_stream_t stream) {
-    if (int rc = check_cond(x_in, x_out, pre_out, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch))
+    if (int rc = check_cond(x_in, x_out, pre_out, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch, kMaxCCondFwdBf16))
         return rc;
     if (int rc = check_bf16_shape(x_in, x_out, goal, H, W)) return rc;
     if (pre_in && pre_in == pre_out) return fail(NCAHIP_EINVAL, "cond step: pre_in and pre_out must not alias");
@@ -405,7 +405,7 @@ int ncahip_cond_grow_fwd_bf16(uint16_t* states, uint8_t* pre, int ring, int T, u
                               int alive_ch, float alive_thr, float fire_rate, float clamp_lo, float clamp_hi,
                               uint64_t seed, uint64_t step0, ncahip_stream_t stream) {
     if (ring < 2 || T < 1 || !pre || !x_final) return fail(NCAHIP_EINVAL, "cond grow: ring >= 2, T >= 1, buffers required");
-    if (int rc = check_cond(states, states + 1, pre, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch))
+    if (int rc = check_cond(states, states + 1, pre, goal, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch, kMaxCCondFwdBf16))
         return rc;
     if (int rc = check_bf16_shape(states, states, goal, H, W)) return rc;
     if (int rc = device_error_rc("cond grow (bf16)")) return rc;

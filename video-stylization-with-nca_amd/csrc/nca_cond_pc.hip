@@ -17,21 +17,54 @@ namespace {
 #endif
 constexpr bool kNtStore = NCA_WT_STORE != 0;   // write-through output stores (see store_tile)
 
+// LDS carve of the pairs.  Offsets are floats from the start of the allocation; `which` is the tile buffer (0/1).
+//   CP <= 16: [weight image F::SHARED][pair 0: buf0 buf1 scratch][pair 1] ...  with XR of 16*M3T rows (whole MFMA row tiles).
+//   CP  > 16 (the reference's default C = 20): the straightforward carve is 217 KB.  Two things bring it to 159 KB:
+//     * XR holds exactly CP rows (mlp_tile_regs guards the rows of the last output tile), and
+//     * the W1 / W2 images are dead once the consumers have moved them into registers (mlp_load_regs), so the SECOND tile buffers
+//       of pairs 0 and 1 live on top of them; the producers wait at one more workgroup barrier before they stage into a second
+//       buffer for the first time.  W3, the biases and the perception taps stay resident (W3 is read from LDS per pass here: 160
+//       operand registers would not fit beside the rest of the consumer).
 template <int CP>
 struct PCfg {
     using F = WCfg<CP>;
-    static constexpr int BUF_Z = 0;
-    static constexpr int BUF_XR = BUF_Z + CP * CS;
-    static constexpr int BUF_MK = BUF_XR + 16 * F::M3T * XRS;       // 16*M3T rows: mlp_tile_regs updates whole MFMA row tiles
-    static constexpr int BUF = BUF_MK + WTH * WTW;                 // one tile buffer (floats)
-    static constexpr int SCR_A3 = 2 * BUF;                         // producer scratch, not double-buffered
+    static constexpr bool WIDE = CP > 16;
+    static constexpr int XR_ROWS = WIDE ? CP : 16 * F::M3T;
+    static constexpr int SZ_Z = CP * CS, SZ_XR = XR_ROWS * XRS, SZ_MK = WTH * WTW;
+    static constexpr int BUF = SZ_Z + SZ_XR + SZ_MK;               // one tile buffer (floats)
+    static constexpr int SCR_A3 = 0;                               // producer scratch of a pair, not double-buffered
     static constexpr int SCR_LIFE = SCR_A3 + (WTH + 6) * RS;
     static constexpr int SCR_A2 = SCR_LIFE + (WTH + 4) * RS;
     static constexpr int SCR_FLAG = SCR_A2 + (WTH + 4) * RS;       // [0] last round staged, [1] last round consumed (ints)
-    static constexpr int PAIR = SCR_FLAG + 4;
-    static constexpr int LDS_FLOATS = F::SHARED + 4 * PAIR;
-    static_assert(BUF % 4 == 0 && PAIR % 4 == 0 && BUF_XR % 4 == 0, "16-byte carve");
+    static constexpr int SCR = SCR_FLAG + 4;
+    static constexpr int PAIR = 2 * BUF + SCR;                     // narrow carve: one contiguous region per pair
+    // wide carve
+    static constexpr int ALIAS_END = F::OFF_W3;                    // [0, OFF_W3) = the W1 and W2 images
+    static constexpr int W_BUF0 = F::SHARED;                       // 4 x buf0
+    static constexpr int W_SCR = W_BUF0 + 4 * BUF;                 // 4 x scratch
+    static constexpr int W_XR1P1 = W_SCR + 4 * SCR;                // XR of pair 1's second buffer (its Z and MK sit in the alias region)
+    static constexpr int W_BUF1 = W_XR1P1 + SZ_XR;                 // second buffers of pairs 2 and 3
+    static constexpr int LDS_FLOATS = WIDE ? W_BUF1 + 2 * BUF : F::SHARED + 4 * PAIR;
+    static_assert(!WIDE || BUF + SZ_Z + SZ_MK <= ALIAS_END, "pair 0's second buffer + pair 1's second Z / MK fit on the dead images");
+    static_assert(BUF % 4 == 0 && SCR % 4 == 0 && SZ_Z % 4 == 0 && SZ_XR % 4 == 0 && F::SHARED % 4 == 0, "16-byte carve");
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+    struct Offs { int z, xr, mk, scr; };
+    static __device__ __forceinline__ Offs offs(int pair, int which) {
+        if constexpr (!WIDE) {
+            const int b = F::SHARED + pair * PAIR + which * BUF;
+            return Offs{b, b + SZ_Z, b + SZ_Z + SZ_XR, F::SHARED + pair * PAIR + 2 * BUF};
+        } else {
+            const int scr = W_SCR + pair * SCR;
+            if (which == 0) {
+                const int b = W_BUF0 + pair * BUF;
+                return Offs{b, b + SZ_Z, b + SZ_Z + SZ_XR, scr};
+            }
+            if (pair == 0) return Offs{0, SZ_Z, SZ_Z + SZ_XR, scr};
+            if (pair == 1) return Offs{BUF, W_XR1P1, BUF + SZ_Z, scr};
+            const int b = W_BUF1 + (pair - 2) * BUF;
+            return Offs{b, b + SZ_Z, b + SZ_Z + SZ_XR, scr};
+        }
+    }
 };
 
 template <int CP, bool EXACT, typename ST, bool SPLIT = false>
@@ -91,11 +124,10 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
         fill_store(fwp, smem + K::OFF_WP, tid);
     }
 
-    float* const PR = smem + K::SHARED + pair * PK::PAIR;
     auto lds_of = [&](int which) -> TileLds {
-        float* const B = PR + which * PK::BUF;
-        return TileLds{B + PK::BUF_Z, B + PK::BUF_XR, PR + PK::SCR_A3, PR + PK::SCR_A3, PR + PK::SCR_LIFE, PR + PK::SCR_A2,
-                       B + PK::BUF_MK};
+        const typename PK::Offs o = PK::offs(pair, which);
+        float* const S = smem + o.scr;
+        return TileLds{smem + o.z, smem + o.xr, S + PK::SCR_A3, S + PK::SCR_A3, S + PK::SCR_LIFE, S + PK::SCR_A2, smem + o.mk};
     };
 
     // every pair walks the same super-tile sequence
@@ -212,7 +244,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
     // and their stores all collide; with pair-local hand-offs the pairs drift apart.  LDS operations of one wave execute in
     // order, so "data, then counter" on the writer side and "counter, then data" on the reader side is all the ordering
     // needed.  The polls are bounded (a broken hand-off never hangs the device; it sets the sticky error word, see await).
-    int* const flags = reinterpret_cast<int*>(PR + PK::SCR_FLAG);
+    int* const flags = reinterpret_cast<int*>(smem + PK::offs(pair, 0).scr + PK::SCR_FLAG);
     auto post = [&](int idx, int round) {
         wave_sync();
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS traffic for the round is done
@@ -239,6 +271,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
         post(0, 0);
         NCA_KSTAMP(1);
         __syncthreads();              // weight image complete, counters initialised
+        if constexpr (PK::WIDE) __syncthreads();   // ... and moved into the consumers' registers: the second buffers may overwrite it
         NCA_KSTAMP(2);
         while (pos.k + 1 < n_rounds) {
             const Pos pn = advance(pos);
@@ -264,6 +297,11 @@ __global__ __launch_bounds__(kThreadsW, 2) void cond_step_fwd_pc_kernel(const Nc
         if constexpr (SPLIT) load_weights_split_lds<CP>(smem, lane, Ws);
         else if constexpr (BF) load_weights_bf16_lds<CP>(smem, lane, Wb);   // same image, rounded to bf16 operand pairs
         else mlp_load_regs<CP>(smem, lane, Wr);
+        if constexpr (PK::WIDE) {
+            static_assert(!PK::WIDE || !SPLIT, "wide carve: the exact-f32 and the bf16 consumer");
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the image reads have landed
+            __syncthreads();
+        }
         while (pos.k < n_rounds) {
             const Pos pn = advance(pos);
             const WTile nxt = tile_of(pn);
@@ -323,11 +361,14 @@ hipError_t nca_launch_cond_step_fwd_pc(const NcaCondArgs& a_in, hipStream_t st) 
     if (a.C == 16 && h64) return launch_cond_pc<16, true>(a, st);
     if (a.C <= 12) return launch_cond_pc<12, false>(a, st);
     if (a.C <= 16) return launch_cond_pc<16, false>(a, st);
+    // the reference's default model, C = 3 + 1 + 16 = 20 (nca.py:62-94)
+    if (a.C == 20 && h64) return launch_cond_pc<20, true>(a, st);
+    if (a.C <= 20) return launch_cond_pc<20, false>(a, st);
     return hipErrorInvalidValue;
 }
 
 // bf16 state / goal behind the float-typed pointers of NcaCondArgs.  Caller (nca_capi.hip) guarantees W % 4 == 0, 8-byte
-// aligned x_in / x_out / goal, C <= 16, hidden <= 64, H*W < 2^24.
+// aligned x_in / x_out / goal, C <= 20, hidden <= 64, H*W < 2^24.
 hipError_t nca_launch_cond_step_fwd_bf16(const NcaCondArgs& a_in, hipStream_t st) {
     NcaCondArgs a = a_in;
     a.dbg = g_stamp_pc;
@@ -337,5 +378,7 @@ hipError_t nca_launch_cond_step_fwd_bf16(const NcaCondArgs& a_in, hipStream_t st
     if (a.C == 16 && h64) return launch_cond_pc<16, true, StBF16>(a, st);
     if (a.C <= 12) return launch_cond_pc<12, false, StBF16>(a, st);
     if (a.C <= 16) return launch_cond_pc<16, false, StBF16>(a, st);
+    if (a.C == 20 && h64) return launch_cond_pc<20, true, StBF16>(a, st);
+    if (a.C <= 20) return launch_cond_pc<20, false, StBF16>(a, st);
     return hipErrorInvalidValue;
 }

@@ -714,23 +714,25 @@ __device__ __forceinline__ void mlp_tile(const NcaCondArgs& a, const float* __re
 template <int CP>
 struct MlpRegs {
     using K = WCfg<CP>;
-    f32x4 w1[4][K::K1S4], w2[4][4], w3[K::M3T][4];
+    static constexpr bool W3_LDS = CP > 16;   // wide channel counts: W3 stays in LDS (32 more operand registers do not fit)
+    f32x4 w1[4][K::K1S4], w2[4][4], w3[W3_LDS ? 1 : K::M3T][4];
 };
 template <int CP>
 __device__ __forceinline__ void mlp_load_regs(const float* __restrict__ WS, int lane, MlpRegs<CP>& R) {
     using K = WCfg<CP>;
     const f32x4* const W1V = reinterpret_cast<const f32x4*>(WS + K::OFF_W1) + lane;
     const f32x4* const W2V = reinterpret_cast<const f32x4*>(WS + K::OFF_W2) + lane;
-    const f32x4* const W3V = reinterpret_cast<const f32x4*>(WS + K::OFF_W3) + lane;
-    const int g = (lane >> 4) & 3;
+    [[maybe_unused]] const f32x4* const W3V = reinterpret_cast<const f32x4*>(WS + K::OFF_W3) + lane;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
 #pragma unroll
         for (int q = 0; q < K::K1S4; ++q) R.w1[m][q] = W1V[(m * K::K1S4 + q) * 64];
 #pragma unroll
         for (int m2 = 0; m2 < 4; ++m2) R.w2[m2][m] = W2V[(m2 * 4 + m) * 64];
+        if constexpr (!MlpRegs<CP>::W3_LDS) {
 #pragma unroll
-        for (int m3 = 0; m3 < K::M3T; ++m3) R.w3[m3][m] = W3V[(m3 * 4 + m) * 64];
+            for (int m3 = 0; m3 < K::M3T; ++m3) R.w3[m3][m] = W3V[(m3 * 4 + m) * 64];
+        }
     }
 }
 // mlp_tile with register-resident operands (same MFMA order per accumulator => bit-identical results).
@@ -738,12 +740,13 @@ __device__ __forceinline__ void mlp_load_regs(const float* __restrict__ WS, int 
 // VALU instruction that lands between two MFMAs drains the matrix pipe first (measured: ~25 cycles per isolated v_max,
 // tools/micro/mlp_pass.hip).  The ReLUs are therefore issued as fenced groups of 8 / 32, and the layer-1 chain of hidden
 // tile m+1 is issued BEFORE the ReLU group of tile m so that group never waits for the chain it reads.
-// XR must provide 16*M3T channel rows.
+// XR must provide 16*M3T channel rows (CP <= 16) / exactly CP rows (CP > 16: the last output tile's rows are guarded).
 template <int CP, int NT>
 __device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, const float* __restrict__ WS, float* __restrict__ XR,
                                               const float* __restrict__ MK, int lane_in, int n0,
                                               const float (&P)[NT][3 * CP / 4]) {
     using K = WCfg<CP>;
+    constexpr bool WIDE = MlpRegs<CP>::W3_LDS;
     int lane_o = lane_in;
     asm volatile("" : "+v"(lane_o));
     const int g = (lane_o >> 4) & 3, ci = lane_o & 15;
@@ -804,9 +807,18 @@ __device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, const float
         for (int m3 = 0; m3 < K::M3T; ++m3)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                // XR holds 16*M3T channel rows (rows >= CP are scratch): no per-lane guard, no exec masking
-                xr[n][m3][r] = XR[xoff + (16 * m3 + r) * XRS + n * WTW];
+                // CP <= 16: XR holds 16*M3T channel rows (rows >= CP are scratch): no per-lane guard, no exec masking
+                if (!WIDE || 16 * m3 + 16 <= CP || 4 * g < CP - 16 * m3) xr[n][m3][r] = XR[xoff + (16 * m3 + r) * XRS + n * WTW];
+                else xr[n][m3][r] = 0.0f;
             }
+    }
+    f32x4 w3l[K::M3T][4];   // WIDE: layer-3 operands from the resident image, requested here (they land under the ReLU group)
+    if constexpr (WIDE) {
+        const f32x4* const W3V = reinterpret_cast<const f32x4*>(WS + K::OFF_W3) + lane_o;
+#pragma unroll
+        for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) w3l[m3][m] = W3V[(m3 * 4 + m) * 64];
     }
     float h2[4][NT][4];
     __builtin_amdgcn_sched_barrier(0);
@@ -829,7 +841,10 @@ __device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, const float
 #pragma unroll
             for (int m3 = 0; m3 < K::M3T; ++m3)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc3[m3][n] = nca_mfma(Wr.w3[m3][m][r], h2[m][n][r], acc3[m3][n]);
+                for (int n = 0; n < NT; ++n) {
+                    if constexpr (WIDE) acc3[m3][n] = nca_mfma(w3l[m3][m][r], h2[m][n][r], acc3[m3][n]);
+                    else acc3[m3][n] = nca_mfma(Wr.w3[m3][m][r], h2[m][n][r], acc3[m3][n]);
+                }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -837,7 +852,8 @@ __device__ __forceinline__ void mlp_tile_regs(const MlpRegs<CP>& Wr, const float
         for (int m3 = 0; m3 < K::M3T; ++m3)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                XR[xoff + (16 * m3 + r) * XRS + n * WTW] = fmaf(mk[n], acc3[m3][n][r], xr[n][m3][r]);
+                if (!WIDE || 16 * m3 + 16 <= CP || 4 * g < CP - 16 * m3)
+                    XR[xoff + (16 * m3 + r) * XRS + n * WTW] = fmaf(mk[n], acc3[m3][n][r], xr[n][m3][r]);
             }
 }
 
@@ -945,8 +961,10 @@ __device__ __forceinline__ void mlp_tile_bf16(const MlpRegsBf<CP>& Wr, const flo
         for (int m3 = 0; m3 < K::M3T; ++m3)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float* const p = XR + (16 * m3 + 4 * g + r) * XRS + (n0 + n) * WTW + ci;
-                *p = fmaf(mk, acc3[m3][r], *p);
+                if (CP <= 16 || 16 * m3 + 16 <= CP || 4 * g < CP - 16 * m3) {   // CP > 16: XR holds exactly CP rows
+                    float* const p = XR + (16 * m3 + 4 * g + r) * XRS + (n0 + n) * WTW + ci;
+                    *p = fmaf(mk, acc3[m3][r], *p);
+                }
             }
     }
 }

@@ -1501,10 +1501,11 @@ hipError_t nca_launch_dynca_step_bwd(const NcaDyncaArgs& a, hipStream_t st) {
 
 hipError_t nca_launch_cond_step_fwd(const NcaCondArgs& a, hipStream_t st) {
     // the tile kernels address with 32-bit byte offsets from the batch item's base (issue_loads): H*W < 2^24, C*H*W*4 < 2^32
-    const bool small = (size_t)a.H * a.W < ((size_t)1 << 24) && (size_t)16 * a.H * a.W * 4 < ((size_t)1 << 32);
-    if (!g_force_generic && small && a.C <= 16 && (a.W % 4 == 0) && aligned16(a.x_in) && aligned16(a.x_out) &&
-        (a.goal == nullptr || aligned16(a.goal)))
-        return g_cond_variant == 1 ? nca_launch_cond_step_fwd_wave(a, st) : nca_launch_cond_step_fwd_pc(a, st);
+    const bool small = (size_t)a.H * a.W < ((size_t)1 << 24) && (size_t)(a.C <= 16 ? 16 : 20) * a.H * a.W * 4 < ((size_t)1 << 32);
+    const bool tiled = !g_force_generic && small && (a.W % 4 == 0) && aligned16(a.x_in) && aligned16(a.x_out) &&
+                       (a.goal == nullptr || aligned16(a.goal));
+    if (tiled && a.C <= 16) return g_cond_variant == 1 ? nca_launch_cond_step_fwd_wave(a, st) : nca_launch_cond_step_fwd_pc(a, st);
+    if (tiled && a.C <= 20) return nca_launch_cond_step_fwd_pc(a, st);   // the reference's default C = 20: producer/consumer kernel, wide carve
     if (a.C <= 12) return launch_cond<12>(a, st);
     if (a.C <= 16) return launch_cond<16>(a, st);
     // the reference's default model is C = 3 + 1 + 16 = 20 (nca.py:62-94): the generic kernel family with two output tiles
