@@ -242,12 +242,22 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
+    # Rehearsal knobs (NOT the measured configuration): NCAHIP_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and NCAHIP_BENCH_BACKEND=gloo
+    # replaces RCCL, so the N > 1 protocol (rendezvous, barriers, max over ranks, the trainers' all-reduce) can be run through on a
+    # one-GPU box (tools/rehearse_dist.sh).  The JSON line then says so in config.parallelism.
+    share_gpu = os.environ.get("NCAHIP_BENCH_SHARE_GPU", "0") == "1"
+    backend = os.environ.get("NCAHIP_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from ncahip import ops
     ops.selftest(dev)
@@ -334,7 +344,8 @@ def main():
                        "B_per_gpu": B, "C": C, "H": H, "W": W, "nca_steps_per_bench_step": T, "hidden": HIDDEN,
                        "mask_rng": "in-kernel philox4x32-10", "alive_fraction_at_end": round(alive_frac, 4),
                        "alive_fraction_roofline_run": round(alive_frac_roof, 4),
-                       "parallelism": f"pool-shard x{world} (no data-path collective)"},
+                       "parallelism": f"pool-shard x{world} (no data-path collective)" +
+                                      (f" [REHEARSAL: backend={backend}, share_gpu={int(share_gpu)}]" if (share_gpu or backend != "nccl") else "")},
             "roofline": {"kernel": "cond_step_fwd_pc_kernel<16,*>", "bound": "mfma", "achieved": tflops,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS,
                          "traffic": tr_step[0], "traffic_provenance": tr_step[1], "launch_ms": ms_launch, "flops_per_cell": FLOPS_PER_CELL,
