@@ -183,8 +183,8 @@ def test_trainer_iterations_on_gpu():
 @pytest.mark.parametrize("pool_dtype", [torch.float32, torch.bfloat16])
 def test_trainer_default_model_c20_pool_dtypes(pool_dtype, monkeypatch):
     """ConditionedNCATrainer around the reference's DEFAULT model (C = 20): fused forward + backward for an fp32 pool; a bf16
-    POOL keeps its storage type (the steps run in fp32 on the exactly widened state -- the bf16-storage kernels cover C <= 16)
-    and update_pool's scatter receives the pool's dtype."""
+    POOL runs the bf16-storage kernels (forward on bf16 MFMA, backward over the bf16 history with exact-f32 products) and
+    update_pool's scatter receives the pool's dtype."""
     from ncahip import autograd as AG
     from ncahip.conditioned_trainer import ConditionedNCATrainer
     from ncahip.nca import ConditionedNCA
@@ -222,7 +222,7 @@ def test_trainer_default_model_c20_pool_dtypes(pool_dtype, monkeypatch):
     assert not torch.equal(m.update_net.out[0].weight.detach(), w0)
     assert tr.pool._dense.dtype == pool_dtype and tr.pool._dense.is_cuda
     assert bool(torch.isfinite(tr.pool._dense.float()).all())
-    with torch.no_grad():     # no-grad grow of a bf16 state at C = 20: fp32 steps, bf16 out
+    with torch.no_grad():     # no-grad grow of a bf16 state at C = 20: bf16-storage kernels, bf16 out
         out = m.grow(m.generate_seed(2).to(DEV, pool_dtype), 3, torch.rand(2, 3, 32, 32, device=DEV))
     assert out.dtype == pool_dtype
 

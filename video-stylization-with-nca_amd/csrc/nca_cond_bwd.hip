@@ -1045,10 +1045,15 @@ hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st, bo
         if (g_bwd_bf16_exact) {   // test hook: exact-f32 recomputation from the widened history
             if (ba.f.C <= 12) return launch_bwd<12, StBF16>(ba, st);
             if (ba.f.C <= 16) return launch_bwd<16, StBF16>(ba, st);
-            return hipErrorInvalidValue;
         }
         if (ba.f.C <= 12) return launch_bwd<12, StBF16, true>(ba, st);
         if (ba.f.C <= 16) return launch_bwd<16, StBF16, true>(ba, st);
+        if (ba.f.C <= 20) {   // the reference's default model over a bf16 history: storage format only (exact-f32 products, as the fp32 form)
+            if (!ba.pscr || !ba.doscr) return hipErrorInvalidValue;
+            if (hipError_t e = nca_launch_cond_step_bwd_fm(ba, st, 1); e != hipSuccess) return e;
+            hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<float>, dim3(ba.nblk), dim3(256), 0, st, ba);
+            return hipGetLastError();
+        }
         return hipErrorInvalidValue;
     }
     if (ba.f.C <= 12) return launch_bwd<12, StF32>(ba, st);

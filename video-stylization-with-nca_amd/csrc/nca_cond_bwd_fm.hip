@@ -1130,7 +1130,8 @@ size_t nca_cond_bwd_fm_doscr_bytes(int B, int C, int H, int W) {
 // 2 = bf16 history with the products on bf16 MFMA.
 hipError_t nca_launch_cond_step_bwd_fm(const NcaCondBwdArgs& ba, hipStream_t st, int mode) {
     if (ba.f.C > 32 || !ba.pscr || !ba.doscr) return hipErrorInvalidValue;
-    if (ba.f.C > 16) {   // wide channel counts (the reference's default model is C = 20): fp32 history and products only
+    if (ba.f.C > 16) {   // wide channel counts (the reference's default model is C = 20): fp32 products only; bf16 history up to C = 20
+        if (mode == 1 && ba.f.C <= 20) return launch_fm<20, StBF16, false>(ba, st);
         if (mode != 0) return hipErrorInvalidValue;
         if (ba.f.C <= 20) return launch_fm<20, StF32, false>(ba, st);
         if (ba.f.C <= 24) return launch_fm<24, StF32, false>(ba, st);

@@ -90,11 +90,11 @@ def cond_grow_autograd(model, x: torch.Tensor, goal: Optional[torch.Tensor], T: 
     bf16 = x.dtype == torch.bfloat16      # bf16 pool (BASELINE configs[2]): bf16-storage kernels, forward and backward
     u = model.update_net.out
     params = (model.perception_net.weight, u[0].weight, u[0].bias, u[2].weight, u[2].bias, u[4].weight)
-    if bf16 and x.shape[1] > 16:
-        # the bf16-storage BACKWARD kernels cover C <= 16, the forward ones C <= 20 (the reference default) at W % 4 == 0: a wider
-        # model keeps its bf16 POOL but, with gradients enabled, steps in fp32 (widening is exact) and returns the pool's dtype
-        if _needs_grad(x, goal, *params) or x.shape[1] > 20 or x.shape[3] % 4 != 0:
-            return cond_grow_autograd(model, x.float(), goal, T).to(torch.bfloat16)
+    if bf16 and (x.shape[1] > 20 or x.shape[3] % 4 != 0):
+        # the bf16-storage kernels cover C <= 20 (the reference default model) at W % 4 == 0 -- bf16 MFMA products up to C = 16,
+        # exact-f32 products in the backward of 16 < C <= 20 (storage format only); anything else keeps its bf16 POOL but steps in
+        # fp32 (widening is exact) and returns the pool's dtype
+        return cond_grow_autograd(model, x.float(), goal, T).to(torch.bfloat16)
     x = x.contiguous() if bf16 else x.float().contiguous()
     us = model._draw(x, T)
     cfg = dict(T=T, us=us, alive_ch=model._alive_ch(), thr=model.alpha_living_threshold, fire_rate=model.cell_fire_rate,
