@@ -297,8 +297,7 @@ int ncahip_dynca_nsteps_fwd_bf16(uint16_t *states, int ring, int T, const float 
  * hidden activations and the weights are rounded to bf16 (RNE) as matrix operands, accumulation in f32; x' = x + mask*out
  * in f32, rounded to bf16 on store.  Replaces the same reference code as the _f32 entry points (nca.py:181-195, :207-208)
  * for callers that keep the pool in bf16 (BASELINE configs[2]).  Needs W % 4 == 0, 8-byte aligned tensors and C <= 20 -- the
- * reference's default model (nca.py:62-94) included; ncahip_cond_grow_bwd_bf16 takes the same range, with exact-f32 products
- * instead of bf16 MFMA for 16 < C <= 20 -- (NCAHIP_ERANGE otherwise;
+ * reference's default model (nca.py:62-94) included; ncahip_cond_grow_bwd_bf16 takes the same range -- (NCAHIP_ERANGE otherwise;
  * there is no any-shape bf16 kernel).                                                                                 */
 int ncahip_cond_step_fwd_bf16(const uint16_t *x_in, const uint8_t *pre_in, uint16_t *x_out, uint8_t *pre_out,
                               const uint16_t *goal, int goal_ch, const float *u,

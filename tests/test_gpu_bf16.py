@@ -176,9 +176,8 @@ def test_module_grow_bf16(ops, hidden_ch, monkeypatch):
 @pytest.mark.parametrize("C,shape,gch,Tn", [(16, (2, 32, 48), 12, 4), (12, (2, 24, 32), 8, 3), (16, (1, 16, 16), 16, 2),
                                             (20, (2, 32, 48), 16, 3), (18, (1, 16, 32), 14, 2)])
 def test_cond_grow_backward_bf16_history(ops, C, shape, gch, Tn):
-    """ncahip_cond_grow_bwd_bf16 (bf16 history, matrix products on bf16 MFMA, everything else fp32; for 16 < C <= 20 -- the
-    reference's default model -- the history is bf16 but the products are exact f32, so (i) holds for the default call as well and
-    the distance to the bf16-faithful oracle of (iii) is the gate-consistency budget of (ii)).  Checked three ways:
+    """ncahip_cond_grow_bwd_bf16 (bf16 history, matrix products on bf16 MFMA, everything else fp32; C = 20 / 18: the reference's
+    default model on the front + matrix kernels at CP = 20).  Checked three ways:
     (i) the storage plumbing: with the exact-f32 product hook the bf16-history kernel equals the fp32 kernel fed the widened
     history bit for bit; (ii) the bf16-MFMA products against those exact-f32 products of the SAME history (relative L2);
     (iii) against oracle autograd through the fp32 steps started from the same bf16-representable inputs (different
@@ -219,9 +218,6 @@ def test_cond_grow_backward_bf16_history(ops, C, shape, gch, Tn):
     # roundings).  Same gates, same operands; the kernel additionally rounds the gradient operands of its products to bf16.
     _, gx, gg, gw = O.cond_grow_bf16_loss_grads(x0, O.cond_pad_goal(goal, C), list(us), prm, 3, 0.1, 0.5, cot)
     tol = 2e-2 if Tn <= 2 else 4e-2          # longer roll-outs: the two trajectories drift apart by final-rounding flips
-    if C > 16:
-        assert all(torch.equal(g16[k], g32[k]) for k in g16)        # exact-f32 products of the widened history, bit for bit
-        tol = 8e-2                                                   # gates from the exact recomputation, see (ii)
     assert rel2(g16["x0"], gx) < tol and rel2(g16["goal"], gg[:, C - gch:]) < tol, (rel2(g16["x0"], gx), rel2(g16["goal"], gg[:, C - gch:]))
     for k, n in names.items():
         assert rel2(g16[k], gw[n]) < tol, (k, rel2(g16[k], gw[n]))

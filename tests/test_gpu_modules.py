@@ -183,7 +183,7 @@ def test_trainer_iterations_on_gpu():
 @pytest.mark.parametrize("pool_dtype", [torch.float32, torch.bfloat16])
 def test_trainer_default_model_c20_pool_dtypes(pool_dtype, monkeypatch):
     """ConditionedNCATrainer around the reference's DEFAULT model (C = 20): fused forward + backward for an fp32 pool; a bf16
-    POOL runs the bf16-storage kernels (forward on bf16 MFMA, backward over the bf16 history with exact-f32 products) and
+    POOL runs the bf16-storage kernels (forward and backward on bf16 MFMA, bf16 history) and
     update_pool's scatter receives the pool's dtype."""
     from ncahip import autograd as AG
     from ncahip.conditioned_trainer import ConditionedNCATrainer

@@ -1048,10 +1048,12 @@ hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st, bo
         }
         if (ba.f.C <= 12) return launch_bwd<12, StBF16, true>(ba, st);
         if (ba.f.C <= 16) return launch_bwd<16, StBF16, true>(ba, st);
-        if (ba.f.C <= 20) {   // the reference's default model over a bf16 history: storage format only (exact-f32 products, as the fp32 form)
+        if (ba.f.C <= 20) {   // the reference's default model over a bf16 history: front + matrix kernels at CP = 20 (bf16 MFMA, one wave per
+                              // SIMD); with the exact hook: exact-f32 products of the widened history, as the fp32 form
             if (!ba.pscr || !ba.doscr) return hipErrorInvalidValue;
-            if (hipError_t e = nca_launch_cond_step_bwd_fm(ba, st, 1); e != hipSuccess) return e;
-            hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<float>, dim3(ba.nblk), dim3(256), 0, st, ba);
+            if (hipError_t e = nca_launch_cond_step_bwd_fm(ba, st, g_bwd_bf16_exact ? 1 : 2); e != hipSuccess) return e;
+            if (g_bwd_bf16_exact) hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<float>, dim3(ba.nblk), dim3(256), 0, st, ba);
+            else hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<uint16_t>, dim3(ba.nblk), dim3(256), 0, st, ba);
             return hipGetLastError();
         }
         return hipErrorInvalidValue;

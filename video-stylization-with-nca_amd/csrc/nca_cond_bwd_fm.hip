@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
     // from the weight tensors (through the index maps of the f32 images composed with the operand order: all loads in flight
     // together, one round trip), rounds and stores them: no f32 images, one barrier.
     constexpr int KS1 = (K::K1S + 3) / 4;                 // bf16 k-steps of layer 1 (slots q = 3*c4 + f, zero padded)
-    constexpr int OP_W1 = 0, OP_W2 = OP_W1 + 4 * KS1, OP_W3T = OP_W2 + 16, OP_W2T = OP_W3T + 4, OP_W1T = OP_W2T + 16, OP_N = OP_W1T + 4 * K::MJ;
+    constexpr int OP_W1 = 0, OP_W2 = OP_W1 + 4 * KS1, OP_W3T = OP_W2 + 16, OP_W2T = OP_W3T + 4 * K::M3T, OP_W1T = OP_W2T + 16, OP_N = OP_W1T + 4 * K::MJ;
     static_assert(OP_N * 64 * 2 <= FK::OFF_B1, "bf16 operand image fits below the bias vectors");
     const bf_s16x4* const BW = reinterpret_cast<const bf_s16x4*>(smem) + lane;      // operand o of this lane: BW[o * 64]
     if constexpr (BFM) {
@@ -355,10 +355,10 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
                 const int m2 = (o - OP_W2) >> 2, kk = (o - OP_W2) & 3;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) raw[k][r] = gw(a.w2, map_w2((m2 * 16 + 4 * kk + r) * 64 + lane));
-            } else if (o < OP_W2T) {                   // W3^T: m
-                const int m = o - OP_W3T;
+            } else if (o < OP_W2T) {                   // W3^T: (m, k3): channels 16 k3 + 4g + r
+                const int m = (o - OP_W3T) / K::M3T, k3 = (o - OP_W3T) % K::M3T;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) raw[k][r] = gw(a.w3, map_w3t((m * 4 + r) * 64 + lane));
+                for (int r = 0; r < 4; ++r) raw[k][r] = gw(a.w3, map_w3t((m * 4 * K::M3T + 4 * k3 + r) * 64 + lane));
             } else if (o < OP_W1T) {                   // W2^T: (m, mp) = W2[h2 = 16mp+4g+r][h1 = 16m+ci]: four consecutive image elements
                 const int m = (o - OP_W2T) >> 2, mp = (o - OP_W2T) & 3;
 #pragma unroll
@@ -432,7 +432,12 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
                     nP[n][q] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), 0.0f, 0.0f};
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ndO[n][r] = __uint_as_float((unsigned)ds[n * K::DOS + 16 * r] << 16);
+                for (int m3 = 0; m3 < K::M3T; ++m3)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {   // channel 16 m3 + 4 gq + r (rows >= CP of the scratch are never written)
+                        if (CP % 16 == 0 || 16 * m3 + 4 * gq + r < CP) ndO[n][4 * m3 + r] = __uint_as_float((unsigned)ds[n * K::DOS + 256 * m3 + 16 * r] << 16);
+                        else ndO[n][4 * m3 + r] = 0.0f;
+                    }
             }
         } else {
             const f32x4* const ps = reinterpret_cast<const f32x4*>(ba.pscr) + (size_t)r_ * (K::KQ * 64) + lane_w;
@@ -539,27 +544,39 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
 #pragma unroll
                     for (int n = 0; n < NT; ++n) h2b[m2][n] = pack4_relu(h2f[m2][n]);
                 NCA_BPHASE(5);   // forward recompute
-                bf_s16x4 dOb[NT];
+                bf_s16x4 dOb[NT][K::M3T];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) dOb[n] = pack4(dOin[n][0], dOin[n][1], dOin[n][2], dOin[n][3]);   // (bf16 values: exact)
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m3 = 0; m3 < K::M3T; ++m3)   // (bf16 values: exact)
+                        dOb[n][m3] = pack4(dOin[n][4 * m3], dOin[n][4 * m3 + 1], dOin[n][4 * m3 + 2], dOin[n][4 * m3 + 3]);
                 bf_s16x4 d2b[4][NT], d1b[4][NT];
                 // ---- layer 3: dW3 += dO x h2 (cells as K);  d2 = (W3^T dO) * 1[h2 > 0] ---------------------------------------
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     wave_sync();
-                    tb_write(tb16, 0, lane, dOb[n]);
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) tb_write(tb16, 1 + m, lane, h2b[m][n]);
+                    for (int m3 = 0; m3 < K::M3T; ++m3) tb_write(tb16, m3, lane, dOb[n][m3]);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) tb_write(tb16, K::M3T + m, lane, h2b[m][n]);
                     wave_sync();
-                    const bf_s16x4 ta = tb_tr_read(tb16, 0, lane);
+                    bf_s16x4 tbv[4];
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) aW3[0][nb] = mfma_bf16(ta, tb_tr_read(tb16, 1 + nb, lane), aW3[0][nb]);
+                    for (int nb = 0; nb < 4; ++nb) tbv[nb] = tb_tr_read(tb16, K::M3T + nb, lane);
+#pragma unroll
+                    for (int m3 = 0; m3 < K::M3T; ++m3) {
+                        const bf_s16x4 ta = tb_tr_read(tb16, m3, lane);
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) aW3[m3][nb] = mfma_bf16(ta, tbv[nb], aW3[m3][nb]);
+                    }
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        f32x4 d = mfma_bf16(BW[(OP_W3T + m) * 64], dOb[n], f32x4{0.f, 0.f, 0.f, 0.f});
+                        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int m3 = 0; m3 < K::M3T; ++m3) d = mfma_bf16(BW[(OP_W3T + m * K::M3T + m3) * 64], dOb[n][m3], d);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { d[r] = (NW == 8 ? bf_nz(h2b[m][n], r) : h2f[m][n][r] > 0.0f) ? d[r] : 0.0f; }
                         db_add4(1, m, d);
@@ -603,7 +620,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
 #pragma unroll
                     for (int m = 0; m < 4; ++m) tb_write(tb16, m, lane, d1b[m][n]);
 #pragma unroll
-                    for (int s_ = 0; s_ < KS1; ++s_) tb_write_chunk(tb16, 16 + 3 * g + s_, lane, pb[n][s_]);   // columns 12g + 4s .. of tiles 4..6
+                    for (int s_ = 0; s_ < KS1; ++s_) tb_write_chunk(tb16, 16 + KS1 * g + s_, lane, pb[n][s_]);   // columns 4 KS1 g + 4s .. of tiles 4..4+MJ-1
                     wave_sync();
                     bf_s16x4 tbv[K::MJ];
 #pragma unroll
@@ -959,8 +976,8 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
                 if (o < hid) {
 #pragma unroll
                     for (int nb = 0; nb < K::MJ; ++nb) {
-                        if constexpr (BFM) {   // column 16nb + ci = 12 g' + q, q = 3 c4 + f: channel 4 c4 + g', filter f
-                            const int col = 16 * nb + ci, gp = col / 12, q = col - 12 * gp, j = 3 * (4 * (q / 3) + gp) + q % 3;
+                        if constexpr (BFM) {   // column 16nb + ci = 4 KS1 g' + q, q = 3 c4 + f: channel 4 c4 + g', filter f
+                            const int col = 16 * nb + ci, gp = col / (4 * KS1), q = col - 4 * KS1 * gp, j = 3 * (4 * (q / 3) + gp) + q % 3;
                             if (gp < 4 && q < K::K1S && j < K1) sw[o * K1 + j] = aW1[ma][nb][r];
                         } else if (16 * nb + ci < K1) sw[o * K1 + 16 * nb + ci] = aW1[ma][nb][r];
                     }
@@ -1014,8 +1031,8 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
             if (o < hid) {
 #pragma unroll
                 for (int nb = 0; nb < K::MJ; ++nb) {
-                    if constexpr (BFM) {   // column 16nb + ci = 12 g' + q, q = 3 c4 + f: channel 4 c4 + g', filter f
-                        const int col = 16 * nb + ci, gp = col / 12, q = col - 12 * gp, j = 3 * (4 * (q / 3) + gp) + q % 3;
+                    if constexpr (BFM) {   // column 16nb + ci = 4 KS1 g' + q, q = 3 c4 + f: channel 4 c4 + g', filter f
+                        const int col = 16 * nb + ci, gp = col / (4 * KS1), q = col - 4 * KS1 * gp, j = 3 * (4 * (q / 3) + gp) + q % 3;
                         if (gp < 4 && q < K::K1S && j < K1) sw[o * K1 + j] = aW1[ma][nb][r];
                     } else if (16 * nb + ci < K1) sw[o * K1 + 16 * nb + ci] = aW1[ma][nb][r];
                 }
@@ -1098,7 +1115,7 @@ hipError_t launch_fm(const NcaCondBwdArgs& ba_in, hipStream_t st) {
                                        : go(cond_step_bwd_front_kernel<CP, ST, BFM, false>, attr_g);
         if (e != hipSuccess) return e;
     }
-    constexpr int NW = BFM ? 8 : 4;   // bf16 MFMA: two waves per SIMD
+    constexpr int NW = (BFM && CP <= 16) ? 8 : 4;   // bf16 MFMA: two waves per SIMD (CP <= 16: 128 accumulators; wider: 160, one wave per SIMD)
     using KM = MCfg<CP, NW>;
     auto kern = cond_step_bwd_mlp_kernel<CP, ST, BFM, NW, NTW>;
     const size_t lds = (size_t)KM::LDS_FLOATS * sizeof(float);
@@ -1132,6 +1149,7 @@ hipError_t nca_launch_cond_step_bwd_fm(const NcaCondBwdArgs& ba, hipStream_t st,
     if (ba.f.C > 32 || !ba.pscr || !ba.doscr) return hipErrorInvalidValue;
     if (ba.f.C > 16) {   // wide channel counts (the reference's default model is C = 20): fp32 products only; bf16 history up to C = 20
         if (mode == 1 && ba.f.C <= 20) return launch_fm<20, StBF16, false>(ba, st);
+        if (mode == 2 && ba.f.C <= 20) return launch_fm<20, StBF16, true>(ba, st);
         if (mode != 0) return hipErrorInvalidValue;
         if (ba.f.C <= 20) return launch_fm<20, StF32, false>(ba, st);
         if (ba.f.C <= 24) return launch_fm<24, StF32, false>(ba, st);

@@ -91,9 +91,8 @@ def cond_grow_autograd(model, x: torch.Tensor, goal: Optional[torch.Tensor], T: 
     u = model.update_net.out
     params = (model.perception_net.weight, u[0].weight, u[0].bias, u[2].weight, u[2].bias, u[4].weight)
     if bf16 and (x.shape[1] > 20 or x.shape[3] % 4 != 0):
-        # the bf16-storage kernels cover C <= 20 (the reference default model) at W % 4 == 0 -- bf16 MFMA products up to C = 16,
-        # exact-f32 products in the backward of 16 < C <= 20 (storage format only); anything else keeps its bf16 POOL but steps in
-        # fp32 (widening is exact) and returns the pool's dtype
+        # the bf16-storage kernels (forward and backward on bf16 MFMA) cover C <= 20 -- the reference default model -- at
+        # W % 4 == 0; anything else keeps its bf16 POOL but steps in fp32 (widening is exact) and returns the pool's dtype
         return cond_grow_autograd(model, x.float(), goal, T).to(torch.bfloat16)
     x = x.contiguous() if bf16 else x.float().contiguous()
     us = model._draw(x, T)
