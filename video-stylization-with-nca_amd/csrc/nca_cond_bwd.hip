@@ -797,7 +797,9 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
 // three-row sliding window held in registers: every row of z / dL/dP is loaded once per thread (16-byte loads,
 // left/right neighbours by wavefront shuffle with a scalar fallback at row/wave edges), and the 27 perception-weight
 // sums are reduced across the block once per strip.  A block never spans two channels.
-constexpr int SROWS = 16;
+constexpr int SROWS = 16;   // tallest strip.  The launcher picks 16, 8 or 4 rows per strip (nca_cond_bwd_srows): a launch whose wave count
+                            // is not a multiple of the chip's resident waves (two per SIMD at 192-200 registers) pays for the last partial
+                            // round in full, and shorter strips make that round cheaper (or, on small grids, fill the chip at all)
 struct Row6 { float v[6]; };   // columns x0-1 .. x0+4
 
 // Two-stage row fetch: issue (raw 16-byte group + the two edge cells that have no neighbour lane) and finish (shuffle the
@@ -854,13 +856,14 @@ __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCon
     const NcaCondArgs& a = ba.f;
     const int C = a.C, H = a.H, W = a.W;
     const size_t plane = (size_t)H * W;
-    const int W4 = W / 4, strips = (H + SROWS - 1) / SROWS;
+    const int SR = ba.srows;
+    const int W4 = W / 4, strips = (H + SR - 1) / SR;
     const int per_plane = strips * W4, blocks_per_plane = (per_plane + 255) / 256;
     const int bc = blockIdx.x / blocks_per_plane, b = bc / C, c = bc % C;
     const int id = (blockIdx.x % blocks_per_plane) * 256 + threadIdx.x;
     const bool active = id < per_plane;
     const int ida = active ? id : per_plane - 1;      // inactive lanes shadow the last item (they still shuffle)
-    const int x0 = (ida % W4) * 4, y0 = (ida / W4) * SROWS;
+    const int x0 = (ida % W4) * 4, y0 = (ida / W4) * SR;
     const int lane = threadIdx.x & 63;
     const bool has_l = x0 > 0 && lane > 0, has_r = x0 + 4 < W && lane < 63 && id + 1 < per_plane;
     float wl[27];
@@ -901,7 +904,7 @@ __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCon
     };
     issue_rmw(y0);
 #pragma unroll 1
-    for (int k = 0; k < SROWS; ++k) {
+    for (int k = 0; k < SR; ++k) {
         const int y = y0 + k;
         zn = issue_row6(zb, H, W, y + 2, x0, has_l, has_r);
 #pragma unroll
@@ -994,6 +997,31 @@ __global__ __launch_bounds__(64) void reduce_wp_kernel(const float* __restrict__
 
 int g_bwd_variant = [] { const char* e = getenv("NCAHIP_BWD_VARIANT"); return e ? atoi(e) : 0; }();
 
+// rows per strip of kernel B: modelled cost = rounds of resident waves x (rows + 2 halo rows), smallest wins (ties: taller strips)
+int stencil_srows(int B, int C, int H, int W) {
+    const long slots = (long)nca_cu_count() * 8;   // two waves per SIMD
+    int best = SROWS;
+    long best_cost = -1;
+    for (int sr = SROWS; sr >= 4; sr /= 2) {
+        const long per_plane = (long)((H + sr - 1) / sr) * (W / 4), waves = (long)B * C * ((per_plane + 255) / 256) * 4;
+        const long cost = ((waves + slots - 1) / slots) * (sr + 2);
+        if (best_cost < 0 || cost < best_cost) { best = sr; best_cost = cost; }
+    }
+    return best;
+}
+int stencil_blocks(int B, int C, int H, int W, int sr) { return B * C * ((((H + sr - 1) / sr) * (W / 4) + 255) / 256); }
+
+hipError_t launch_stencil(const NcaCondBwdArgs& ba_in, hipStream_t st, bool bf16_scratch) {
+    NcaCondBwdArgs ba = ba_in;
+    const NcaCondArgs& a = ba.f;
+    ba.srows = stencil_srows(a.B, a.C, a.H, a.W);
+    const int nblk = stencil_blocks(a.B, a.C, a.H, a.W, ba.srows);
+    if (nblk > ba.nblk) return hipErrorInvalidValue;   // wp_partials holds ba.nblk rows (nca_cond_bwd_nblk)
+    if (bf16_scratch) hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<uint16_t>, dim3(nblk), dim3(256), 0, st, ba);
+    else hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<float>, dim3(nblk), dim3(256), 0, st, ba);
+    return hipGetLastError();
+}
+
 template <int CP, typename ST, bool BFM = false>
 hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
     // Kernel A exists in two forms with the same results (the products run in the same per-wave order): ONE launch, everything
@@ -1003,9 +1031,7 @@ hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
     const bool fm = ba.pscr && ba.doscr && (g_bwd_variant == 2 || (g_bwd_variant == 0 && BFM) || (g_bwd_variant == 3 && !BFM));
     if (fm) {
         if (hipError_t e = nca_launch_cond_step_bwd_fm(ba, st, BFM ? 2 : (ST::BYTES == 2 ? 1 : 0)); e != hipSuccess) return e;
-        if (BFM) hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<uint16_t>, dim3(ba.nblk), dim3(256), 0, st, ba);
-        else hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<float>, dim3(ba.nblk), dim3(256), 0, st, ba);
-        return hipGetLastError();
+        return launch_stencil(ba, st, BFM);
     }
     using K = BCfg<CP>;
     auto kern = cond_step_bwd_kernel<CP, ST, BFM>;
@@ -1024,16 +1050,14 @@ hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
 #endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (BFM) hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<uint16_t>, dim3(ba.nblk), dim3(256), 0, st, ba);
-    else hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<float>, dim3(ba.nblk), dim3(256), 0, st, ba);
-    return hipGetLastError();
+    return launch_stencil(ba, st, BFM);
 }
 
 }  // namespace
 
 int nca_cond_bwd_slab_floats(int C, int hidden) { return slab_floats(C, hidden); }
 int nca_cond_bwd_nslab() { return nca_cu_count(); }   // one persistent workgroup (and one slab) per CU
-int nca_cond_bwd_nblk(int B, int C, int H, int W) { return B * C * ((((H + SROWS - 1) / SROWS) * (W / 4) + 255) / 256); }
+int nca_cond_bwd_nblk(int B, int C, int H, int W) { return stencil_blocks(B, C, H, W, stencil_srows(B, C, H, W)); }
 
 static bool g_bwd_bf16_exact = getenv("NCAHIP_BWD_BF16_EXACT") != nullptr;
 void nca_set_bwd_bf16_exact(bool on) { g_bwd_bf16_exact = on; }
@@ -1052,9 +1076,7 @@ hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st, bo
                               // SIMD); with the exact hook: exact-f32 products of the widened history, as the fp32 form
             if (!ba.pscr || !ba.doscr) return hipErrorInvalidValue;
             if (hipError_t e = nca_launch_cond_step_bwd_fm(ba, st, g_bwd_bf16_exact ? 1 : 2); e != hipSuccess) return e;
-            if (g_bwd_bf16_exact) hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<float>, dim3(ba.nblk), dim3(256), 0, st, ba);
-            else hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<uint16_t>, dim3(ba.nblk), dim3(256), 0, st, ba);
-            return hipGetLastError();
+            return launch_stencil(ba, st, !g_bwd_bf16_exact);
         }
         return hipErrorInvalidValue;
     }
@@ -1063,8 +1085,7 @@ hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st, bo
     if (ba.f.C <= 32) {   // 16 < C <= 32 (the reference's default model is C = 20, nca.py:62-94): front + matrix kernels only
         if (!ba.pscr || !ba.doscr) return hipErrorInvalidValue;
         if (hipError_t e = nca_launch_cond_step_bwd_fm(ba, st, 0); e != hipSuccess) return e;
-        hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<float>, dim3(ba.nblk), dim3(256), 0, st, ba);
-        return hipGetLastError();
+        return launch_stencil(ba, st, false);
     }
     return hipErrorInvalidValue;
 }
@@ -1074,7 +1095,7 @@ hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hi
     return hipGetLastError();
 }
 hipError_t nca_launch_reduce_wp(const float* part, float* dst, int B, int C, int H, int W, hipStream_t st) {
-    const int bpp = (((H + SROWS - 1) / SROWS) * (W / 4) + 255) / 256;
+    const int sr = stencil_srows(B, C, H, W), bpp = (((H + sr - 1) / sr) * (W / 4) + 255) / 256;
     hipLaunchKernelGGL(reduce_wp_kernel, dim3(C), dim3(64), 0, st, part, dst, B, C, bpp);
     return hipGetLastError();
 }

@@ -129,6 +129,7 @@ struct NcaCondBwdArgs {
     float* slabs;           // per-workgroup weight-gradient partials, accumulated   [nslab, slab_floats]
     float* wp_partials;     // per-block perception-weight partials             [nblk, 27] accumulated
     int nslab, nblk;
+    int srows;              // rows per strip of the stencil-adjoint kernel (set by its launcher: nca_cond_bwd_srows)
     void* pscr;             // front/matrix form: perception vectors in MFMA-operand order  (nca_cond_bwd_fm_pscr_bytes)
     void* doscr;            // front/matrix form: dL/dx'_t * fire mask, [row tile][channel][cell] (nca_cond_bwd_fm_doscr_bytes)
 };
