@@ -756,7 +756,7 @@ static int cond_grow_bwd_impl(const void* states_v, int sb, const uint8_t* pre, 
     const bool bf16 = sb == 2;
     if (T < 1 || !states || !pre || !g_final || !g_x0 || !g_wp || !g_w1 || !g_b1 || !g_w2 || !g_b2 || !g_w3 || !workspace)
         return fail(NCAHIP_EINVAL, "cond grow bwd: null pointer or T < 1");
-    // fp32 history: C <= 32 (16 < C <= 32 on the front + matrix kernels); bf16 history: C <= 20 (as the bf16 forward; 16 < C: exact-f32 products)
+    // fp32 history: C <= 32 (16 < C <= 32 on the front + matrix kernels); bf16 history: C <= 20 (as the bf16 forward)
     if (int rc = check_cond(states, g_x0, pre, goal_v, wp, w1, b1, w2, b2, w3, B, C, H, W, hidden, goal_ch, alive_ch, bf16 ? kMaxCCondFwdBf16 : kMaxCCondFwd)) return rc;
     if (goal_ch > 0 && !g_goal) return fail(NCAHIP_EINVAL, "cond grow bwd: g_goal required when goal_ch > 0");
     const uintptr_t amask = bf16 ? 7 : 15;   // state-type tensors: 4-cell groups (16 bytes fp32, 8 bytes bf16)

@@ -851,12 +851,12 @@ __device__ __forceinline__ Row6 load_row6(const ET* __restrict__ plane, int H, i
 }
 
 // ET = element type of the two scratch tensors kernel A wrote (z_t, dL/dperception): float, or uint16_t (bf16) behind the BFM kernel A
-template <typename ET>
+template <typename ET, int SR>
 __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCondBwdArgs ba) {
     const NcaCondArgs& a = ba.f;
     const int C = a.C, H = a.H, W = a.W;
     const size_t plane = (size_t)H * W;
-    const int SR = ba.srows;
+    static_assert(SR == 16 || SR == 8 || SR == 4, "strip heights the launcher chooses from");
     const int W4 = W / 4, strips = (H + SR - 1) / SR;
     const int per_plane = strips * W4, blocks_per_plane = (per_plane + 255) / 256;
     const int bc = blockIdx.x / blocks_per_plane, b = bc / C, c = bc % C;
@@ -1017,9 +1017,14 @@ hipError_t launch_stencil(const NcaCondBwdArgs& ba_in, hipStream_t st, bool bf16
     ba.srows = stencil_srows(a.B, a.C, a.H, a.W);
     const int nblk = stencil_blocks(a.B, a.C, a.H, a.W, ba.srows);
     if (nblk > ba.nblk) return hipErrorInvalidValue;   // wp_partials holds ba.nblk rows (nca_cond_bwd_nblk)
-    if (bf16_scratch) hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<uint16_t>, dim3(nblk), dim3(256), 0, st, ba);
-    else hipLaunchKernelGGL(cond_step_bwd_stencil_kernel<float>, dim3(nblk), dim3(256), 0, st, ba);
-    return hipGetLastError();
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), 0, st, ba);
+        return hipGetLastError();
+    };
+    if (bf16_scratch) return ba.srows == 16 ? go(cond_step_bwd_stencil_kernel<uint16_t, 16>) : ba.srows == 8 ? go(cond_step_bwd_stencil_kernel<uint16_t, 8>)
+                                                                                                             : go(cond_step_bwd_stencil_kernel<uint16_t, 4>);
+    return ba.srows == 16 ? go(cond_step_bwd_stencil_kernel<float, 16>) : ba.srows == 8 ? go(cond_step_bwd_stencil_kernel<float, 8>)
+                                                                                         : go(cond_step_bwd_stencil_kernel<float, 4>);
 }
 
 template <int CP, typename ST, bool BFM = false>
