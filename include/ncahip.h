@@ -75,7 +75,9 @@ int ncahip_cond_precision(int mode);
  * bit 1 = symmetric wave-private ConditionedNCA kernel instead of the default producer/consumer one;
  * bit 2 = ncahip_cond_grow_bwd_bf16 evaluates its matrix products in exact fp32 instead of on bf16 MFMA;
  * bit 3 = the ConditionedNCA backward runs its main kernel in the other of its two forms (one launch <-> front kernel +
- * matrix kernel; same results, each mode defaults to the faster one: an independent implementation to cross-check with). */
+ * matrix kernel; same results, each mode defaults to the faster one: an independent implementation to cross-check with);
+ * bit 4 = the matrix kernel walks whole super-tiles on small grids as well (by default a grid with fewer super-tiles than half
+ * the CUs gives each workgroup half a super-tile; with this bit its summation order equals the one-launch form's bit for bit). */
 int ncahip_debug_force_generic(int on);
 
 /* Device-side check that the MFMA operand/accumulator lane maps the kernels assume hold on

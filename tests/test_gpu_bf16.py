@@ -365,14 +365,20 @@ def test_cond_backward_kernel_forms_agree(ops, dtype, C, shape, gch, Tn):
     _, states, pre = ops.cond_grow(xd, Tn, gd, ud, w, 3, keep_history=True)
     res = []
     try:
-        for form in (0, 8):
+        # bit 3 (8) = the form that is not the default, bit 4 (16) = the matrix kernel walks whole super-tiles.  On these small grids the
+        # default is front + matrix with every super-tile split over two workgroups, so: 16 = front + matrix unsplit, 8 | 16 = one launch,
+        # 0 = front + matrix split
+        for form in (8 | 16, 16, 0):
             ops.force_generic(form)
             res.append(ops.cond_grow_backward(states, pre, gd, ud, w, cd, Tn, 3))
             ops.check_errors()
     finally:
         ops.force_generic(0)
-    one, two = res
+    one, two, split = res
     for k in one:
+        # the split: same products, the partial sums of a super-tile meet in another order (two slabs)
+        ds = float((split[k] - two[k]).abs().max()) / max(1e-12, float(two[k].abs().max()))
+        assert ds <= 2e-6, (k, ds)
         if dtype == torch.float32:
             assert torch.equal(one[k], two[k]), k
         else:
@@ -410,7 +416,7 @@ def test_cond_backward_forms_fuzz(ops):
         _, states, pre = ops.cond_grow(xd, Tn, gd, us, w, ach, seed=case, keep_history=True)
         res = []
         try:
-            for form in (0, 8):
+            for form in (16, 8 | 16):     # the two forms with whole super-tiles per workgroup (the split of small grids: test_cond_backward_kernel_forms_agree)
                 ops.force_generic(form)
                 res.append(ops.cond_grow_backward(states, pre, gd, us, w, cot, Tn, ach, seed=case))
                 ops.check_errors()

@@ -172,6 +172,10 @@ def loss_leg():
     from ncahip.loss import Loss
     dev = torch.device(DEV)
     style = (np.random.RandomState(0).rand(256, 256, 3) * 255).astype(np.uint8)
+    if os.environ.get("NCAHIP_MIOPEN_BENCHMARK") == "1":      # probe: MIOpen's exhaustive find instead of its immediate-mode pick
+        torch.backends.cudnn.benchmark = True
+    import time as _time
+    _t0 = _time.perf_counter()
     for name, dt, cl in (("float32", torch.float32, False), ("bfloat16", torch.bfloat16, False), ("bfloat16 NHWC", torch.bfloat16, True)):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -184,7 +188,8 @@ def loss_leg():
             gen.grad = None
             L(d)[0].backward()
         (ms,), (mn,) = timed([f], iters=10)
-        emit(path="cfg3_loss", features=name, B=32, ms_fwd_bwd=ms, min_ms=mn, objective="overflow + OT appearance (batched) + content, VGG16 random weights")
+        emit(path="cfg3_loss", features=name, B=32, ms_fwd_bwd=ms, min_ms=mn, objective="overflow + OT appearance (batched) + content, VGG16 random weights",
+             miopen_benchmark=bool(torch.backends.cudnn.benchmark), wall_s_so_far=_time.perf_counter() - _t0)
 
 
 def video_leg():

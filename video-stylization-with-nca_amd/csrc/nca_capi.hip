@@ -161,6 +161,7 @@ int ncahip_debug_force_generic(int on) {
     nca_set_cond_variant((on >> 1) & 1);     // bit 1: symmetric wave-private ConditionedNCA kernel instead of producer/consumer
     nca_set_bwd_bf16_exact((on & 4) != 0);   // bit 2: bf16-history backward with exact-f32 products instead of bf16 MFMA
     nca_set_bwd_variant((on & 8) ? 3 : 0);   // bit 3: ConditionedNCA backward kernel A in the form that is NOT the mode's default (one launch <-> front + matrix)
+    nca_set_bwd_fm_nosplit((on & 16) != 0);  // bit 4: the matrix kernel walks whole super-tiles on small grids too (its summation order then equals the one-launch form's)
     return 0;
 }
 

@@ -1033,7 +1033,11 @@ hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
     // for a tile in one wave (this file), or TWO launches, front + matrix part (nca_cond_bwd_fm.hip).  Measured at 8 x 16 x 256^2:
     // fp32 products 360 vs 370 us per backward step, bf16 MFMA 196 vs 191 us -- each mode defaults to its faster form, the test
     // hook (ncahip_debug_force_generic bit 3) swaps them so that the parity suite checks both.
-    const bool fm = ba.pscr && ba.doscr && (g_bwd_variant == 2 || (g_bwd_variant == 0 && BFM) || (g_bwd_variant == 3 && !BFM));
+    // Small grids (fewer super-tiles than half the CUs): the matrix kernel splits each super-tile over two workgroups, which the one-launch
+    // form cannot -- front + matrix is then the faster form for fp32 products as well (64 x 64, batch 8, C = 16: 53 -> ~40 us per step).
+    const int nst_ = ba.f.B * ((ba.f.W + 15) / 16) * ((ba.f.H + 15) / 16);
+    const bool default_fm = BFM || 2 * nst_ <= ba.nslab;
+    const bool fm = ba.pscr && ba.doscr && (g_bwd_variant == 2 || (g_bwd_variant == 0 && default_fm) || (g_bwd_variant == 3 && !default_fm));
     if (fm) {
         if (hipError_t e = nca_launch_cond_step_bwd_fm(ba, st, BFM ? 2 : (ST::BYTES == 2 ? 1 : 0)); e != hipSuccess) return e;
         return launch_stencil(ba, st, BFM);

@@ -457,21 +457,27 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
         }
         pre_rid = r_;
     };
-    for (NcaTileWalk tw = nca_tile_walk(a.B * st_x * st_y); tw.t < tw.end; tw.t += tw.stride) {
+    // Walk items: super-tiles -- or, on grids with fewer super-tiles than half the workgroup slots (ba.msplit), (super-tile, pass)
+    // pairs, so that twice as many workgroups share the work (the launch is otherwise one super-tile per workgroup on half the chip,
+    // behind a fixed start-up + flush of ~20 us).  Item i = super-tile i >> msplit, the first or second half of the passes by i & 1.
+    const int msplit = ba.msplit;
+    for (NcaTileWalk tw = nca_tile_walk((a.B * st_x * st_y) << msplit); tw.t < tw.end; tw.t += tw.stride) {
         int lane = lane_w;   // opaque per tile: lane-derived offsets are recomputed where used, not hoisted out of the tile loop and spilled
         asm volatile("" : "+v"(lane));
         const int g = (lane >> 4) & 3, ci = lane & 15;
         WTile t;
-        t.b = tw.t / (st_x * st_y);
-        t.ty0 = ((tw.t / st_x) % st_y) * BSTH + tslot * WTH;
-        t.tx0 = (tw.t % st_x) * BSTW;
+        const int sti = tw.t >> msplit;                    // super-tile of this item
+        t.b = sti / (st_x * st_y);
+        t.ty0 = ((sti / st_x) % st_y) * BSTH + tslot * WTH;
+        t.tx0 = (sti % st_x) * BSTW;
         if (t.ty0 >= H || t.tx0 >= W) continue;
         const int ty0 = t.ty0, tx0 = t.tx0;
         NCA_BPHASE(0);   // loop overhead / previous tile's tail
         const int nbase = NW == 8 ? (wave & 1) * 2 : 0;   // first row of this wave inside the tile
-        const size_t rid0 = ((size_t)tw.t * kBwdWaves + tslot) * WTH + nbase;   // 16-cell row tiles of the front kernel's scratch
+        const size_t rid0 = ((size_t)sti * kBwdWaves + tslot) * WTH + nbase;   // 16-cell row tiles of the front kernel's scratch
+        const int pass0 = msplit ? (tw.t & 1) * (NPASS / 2) : 0, pass1 = msplit ? pass0 + NPASS / 2 : NPASS;
 #pragma unroll 1
-        for (int pass = 0; pass < NPASS; ++pass) {
+        for (int pass = pass0; pass < pass1; ++pass) {
             const int n0 = nbase + pass * NT;
             // ---- forward recompute: P, h1, h2 kept in registers ------------------------------------------
             // ---- this pass's two 16-cell rows from the front kernel's scratch: the perception vector in B-operand order
@@ -498,10 +504,10 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
             {
                 long nrid = rid + NT;
                 bool has = true;
-                if (pass == NPASS - 1) {
+                if (pass == pass1 - 1) {
                     const int tn = tw.t + tw.stride;
                     has = tn < tw.end;
-                    nrid = (long)(((size_t)tn * kBwdWaves + tslot) * WTH + nbase);
+                    nrid = (long)(((size_t)(tn >> msplit) * kBwdWaves + tslot) * WTH + nbase + (msplit ? (tn & 1) * (NPASS / 2) * NT : 0));
                 }
                 if (has) fetch(nrid);
                 else pre_rid = -1;
@@ -1096,6 +1102,8 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
 }
 
 
+bool g_fm_nosplit = false;   // test hook (ncahip_debug_force_generic bit 4): whole super-tiles per walk item on every grid
+
 template <int CP, typename ST, bool BFM, int NTW = 2>
 hipError_t launch_fm(const NcaCondBwdArgs& ba_in, hipStream_t st) {
     NcaCondBwdArgs ba = ba_in;
@@ -1121,7 +1129,9 @@ hipError_t launch_fm(const NcaCondBwdArgs& ba_in, hipStream_t st) {
     const size_t lds = (size_t)KM::LDS_FLOATS * sizeof(float);
     static NcaLdsAttr attr;
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
-    const int grid = nst < ba.nslab ? nst : ba.nslab;   // one slab per workgroup
+    ba.msplit = (!g_fm_nosplit && 2 * nst <= ba.nslab) ? 1 : 0;           // small grids: (super-tile, pass) items
+    const int items = nst << ba.msplit;
+    const int grid = items < ba.nslab ? items : ba.nslab;               // one slab per workgroup
 #if defined(NCA_STAMPS)
     ba.f.dbg = nca_debug_stamp_ptr();
 #endif
@@ -1130,6 +1140,8 @@ hipError_t launch_fm(const NcaCondBwdArgs& ba_in, hipStream_t st) {
 }
 
 }  // namespace
+
+void nca_set_bwd_fm_nosplit(bool on) { g_fm_nosplit = on; }
 
 // channel padding of the instantiation that serves C channels
 static int fm_cp(int C) { return C <= 12 ? 12 : (C <= 16 ? 16 : (C <= 20 ? 20 : (C <= 24 ? 24 : 32))); }

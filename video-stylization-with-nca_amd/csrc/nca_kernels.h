@@ -130,12 +130,14 @@ struct NcaCondBwdArgs {
     float* wp_partials;     // per-block perception-weight partials             [nblk, 27] accumulated
     int nslab, nblk;
     int srows;              // rows per strip of the stencil-adjoint kernel (set by its launcher: nca_cond_bwd_srows)
+    int msplit;             // matrix kernel: 1 = a workgroup takes ONE pass (half the rows) of a super-tile per walk item (small grids: twice the workgroups)
     void* pscr;             // front/matrix form: perception vectors in MFMA-operand order  (nca_cond_bwd_fm_pscr_bytes)
     void* doscr;            // front/matrix form: dL/dx'_t * fire mask, [row tile][channel][cell] (nca_cond_bwd_fm_doscr_bytes)
 };
 int nca_cond_bwd_slab_floats(int C, int hidden);
 int nca_cond_bwd_nslab();
 int nca_cond_bwd_nblk(int B, int C, int H, int W);
+void nca_set_bwd_fm_nosplit(bool on);
 hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& a, hipStream_t st, bool bf16 = false);   // bf16: f.x_in / x_next / f.goal hold bf16
 // kernel A as two launches (nca_cond_bwd_fm.hip); mode 0 = f32 history, 1 = bf16 history / exact-f32 products, 2 = bf16 MFMA
 hipError_t nca_launch_cond_step_bwd_fm(const NcaCondBwdArgs& a, hipStream_t st, int mode);
