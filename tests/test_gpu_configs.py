@@ -285,6 +285,38 @@ def test_cfg3_batch_independence_and_determinism(ops):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_default_model_c20_full_size_properties(ops, dtype):
+    """The reference's default channel count (C = 20, nca.py:62-94) at the bench grid, 8 x 20 x 256^2, 3 steps, fp32 and bf16 pool
+    (size-independent properties; values are pinned at small sizes by G11 and the oracle tests): the backward is LINEAR in the
+    cotangent (every gradient of a*c1 + b*c2 equals a*g(c1) + b*g(c2) to rounding), two identical calls agree bit for bit
+    (deterministic slabs, no float atomics), items 2..3 of the batch equal a 2-item call (forward and dL/dx0 / dL/dgoal bit for bit)."""
+    B, C, S, Tn = 8, 20, 256, 3
+    prm = rand_cond_prm(C, seed=6, out_scale=0.5)
+    gen = torch.Generator().manual_seed(22)
+    x = torch.rand(B, C, S, S, generator=gen).to(DEV).to(dtype)
+    goal = (torch.randn(B, 16, S, S, generator=gen) * 0.5).to(DEV).to(dtype)
+    us = torch.rand(Tn, B, 1, S, S, generator=gen).to(DEV)
+    c1 = torch.randn(B, C, S, S, generator=gen).to(DEV)
+    c2 = torch.randn(B, C, S, S, generator=gen).to(DEV)
+    w = cond_w(ops, prm, x)
+    out, states, pre = ops.cond_grow(x, Tn, goal, us, w, 3, keep_history=True)
+    assert states.dtype == dtype and bool(torch.isfinite(out.float()).all())
+    g1 = ops.cond_grow_backward(states, pre, goal, us, w, c1, Tn, 3)
+    g1b = ops.cond_grow_backward(states, pre, goal, us, w, c1, Tn, 3)
+    g2 = ops.cond_grow_backward(states, pre, goal, us, w, c2, Tn, 3)
+    g12 = ops.cond_grow_backward(states, pre, goal, us, w, 0.75 * c1 - 1.5 * c2, Tn, 3)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2      # bf16 MFMA rounds the gradient operands of its products: linear up to bf16 rounding
+    for k in g1:
+        assert torch.equal(g1[k], g1b[k]), k
+        lin = 0.75 * g1[k] - 1.5 * g2[k]
+        assert _rel(g12[k].reshape(-1), lin.reshape(-1)) < tol, (k, _rel(g12[k].reshape(-1), lin.reshape(-1)))
+    sl = slice(2, 4)
+    o2, s2, p2 = ops.cond_grow(x[sl].contiguous(), Tn, goal[sl].contiguous(), us[:, sl].contiguous(), w, 3, keep_history=True)
+    h2 = ops.cond_grow_backward(s2, p2, goal[sl].contiguous(), us[:, sl].contiguous(), w, c1[sl].contiguous(), Tn, 3)
+    assert torch.equal(out[sl], o2) and torch.equal(g1["x0"][sl], h2["x0"]) and torch.equal(g1["goal"][sl], h2["goal"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_cfg3_full_length_module_training_step(ops, dtype):
     """configs[2] as the trainer issues it: ConditionedNCA.grow(B=32, 96 steps) + a loss + backward + finite gradients for
     every parameter (encoder included), fp32 and bf16 pool.  Values are pinned by the crop test above; this is the
