@@ -10,3 +10,7 @@ for seed in 1 31337 90210 4242; do
   echo "== NCAHIP_FUZZ_SEED=$seed (48 cases)"
   NCAHIP_FUZZ_SEED=$seed NCAHIP_FUZZ_CASES=48 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "shape_fuzz" 2>&1 | tail -2
 done
+for seed in 7 2024; do
+  echo "== NCAHIP_FUZZ_SEED=$seed: the two forms of backward kernel A + bf16 tests"
+  NCAHIP_FUZZ_SEED=$seed NCAHIP_FUZZ_CASES=24 timeout -k 10 600 python -m pytest tests/test_gpu_bf16.py -q -m gpu 2>&1 | tail -2
+done
