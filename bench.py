@@ -18,6 +18,8 @@ Extra objects on the JSON line:
   roofline_stencil  standalone DyNCA perception stencil: HBM bound, 20*C bytes/cell.
   bf16_storage      the same grow loop on the bf16-storage kernels (informational; `value` stays the fp32 path).
   backward          the recompute-based backward of the same loop (fp32 / bf16 history), per step (informational).
+  default_model_c20 the reference's DEFAULT ConditionedNCA (C = 20) at the same grid: forward, forward with history + backward, fp32 and
+                    bf16 pool (informational).
   f32_bf16x3        the same loop with ncahip_cond_precision(1) (opt-in bf16-pair emulation of the fp32 products).
   train             ConditionedNCATrainer iterations at BASELINE configs[2] as written (B=32, T=96, bf16 pool, the default
                     objective on seeded-random VGG16) + stand-in objective lines, with per-phase device times; on every rank
@@ -405,6 +407,30 @@ def main():
                 result["backward"][name] = {"fwd_us_per_step": ms_f * 1e3, "bwd_us_per_step": ms_w * 1e3, "bwd_over_fwd": ms_w / ms_f,
                                             "fwd_bwd_cell_updates_per_s": cells / ((ms_f + ms_w) * 1e-3)}
                 del st_h, pre_h
+            # ---- the reference's DEFAULT ConditionedNCA (nca.py:62-94: 3 rgb + 1 alpha + 16 hidden = 20 channels) at the bench grid:
+            # forward (producer/consumer kernel, wide LDS carve), forward with history + fused backward, fp32 and bf16 pool: informational
+            C20, G20 = 20, 16
+            g20 = torch.Generator().manual_seed(20)
+            p20 = {"wp": torch.randn(3 * C20, 1, 3, 3, generator=g20) * 0.3, "w1": torch.randn(HIDDEN, 3 * C20, 1, 1, generator=g20) / (3 * C20) ** 0.5,
+                   "b1": torch.randn(HIDDEN, generator=g20) * 0.1, "w2": torch.randn(HIDDEN, HIDDEN, 1, 1, generator=g20) / HIDDEN ** 0.5,
+                   "b2": torch.randn(HIDDEN, generator=g20) * 0.1, "w3": torch.randn(C20, HIDDEN, 1, 1, generator=g20) * (0.02 / HIDDEN ** 0.5)}
+            x20 = torch.rand(B, C20, H, W, generator=g20).to(dev)
+            gl20 = (torch.randn(B, G20, H, W, generator=g20) * 0.5).to(dev)
+            cot20 = torch.randn(B, C20, H, W, generator=g20).to(dev)
+            w20 = ops.CondWeights(p20["wp"], p20["w1"], p20["b1"], p20["w2"], p20["b2"], p20["w3"], x20)
+            flop20 = 2 * (27 * C20 + 256 * C20 + 4096)
+            result["default_model_c20"] = {"C": C20, "nca_steps": TB_, "flops_per_cell": flop20}
+            for name, xq, gq in (("f32", x20, gl20), ("bf16", x20.bfloat16(), gl20.bfloat16())):
+                ms_i = event_ms(lambda: ops.cond_grow(xq, T, gq, None, w20, ALIVE_CH, seed=42), 3) / T
+                _, st_h, pre_h = ops.cond_grow(xq, TB_, gq, None, w20, ALIVE_CH, seed=42, keep_history=True)
+                ms_f = event_ms(lambda: ops.cond_grow(xq, TB_, gq, None, w20, ALIVE_CH, seed=42, keep_history=True), 3) / TB_
+                ms_w = event_ms(lambda: ops.cond_grow_backward(st_h, pre_h, gq, None, w20, cot20, TB_, ALIVE_CH, seed=42), 3) / TB_
+                result["default_model_c20"][name] = {"fwd_us_per_step": ms_i * 1e3, "fwd_cell_updates_per_s": cells / (ms_i * 1e-3),
+                                                     "fwd_frac_f32_mfma": cells * flop20 / (ms_i * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS if name == "f32" else None,
+                                                     "fwd_with_history_us_per_step": ms_f * 1e3, "bwd_us_per_step": ms_w * 1e3,
+                                                     "fwd_bwd_cell_updates_per_s": cells / ((ms_f + ms_w) * 1e-3)}
+                del st_h, pre_h
+            del x20, gl20, cot20
     # ---- training-shaped leg on EVERY rank (the path that contains the gradient all-reduce when N > 1): informational
     train = train_leg(dev, world, args.train_iters) if (args.train_iters > 0 and not args.no_extras) else None
     if rank == 0:
