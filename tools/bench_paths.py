@@ -10,6 +10,7 @@ HIP events on the launch stream).  `python tools/bench_paths.py [names...]`; wit
   dynca_train     DyNCA forward with history + backward (the C driver): C=16/fc=128, C=12/fc=96, C=32/fc=256 at 2x512^2
   big             working sets beyond the 256 MiB Infinity Cache: perception stencil and fused fp32 step at B=64
   video           B = 1 inference at 256^2 with the shipped video models' shapes, single- and two-scale
+  trainer_default ConditionedNCATrainer at the reference's own defaults (C = 20, 64 x 64, batch 8, nca_steps [48, 96]): ms per iteration
   loss            the default objective (VGG16 features + batched OT + content + overflow) at 32 x 3 x 256^2, fp32 / bf16 features
 """
 import json
@@ -192,6 +193,72 @@ def loss_leg():
              miopen_benchmark=bool(torch.backends.cudnn.benchmark), wall_s_so_far=_time.perf_counter() - _t0)
 
 
+def trainer_default_leg():
+    """ConditionedNCATrainer at the reference's OWN defaults (EncoderConditioning/train.py:30-50: default ConditionedNCA = C 20, 64 x 64
+    targets, batch 8, nca_steps [48, 96] drawn per batch, pool 512, lr 2e-3): wall time per trainer iteration (two train_batch calls:
+    grow with history, objective, fused backward, per-tensor normalisation, Adam, pool write-back) with the default objective (OT +
+    content + overflow on seeded-random VGG16 features) and with a stand-in objective, fp32 and bf16 pool; host overhead included."""
+    import tempfile, time, warnings
+    import numpy as np
+    from ncahip.conditioned_trainer import ConditionedNCATrainer, PhaseTimer
+    from ncahip.loss import Loss
+    from ncahip.nca import ConditionedNCA
+    dev = torch.device(DEV)
+    S = 64
+
+    class Targets:
+        target_size = (3, S, S)
+
+        def __init__(self):
+            self.data = torch.rand(16, 3, S, S, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+
+        def __len__(self):
+            return self.data.shape[0]
+
+        def __getitem__(self, idx):
+            return self.data[torch.as_tensor(idx, device=dev)]
+
+    class StandIn(torch.nn.Module):
+        def forward(self, d):
+            s = d["nca_state"].float()
+            return [(d["generated_images"].float() - d["target_images"]).square().mean() + (s - s.clamp(-1.0, 1.0)).abs().mean(), {}]
+
+    style = (np.random.RandomState(0).rand(S, S, 3) * 255).astype(np.uint8)
+    for name, dt, default_obj in (("default objective", torch.float32, True), ("stand-in objective", torch.float32, False),
+                                  ("stand-in objective", torch.bfloat16, False)):
+        torch.manual_seed(0)
+        nca = ConditionedNCA(target_shape=(3, S, S)).to(dev)          # the reference's default arguments: C = 20
+        if default_obj:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                objective = Loss(dev, target_style_image=style, feature_dtype=torch.bfloat16)
+        else:
+            objective = StandIn()
+        tr = ConditionedNCATrainer(nca, Targets(), None, nca_steps=[48, 96], pool_size=512, loss=objective, device=dev,
+                                   log_base_path=tempfile.mkdtemp(prefix="ncahip_bench_"), pool_dtype=dt)
+        for i in range(3):
+            tr._iteration(i, 8)
+        torch.cuda.synchronize()
+        tr.phase_timer = PhaseTimer()
+        times, steps, phases = [], [], []
+        for i in range(12):
+            tr.phase_timer.reset()
+            s0 = nca._mask_step
+            t0 = time.perf_counter()
+            tr._iteration(3 + i, 8)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+            steps.append(nca._mask_step - s0)
+            phases.append(tr.phase_timer.summary())
+        med = statistics.median(times)
+        per_step = statistics.median([t / max(1, n) for t, n in zip(times, steps)])
+        ph = {k: round(float(np.median([p.get(k, 0.0) for p in phases])), 3) for k in sorted({k for p in phases for k in p})}
+        emit(path="trainer_default", objective=name, pool=str(dt).split(".")[-1], C=nca.num_channels, HW=S, batch=8, ms_per_iteration=med * 1e3,
+             nca_steps_per_iteration_median=statistics.median(steps), wall_us_per_nca_step=per_step * 1e6, phase_ms_per_iteration=ph)
+        tr.phase_timer = None
+        del tr, objective
+
+
 def video_leg():
     """B = 1 inference as the video loop issues it (utils/misc/video_utils.py:66-83: forward_nsteps(h, step_n, cond_img=frame) per
     frame) with the shipped video models' shapes (C = 12 / fc = 96 and C = 16 / fc = 128, pos_emb, two-scale perception), 256^2."""
@@ -248,6 +315,8 @@ def main(names):
         loss_leg()
     if allp or "video" in names:
         video_leg()
+    if allp or "trainer_default" in names:
+        trainer_default_leg()
 
 
 if __name__ == "__main__":
