@@ -10,12 +10,15 @@ sys.path[:0] = [ROOT, PKG]
 import bench
 from ncahip import ops
 B, C, H, W, T = 8, 16, 256, 256, 2
+if os.environ.get("NCAHIP_STAMP_SHAPE"):     # e.g. "8,20,64,64": the reference's default training shape (front + matrix kernels)
+    B, C, H, W = [int(v) for v in os.environ["NCAHIP_STAMP_SHAPE"].split(",")]
+    bench.C = C
 dev = "cuda"
 gen = torch.Generator().manual_seed(0)
 prm = bench.make_weights(gen)
 DT = torch.bfloat16 if "bf16" in sys.argv[1:] else torch.float32      # bf16: the bf16-history / bf16-MFMA backward
 x = torch.rand(B, C, H, W, generator=gen).to(dev, DT)
-goal = (torch.randn(B, 12, H, W, generator=gen) * 0.5).to(dev, DT)
+goal = (torch.randn(B, C - 4, H, W, generator=gen) * 0.5).to(dev, DT)
 cot = torch.randn(B, C, H, W, generator=gen).to(dev)
 w = ops.CondWeights(prm["perception_net.weight"], prm["update_net.out.0.weight"], prm["update_net.out.0.bias"],
                     prm["update_net.out.2.weight"], prm["update_net.out.2.bias"], prm["update_net.out.4.weight"], x)
@@ -34,7 +37,7 @@ ops.cond_grow_backward(states, pre, goal, None, w, cot, 1, 3, seed=1) if False e
 e1.record(); torch.cuda.synchronize()
 L.nca_debug_set_stamp_buffer_pc(None)
 k = buf[:NW * 16].cpu().numpy().reshape(NW, 16).astype(np.float64)   # last launch (t = 0) wins
-names = ["loop/tail", "fwd staging", "x'/g loads, z out", "gate", "perception", "fwd recompute", "layer 3", "layer 2",
+names = ["loop/tail", "flush: arrive", "flush: stage 1", "flush: sum 1", "perception", "fwd recompute", "layer 3", "layer 2",
          "layer 1", "dP out", "start-up", "slab flush"]
 tot = k[:, :12].sum(1)
 print("backward of %d steps: %.1f us/step (event, stamps build)" % (T, e0.elapsed_time(e1) * 1e3 / T))

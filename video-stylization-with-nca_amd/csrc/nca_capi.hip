@@ -808,15 +808,9 @@ static int cond_grow_bwd_impl(const void* states_v, int sb, const uint8_t* pre, 
         if (int rc = hip_result(nca_launch_cond_step_bwd(ba, st, bf16), "cond_grow_bwd step")) return rc;
         gcur = ba.g_out;
     }
-    // slabs -> gradients (layout: w1 | w2 | w3 | b1 | b2)
+    // slabs -> one summed slab (tile-major) -> gradients in the reference layouts
     if (int rc = hip_result(nca_launch_reduce_rows(slabs, red, nslab, sf, st), "cond_grow_bwd reduce")) return rc;
-    const size_t o2 = (size_t)hidden * 3 * C, o3 = o2 + (size_t)hidden * hidden, ob1 = o3 + (size_t)C * hidden, ob2 = ob1 + hidden;
-    e = hipMemcpyAsync(g_w1, red, o2 * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(g_w2, red + o2, (size_t)hidden * hidden * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(g_w3, red + o3, (size_t)C * hidden * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(g_b1, red + ob1, hidden * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(g_b2, red + ob2, hidden * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return hip_result(e, "cond grow bwd copy");
+    if (int rc = hip_result(nca_launch_cond_bwd_unpermute(red, C, hidden, bf16, g_w1, g_w2, g_w3, g_b1, g_b2, st), "cond_grow_bwd unpermute")) return rc;
     return hip_result(nca_launch_reduce_wp(wpp, g_wp, B, C, H, W, st), "cond_grow_bwd reduce wp");
 }
 

@@ -728,64 +728,10 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
 #endif
     // ---- weight-gradient partials: the four waves' accumulators are summed through LDS (tiles and weight images are dead
     //      by now) and added to the WORKGROUP's slab with coalesced accesses; fixed summation order (deterministic).
-    const int sf = slab_floats(C, hid);
-    static_assert(kBwdWaves * (64 * 3 * CP + 64 * 64 + CP * 64 + 128) <= K::LDS_FLOATS, "slab staging fits the LDS carve");
-    // the read half of the slab's read-modify-write goes out first: one memory round trip, under the LDS staging below
-    float* const slab = ba.slabs + (size_t)blockIdx.x * sf;
-    constexpr int PER = (64 * 3 * CP + 64 * 64 + CP * 64 + 128 + kBwdThreads - 1) / kBwdThreads;
-    float cur[PER];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int i = tid + kBwdThreads * k;
-        cur[k] = i < sf ? slab[i] : 0.0f;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    float* const sw = smem + wave * sf;
-#pragma unroll
-    for (int ma = 0; ma < 4; ++ma)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = 16 * ma + 4 * g + r;
-            if (o < hid) {
-#pragma unroll
-                for (int nb = 0; nb < K::MJ; ++nb) {
-                    if constexpr (BFM) {   // column 16nb + ci = 12 g' + q, q = 3 c4 + f: channel 4 c4 + g', filter f
-                        const int col = 16 * nb + ci, gp = col / 12, q = col - 12 * gp, j = 3 * (4 * (q / 3) + gp) + q % 3;
-                        if (gp < 4 && q < K::K1S && j < K1) sw[o * K1 + j] = aW1[ma][nb][r];
-                    } else if (16 * nb + ci < K1) sw[o * K1 + 16 * nb + ci] = aW1[ma][nb][r];
-                }
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-                    if (16 * nb + ci < hid) sw[slab_off_w2(C, hid) + o * hid + 16 * nb + ci] = aW2[ma][nb][r];
-            }
-        }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int ch = 4 * g + r;
-        if (ch < C) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-                if (16 * nb + ci < hid) sw[slab_off_w3(C, hid) + ch * hid + 16 * nb + ci] = aW3[nb][r];
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float s1 = row16_sum(db1[m][r]), s2 = row16_sum(db2[m][r]);
-            const int o = 16 * m + 4 * g + r;
-            if (ci == 0 && o < hid) {
-                sw[slab_off_b1(C, hid) + o] = s1;
-                sw[slab_off_b2(C, hid) + o] = s2;
-            }
-        }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int i = tid + kBwdThreads * k;
-        if (i < sf) slab[i] = cur[k] + ((smem[i] + smem[sf + i]) + (smem[2 * sf + i] + smem[3 * sf + i]));
-    }
+    using TM = SlabTM<K::MJ, 1>;
+    static_assert(TM::STAGE <= K::LDS_FLOATS, "slab staging fits the LDS carve");
+    slab_flush_tm<TM, kBwdThreads>(smem, ba.slabs + (size_t)blockIdx.x * TM::SF, tid, lane, wave, true, aW1, aW2,
+                                   reinterpret_cast<const f32x4 (&)[1][4]>(aW3), db1, db2);
 #if defined(NCA_STAMPS)
     NCA_BPHASE(11);  // slab flush
     if (a.dbg && lane == 0) a.dbg[(size_t)(blockIdx.x * kBwdWaves + wave) * 16 + 11] = ph_acc[11];
@@ -985,6 +931,42 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
         dst[j] = accumulate ? dst[j] + v : v;
     }
 }
+// Summed tile-major slab (SlabTM) -> gradients in the reference layouts: w1 [hid, 3C], w2 [hid, hid], w3 [C, hid], b1, b2.  Once per
+// backward pass.  `slot_order`: the bf16-MFMA kernels accumulate dW1 with the perception index in operand-slot order (column
+// 4 KS1 g' + q, q = 3 c4 + f  <->  channel 4 c4 + g', filter f).
+__global__ __launch_bounds__(256) void cond_bwd_unpermute_kernel(const float* __restrict__ red, int C, int cp, int hid, int slot_order,
+                                                                 float* __restrict__ g_w1, float* __restrict__ g_w2, float* __restrict__ g_w3,
+                                                                 float* __restrict__ g_b1, float* __restrict__ g_b2) {
+    const int K1 = 3 * C, mj = slab_mj(cp), m3t = slab_m3t(cp), ks1 = (3 * cp / 4 + 3) / 4;
+    const int s1 = 1024 * mj, n1 = hid * K1, n2 = hid * hid, n3 = C * hid;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    auto tile_at = [&](int base, int tiles_per_row, int row, int col) -> float {   // element (row, col) of a [.][tiles_per_row] tile grid
+        const int ma = row >> 4, g = (row >> 2) & 3, r = row & 3, nb = col >> 4, ci = col & 15;
+        return red[base + ((ma * tiles_per_row + nb) * 64 + g * 16 + ci) * 4 + r];
+    };
+    if (i < n1) {
+        const int o = i / K1, j = i - o * K1;
+        int col = j;
+        if (slot_order) {
+            const int ch = j / 3, f = j - 3 * ch;
+            col = 4 * ks1 * (ch & 3) + 3 * (ch >> 2) + f;
+        }
+        g_w1[i] = tile_at(0, mj, o, col);
+    } else if (i < n1 + n2) {
+        const int e = i - n1, o = e / hid, k = e - o * hid;
+        g_w2[e] = tile_at(s1, 4, o, k);
+    } else if (i < n1 + n2 + n3) {
+        const int e = i - n1 - n2, ch = e / hid, k = e - ch * hid;
+        g_w3[e] = tile_at(s1 + 4096, 4, ch, k);
+    } else if (i < n1 + n2 + n3 + hid) {
+        const int o = i - n1 - n2 - n3;
+        g_b1[o] = red[s1 + 4096 + 1024 * m3t + o];
+    } else if (i < n1 + n2 + n3 + 2 * hid) {
+        const int o = i - n1 - n2 - n3 - hid;
+        g_b2[o] = red[s1 + 4096 + 1024 * m3t + 64 + o];
+    }
+}
+
 // perception-weight partials [B*C*bpp][27] -> grad [C][27]
 __global__ __launch_bounds__(64) void reduce_wp_kernel(const float* __restrict__ part, float* __restrict__ dst, int B, int C, int bpp) {
     const int c = blockIdx.x, i = threadIdx.x;
@@ -1064,7 +1046,9 @@ hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
 
 }  // namespace
 
-int nca_cond_bwd_slab_floats(int C, int hidden) { return slab_floats(C, hidden); }
+// channel padding of the backward kernels' instantiation that serves C channels (nca_cond_bwd_fm.hip: fm_cp)
+static int bwd_cp(int C) { return C <= 12 ? 12 : (C <= 16 ? 16 : (C <= 20 ? 20 : (C <= 24 ? 24 : 32))); }
+int nca_cond_bwd_slab_floats(int C, int hidden) { (void)hidden; return slab_floats_cp(bwd_cp(C)); }
 int nca_cond_bwd_nslab() { return nca_cu_count(); }   // one persistent workgroup (and one slab) per CU
 int nca_cond_bwd_nblk(int B, int C, int H, int W) { return stencil_blocks(B, C, H, W, stencil_srows(B, C, H, W)); }
 
@@ -1101,6 +1085,14 @@ hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st, bo
 
 hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st, bool accumulate) {
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((m + 15) / 16), dim3(256), 0, st, src, dst, n, m, accumulate ? 1 : 0);
+    return hipGetLastError();
+}
+hipError_t nca_launch_cond_bwd_unpermute(const float* red, int C, int hidden, bool bf16_history, float* g_w1, float* g_w2, float* g_w3,
+                                         float* g_b1, float* g_b2, hipStream_t st) {
+    const int n = hidden * 3 * C + hidden * hidden + C * hidden + 2 * hidden;
+    const int slot_order = (bf16_history && !g_bwd_bf16_exact) ? 1 : 0;   // the bf16-MFMA products accumulate dW1 in operand-slot order
+    hipLaunchKernelGGL(cond_bwd_unpermute_kernel, dim3((n + 255) / 256), dim3(256), 0, st, red, C, bwd_cp(C), hidden, slot_order, g_w1, g_w2,
+                       g_w3, g_b1, g_b2);
     return hipGetLastError();
 }
 hipError_t nca_launch_reduce_wp(const float* part, float* dst, int B, int C, int H, int W, hipStream_t st) {

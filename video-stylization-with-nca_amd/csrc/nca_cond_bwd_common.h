@@ -28,12 +28,24 @@ struct BCfg {
     static_assert(CP <= 16, "one 16-row output tile (M3T == 1)");
 };
 
-// slab layout (floats), runtime C / hidden: [w1 hid*3C | w2 hid*hid | w3 C*hid | b1 hid | b2 hid]
-__host__ __device__ inline int slab_off_w2(int C, int hid) { return hid * 3 * C; }
-__host__ __device__ inline int slab_off_w3(int C, int hid) { return slab_off_w2(C, hid) + hid * hid; }
-__host__ __device__ inline int slab_off_b1(int C, int hid) { return slab_off_w3(C, hid) + C * hid; }
-__host__ __device__ inline int slab_off_b2(int C, int hid) { return slab_off_b1(C, hid) + hid; }
-__host__ __device__ inline int slab_floats(int C, int hid) { return slab_off_b2(C, hid) + hid; }
+// Slab layout (floats) of one workgroup's weight-gradient partial -- TILE-MAJOR, i.e. the accumulator registers as they stand:
+//   section 1:  W1 tiles [4 ma][MJ nb][64 lanes][4 r]           lane (g, ci) of tile (ma, nb) holds rows 16 ma + 4 g + r, column 16 nb + ci
+//   section 2:  W2 tiles [4 ma][4 nb][64][4] | W3 tiles [M3T m3][4 nb][64][4] | b1 [64] | b2 [64]
+// The flush writes every accumulator with ONE 16-byte LDS store, sums the four partials and read-modify-writes the slab with 16-byte
+// accesses; nothing in it depends on C / hidden.  (The reference-layout version spent 24 K cycles per launch in scattered 4-byte LDS
+// stores behind per-element index arithmetic and bounds tests -- 14 % of the bf16 matrix kernel.)  The permutation to the reference
+// layouts happens ONCE per backward pass, after the slabs of all workgroups are summed (cond_bwd_unpermute_kernel).
+template <int MJ_, int M3T_>
+struct SlabTM {
+    static constexpr int MJ = MJ_, M3T = M3T_;
+    static constexpr int S1 = 1024 * MJ;
+    static constexpr int OFF_W3 = 4096, OFF_B1 = OFF_W3 + 1024 * M3T, OFF_B2 = OFF_B1 + 64, S2 = OFF_B2 + 64;
+    static constexpr int SF = S1 + S2;
+    static constexpr int STAGE = 4 * (S1 > S2 ? S1 : S2);   // LDS floats the flush needs (four partials of one section)
+};
+__host__ __device__ inline int slab_mj(int cp) { return (3 * cp + 15) / 16; }
+__host__ __device__ inline int slab_m3t(int cp) { return (cp + 15) / 16; }
+__host__ __device__ inline int slab_floats_cp(int cp) { return 1024 * slab_mj(cp) + 4096 + 1024 * slab_m3t(cp) + 128; }
 
 // Operand streaming for one wave per SIMD: with nobody to switch to, an LDS read issued right before its MFMAs costs the
 // whole LDS round trip (and that is where the compiler's scheduler puts it, to save registers).  piped() runs N steps with
@@ -58,6 +70,79 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
     return v;
 }
+// LDS hand-off between the waves of a workgroup that does NOT wait for this wave's outstanding global loads / stores (the compiler's
+// __syncthreads() drains vmcnt as well: at the flush that is the slab prefetch and the last tile's stores, ~6 us of pure latency).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// The flush of one workgroup: `stager` waves (four of them, partial index `part`) hold the accumulators; every thread takes part in
+// the read-modify-write.  Sums in a fixed order (deterministic): slab += (p0 + p1) + (p2 + p3), element by element.
+template <typename TM, int THREADS>
+__device__ __forceinline__ void slab_flush_tm(float* __restrict__ smem, float* __restrict__ slab, int tid, int lane, int part, bool stager,
+                                              const f32x4 (&aW1)[4][TM::MJ], const f32x4 (&aW2)[4][4], const f32x4 (&aW3)[TM::M3T][4],
+                                              const float (&db1)[4][4], const float (&db2)[4][4]) {
+    constexpr int N4 = TM::SF / 4, N41 = TM::S1 / 4, PER4 = (N4 + THREADS - 1) / THREADS;
+    f32x4* const slab4 = reinterpret_cast<f32x4*>(slab);
+    // the read half of the read-modify-write goes out first: one memory round trip, under the LDS staging below
+    f32x4 cur[PER4];
+#pragma unroll
+    for (int k = 0; k < PER4; ++k) {
+        const int i4 = tid + THREADS * k;
+        cur[k] = i4 < N4 ? slab4[i4] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();   // tiles and weight images are dead in every wave
+    if (stager) {
+        float* const s1 = smem + part * TM::S1 + lane * 4;
+#pragma unroll
+        for (int ma = 0; ma < 4; ++ma)
+#pragma unroll
+            for (int nb = 0; nb < TM::MJ; ++nb) st4(s1 + (ma * TM::MJ + nb) * 256, aW1[ma][nb]);
+    }
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < PER4; ++k) {
+        const int i4 = tid + THREADS * k;
+        if (i4 < N41) {
+            const float* const q = smem + 4 * i4;
+            slab4[i4] = cur[k] + ((ld4(q) + ld4(q + TM::S1)) + (ld4(q + 2 * TM::S1) + ld4(q + 3 * TM::S1)));
+        }
+    }
+    lds_barrier();
+    if (stager) {
+        float* const s2 = smem + part * TM::S2;
+#pragma unroll
+        for (int ma = 0; ma < 4; ++ma)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) st4(s2 + ((ma * 4 + nb) * 64 + lane) * 4, aW2[ma][nb]);
+#pragma unroll
+        for (int m3 = 0; m3 < TM::M3T; ++m3)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) st4(s2 + TM::OFF_W3 + ((m3 * 4 + nb) * 64 + lane) * 4, aW3[m3][nb]);
+        const int g = (lane >> 4) & 3, ci = lane & 15;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t1 = row16_sum(db1[m][r]), t2 = row16_sum(db2[m][r]);
+                if (ci == 0) {
+                    s2[TM::OFF_B1 + 16 * m + 4 * g + r] = t1;
+                    s2[TM::OFF_B2 + 16 * m + 4 * g + r] = t2;
+                }
+            }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < PER4; ++k) {
+        const int i4 = tid + THREADS * k;
+        if (i4 >= N41 && i4 < N4) {
+            const float* const q = smem + 4 * (i4 - N41);
+            slab4[i4] = cur[k] + ((ld4(q) + ld4(q + TM::S2)) + (ld4(q + 2 * TM::S2) + ld4(q + 3 * TM::S2)));
+        }
+    }
+}
+
 template <int N, typename LD, typename MM>
 __device__ __forceinline__ void piped(LD&& ld, MM&& mm) {
     auto cur = ld(0);

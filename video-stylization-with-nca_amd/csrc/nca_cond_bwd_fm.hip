@@ -230,10 +230,8 @@ struct MCfg {
     static constexpr int PW = NW == 8 ? 16 * TBH / 2 : PW_F32;   // (NW = 8 is bf16-only: x 144 bf16)
     static constexpr int OFF_DB = SHARED + NW * PW;         // NW = 8: bias-gradient sums, [wave][32 values][64 lanes], accumulated with LDS adds
     static constexpr int DB = NW == 8 ? NW * 32 * 64 : 0;
-    // the flush stages four partial slabs: all of them at once when that fits (CP <= 16), else in two sections (w1 | the rest)
-    static constexpr int SEC1 = 64 * 3 * CP, SEC2 = 64 * 64 + CP * 64 + 128;
-    static constexpr bool SPLIT_FLUSH = kBwdWaves * (SEC1 + SEC2) * 4 > 160 * 1024;
-    static constexpr int SLABS = SPLIT_FLUSH ? kBwdWaves * (SEC1 > SEC2 ? SEC1 : SEC2) : kBwdWaves * (SEC1 + SEC2);
+    // the flush stages four partial slabs in their tile-major form, one section at a time (SlabTM)
+    static constexpr int SLABS = SlabTM<MJ, M3T>::STAGE;
     static constexpr int MERGE = NW == 8 ? 4 * 128 * 64 : 0;   // two waves per SIMD: the pairs' accumulators meet in LDS before the flush
     static constexpr int LDS_A = (SHARED + NW * PW + DB) > SLABS ? (SHARED + NW * PW + DB) : SLABS;
     static constexpr int LDS_FLOATS = LDS_A > MERGE ? LDS_A : MERGE;
@@ -912,19 +910,10 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
 #endif
     // ---- weight-gradient partials: the four waves' accumulators are summed through LDS (tiles and weight images are dead
     //      by now) and added to the WORKGROUP's slab with coalesced accesses; fixed summation order (deterministic).
-    const int sf = slab_floats(C, hid);
-    static_assert(K::SLABS <= K::LDS_FLOATS, "slab staging fits the LDS carve");
-    // the read half of the slab's read-modify-write goes out first: one memory round trip, under the LDS staging below
-    float* const slab = ba.slabs + (size_t)blockIdx.x * sf;
-    constexpr int PER = (64 * 3 * CP + 64 * 64 + CP * 64 + 128 + kThr - 1) / kThr;
-    float cur[PER];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int i = tid + kThr * k;
-        cur[k] = i < sf ? slab[i] : 0.0f;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
+    using TM = SlabTM<K::MJ, K::M3T>;
+    static_assert(TM::STAGE <= K::LDS_FLOATS, "slab staging fits the LDS carve");
+    float* const slab = ba.slabs + (size_t)blockIdx.x * TM::SF;
+    if constexpr (NW == 8) __syncthreads();   // every wave is out of the tile loop: the carve is free for the pair merge
     if constexpr (NW == 8) {
         // the bias sums leave their LDS accumulators (the merge below reuses that part of the carve)
 #pragma unroll
@@ -971,130 +960,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
         }
         __syncthreads();
     }
-    const bool stager = NW == 4 || (wave & 1) == 0;
-    // section 1 = the w1 part of the slab (indices [0, hid * 3C)), section 2 = w2 | w3 | b1 | b2 behind it
-    auto stage_w1 = [&](float* const sw) {
-#pragma unroll
-        for (int ma = 0; ma < 4; ++ma)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 16 * ma + 4 * g + r;
-                if (o < hid) {
-#pragma unroll
-                    for (int nb = 0; nb < K::MJ; ++nb) {
-                        if constexpr (BFM) {   // column 16nb + ci = 4 KS1 g' + q, q = 3 c4 + f: channel 4 c4 + g', filter f
-                            const int col = 16 * nb + ci, gp = col / (4 * KS1), q = col - 4 * KS1 * gp, j = 3 * (4 * (q / 3) + gp) + q % 3;
-                            if (gp < 4 && q < K::K1S && j < K1) sw[o * K1 + j] = aW1[ma][nb][r];
-                        } else if (16 * nb + ci < K1) sw[o * K1 + 16 * nb + ci] = aW1[ma][nb][r];
-                    }
-                }
-            }
-    };
-    auto stage_rest = [&](float* const sw) {   // sw[i] <-> slab index slab_off_w2 + i
-        const int o3 = hid * hid, ob1 = o3 + C * hid, ob2 = ob1 + hid;
-#pragma unroll
-        for (int ma = 0; ma < 4; ++ma)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 16 * ma + 4 * g + r;
-                if (o < hid) {
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
-                        if (16 * nb + ci < hid) sw[o * hid + 16 * nb + ci] = aW2[ma][nb][r];
-                }
-            }
-#pragma unroll
-        for (int m3 = 0; m3 < K::M3T; ++m3)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ch = 16 * m3 + 4 * g + r;
-                if (ch < C) {
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
-                        if (16 * nb + ci < hid) sw[o3 + ch * hid + 16 * nb + ci] = aW3[m3][nb][r];
-                }
-            }
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float s1 = row16_sum(db1[m][r]), s2 = row16_sum(db2[m][r]);
-                const int o = 16 * m + 4 * g + r;
-                if (ci == 0 && o < hid) {
-                    sw[ob1 + o] = s1;
-                    sw[ob2 + o] = s2;
-                }
-            }
-    };
-    if constexpr (!K::SPLIT_FLUSH) {
-        float* const sw = smem + tslot * sf;
-        if (stager) {
-#pragma unroll
-    for (int ma = 0; ma < 4; ++ma)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = 16 * ma + 4 * g + r;
-            if (o < hid) {
-#pragma unroll
-                for (int nb = 0; nb < K::MJ; ++nb) {
-                    if constexpr (BFM) {   // column 16nb + ci = 4 KS1 g' + q, q = 3 c4 + f: channel 4 c4 + g', filter f
-                        const int col = 16 * nb + ci, gp = col / (4 * KS1), q = col - 4 * KS1 * gp, j = 3 * (4 * (q / 3) + gp) + q % 3;
-                        if (gp < 4 && q < K::K1S && j < K1) sw[o * K1 + j] = aW1[ma][nb][r];
-                    } else if (16 * nb + ci < K1) sw[o * K1 + 16 * nb + ci] = aW1[ma][nb][r];
-                }
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-                    if (16 * nb + ci < hid) sw[slab_off_w2(C, hid) + o * hid + 16 * nb + ci] = aW2[ma][nb][r];
-            }
-        }
-#pragma unroll
-    for (int m3 = 0; m3 < K::M3T; ++m3)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int ch = 16 * m3 + 4 * g + r;
-        if (ch < C) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-                if (16 * nb + ci < hid) sw[slab_off_w3(C, hid) + ch * hid + 16 * nb + ci] = aW3[m3][nb][r];
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float s1 = row16_sum(db1[m][r]), s2 = row16_sum(db2[m][r]);
-            const int o = 16 * m + 4 * g + r;
-            if (ci == 0 && o < hid) {
-                sw[slab_off_b1(C, hid) + o] = s1;
-                sw[slab_off_b2(C, hid) + o] = s2;
-            }
-        }
-        }   // stager
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = tid + kThr * k;
-            if (i < sf) slab[i] = cur[k] + ((smem[i] + smem[sf + i]) + (smem[2 * sf + i] + smem[3 * sf + i]));
-        }
-    } else {
-        // wide channel counts: four partial slabs do not fit the LDS at once -- two sections, same sums in the same order
-        const int sec1 = slab_off_w2(C, hid), sec2 = sf - sec1;
-        if (stager) stage_w1(smem + tslot * sec1);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = tid + kThr * k;
-            if (i < sec1) slab[i] = cur[k] + ((smem[i] + smem[sec1 + i]) + (smem[2 * sec1 + i] + smem[3 * sec1 + i]));
-        }
-        __syncthreads();
-        if (stager) stage_rest(smem + tslot * sec2);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = tid + kThr * k, j = i - sec1;
-            if (i >= sec1 && i < sf) slab[i] = cur[k] + ((smem[j] + smem[sec2 + j]) + (smem[2 * sec2 + j] + smem[3 * sec2 + j]));
-        }
-    }
+    slab_flush_tm<TM, kThr>(smem, slab, tid, lane, tslot, NW == 4 || (wave & 1) == 0, aW1, aW2, aW3, db1, db2);
 #if defined(NCA_STAMPS)
     NCA_BPHASE(11);  // slab flush
     if (a.dbg && lane == 0) a.dbg[(size_t)(blockIdx.x * kBwdWaves + wave) * 16 + 11] = ph_acc[11];

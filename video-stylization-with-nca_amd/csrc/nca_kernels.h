@@ -126,7 +126,7 @@ struct NcaCondBwdArgs {
     float* dP;              // scratch: dL/d perception                         [B,3C,H,W]
     float* zbuf;            // scratch: z_t = s_t + goal*pre_t                  [B,C,H,W]
     float* dgoal;           // accumulated over steps                           [B,goal_ch,H,W]
-    float* slabs;           // per-workgroup weight-gradient partials, accumulated   [nslab, slab_floats]
+    float* slabs;           // per-workgroup weight-gradient partials, accumulated   [nslab, nca_cond_bwd_slab_floats] (tile-major: SlabTM)
     float* wp_partials;     // per-block perception-weight partials             [nblk, 27] accumulated
     int nslab, nblk;
     int srows;              // rows per strip of the stencil-adjoint kernel (set by its launcher: nca_cond_bwd_srows)
@@ -135,6 +135,8 @@ struct NcaCondBwdArgs {
     void* doscr;            // front/matrix form: dL/dx'_t * fire mask, [row tile][channel][cell] (nca_cond_bwd_fm_doscr_bytes)
 };
 int nca_cond_bwd_slab_floats(int C, int hidden);
+hipError_t nca_launch_cond_bwd_unpermute(const float* red, int C, int hidden, bool bf16_history, float* g_w1, float* g_w2, float* g_w3,
+                                         float* g_b1, float* g_b2, hipStream_t st);
 int nca_cond_bwd_nslab();
 int nca_cond_bwd_nblk(int B, int C, int H, int W);
 void nca_set_bwd_fm_nosplit(bool on);
