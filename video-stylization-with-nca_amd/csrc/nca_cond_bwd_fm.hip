@@ -913,14 +913,15 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
     using TM = SlabTM<K::MJ, K::M3T>;
     static_assert(TM::STAGE <= K::LDS_FLOATS, "slab staging fits the LDS carve");
     float* const slab = ba.slabs + (size_t)blockIdx.x * TM::SF;
-    if constexpr (NW == 8) __syncthreads();   // every wave is out of the tile loop: the carve is free for the pair merge
+    if constexpr (NW == 8) lds_barrier();   // every wave is out of the tile loop: the carve is free for the pair merge (LDS-only hand-offs:
+                                            // none of these barriers waits for the last tile's global stores)
     if constexpr (NW == 8) {
         // the bias sums leave their LDS accumulators (the merge below reuses that part of the carve)
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { db1[m][r] = DBL[m * 256 + r]; db2[m][r] = DBL[(4 + m) * 256 + r]; }
-        __syncthreads();
+        lds_barrier();
     }
     if constexpr (NW == 8) {
         // the pair's partial sums meet in the even wave: the odd wave parks its accumulators in LDS (16-byte groups, lane-major:
@@ -939,9 +940,9 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
             }
         };
         if (odd) each_acc([&](f32x4& v, int q) { st4(xb + q * 256, v); });
-        __syncthreads();
+        lds_barrier();
         if (!odd) each_acc([&](f32x4& v, int q) { v += ld4(xb + q * 256); });
-        __syncthreads();
+        lds_barrier();
         if (odd) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -949,7 +950,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
                 st4(xb + (4 + m) * 256, f32x4{db2[m][0], db2[m][1], db2[m][2], db2[m][3]});
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (!odd) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -958,7 +959,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
                 for (int r = 0; r < 4; ++r) { db1[m][r] += u[r]; db2[m][r] += v[r]; }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     slab_flush_tm<TM, kThr>(smem, slab, tid, lane, tslot, NW == 4 || (wave & 1) == 0, aW1, aW2, aW3, db1, db2);
 #if defined(NCA_STAMPS)
