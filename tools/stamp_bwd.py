@@ -37,7 +37,8 @@ ops.cond_grow_backward(states, pre, goal, None, w, cot, 1, 3, seed=1) if False e
 e1.record(); torch.cuda.synchronize()
 L.nca_debug_set_stamp_buffer_pc(None)
 k = buf[:NW * 16].cpu().numpy().reshape(NW, 16).astype(np.float64)   # last launch (t = 0) wins
-names = ["loop/tail", "flush: arrive", "flush: stage 1", "flush: sum 1", "perception", "fwd recompute", "layer 3", "layer 2",
+# phases 1-3 belong to the one-launch kernel (the front + matrix form has no staging in its matrix kernel: they read 0 there)
+names = ["loop/tail", "fwd staging", "x'/g loads, z out", "gate", "perception", "fwd recompute", "layer 3", "layer 2",
          "layer 1", "dP out", "start-up", "slab flush"]
 tot = k[:, :12].sum(1)
 print("backward of %d steps: %.1f us/step (event, stamps build)" % (T, e0.elapsed_time(e1) * 1e3 / T))
