@@ -754,12 +754,10 @@ struct Row6 { float v[6]; };   // columns x0-1 .. x0+4
 struct RawRow {
     float4 c;
     float el, er;
-    bool in;
-};
+};   // (whether the row lies inside the image is recomputed from its index at finish time: one register less per row in flight)
 __device__ __forceinline__ RawRow issue_row6(const float* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r) {
     RawRow r;
-    r.in = y >= 0 && y < H;
-    const float* const row = plane + (size_t)(r.in ? y : 0) * W;
+    const float* const row = plane + (size_t)((y >= 0 && y < H) ? y : 0) * W;
     r.c = *reinterpret_cast<const float4*>(row + x0);
     r.el = 0.0f;
     r.er = 0.0f;
@@ -771,8 +769,7 @@ __device__ __forceinline__ RawRow issue_row6(const float* __restrict__ plane, in
 // row issued two rows ahead pays no wait here either: the compiler places the wait at the first shift)
 __device__ __forceinline__ RawRow issue_row6(const uint16_t* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r) {
     RawRow r;
-    r.in = y >= 0 && y < H;
-    const uint16_t* const row = plane + (size_t)(r.in ? y : 0) * W;
+    const uint16_t* const row = plane + (size_t)((y >= 0 && y < H) ? y : 0) * W;
     const u32x2 c = *reinterpret_cast<const u32x2*>(row + x0);
     unsigned el = 0u, er = 0u;
     if (!has_l && x0 > 0) el = row[x0 - 1];
@@ -782,9 +779,9 @@ __device__ __forceinline__ RawRow issue_row6(const uint16_t* __restrict__ plane,
     r.er = __uint_as_float(er << 16);
     return r;
 }
-__device__ __forceinline__ Row6 finish_row6(const RawRow& q, bool has_l, bool has_r) {
+__device__ __forceinline__ Row6 finish_row6(const RawRow& q, bool in, bool has_l, bool has_r) {
     Row6 r;
-    const float z = q.in ? 1.0f : 0.0f;   // rows outside the image read row 0 and are zeroed here
+    const float z = in ? 1.0f : 0.0f;   // rows outside the image read row 0 and are zeroed here
     float l = __shfl_up(q.c.w, 1), rr = __shfl_down(q.c.x, 1);
     if (!has_l) l = q.el;
     if (!has_r) rr = q.er;
@@ -793,12 +790,12 @@ __device__ __forceinline__ Row6 finish_row6(const RawRow& q, bool has_l, bool ha
 }
 template <typename ET>
 __device__ __forceinline__ Row6 load_row6(const ET* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r) {
-    return finish_row6(issue_row6(plane, H, W, y, x0, has_l, has_r), has_l, has_r);
+    return finish_row6(issue_row6(plane, H, W, y, x0, has_l, has_r), y >= 0 && y < H, has_l, has_r);
 }
 
 // ET = element type of the two scratch tensors kernel A wrote (z_t, dL/dperception): float, or uint16_t (bf16) behind the BFM kernel A
 template <typename ET, int SR>
-__global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCondBwdArgs ba) {
+__global__ __launch_bounds__(256, 2) void cond_step_bwd_stencil_kernel(const NcaCondBwdArgs ba) {
     const NcaCondArgs& a = ba.f;
     const int C = a.C, H = a.H, W = a.W;
     const size_t plane = (size_t)H * W;
@@ -821,10 +818,12 @@ __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCon
 #pragma unroll
     for (int i = 0; i < 27; ++i) wsum[i] = 0.f;
     const int gch0 = C - a.goal_ch;
-    // window rows: index 0 = y-1, 1 = y, 2 = y+1; row y+2 (zn / pn) is loaded while row y is computed, so no load
-    // is consumed in the iteration that issues it
+    // window rows: index 0 = y-1, 1 = y, 2 = y+1.  Prefetch depth TWO: the loads of row y+3 are requested in the iteration that
+    // computes row y and enter the window at the end of the NEXT iteration (two register sets, A / B, the loop unrolled by two) -- one
+    // iteration's ~1 K cycles of arithmetic do not cover a memory round trip, and with a single set every iteration waited for its own
+    // request.  The row's own read-modify-write operands (dL/dx', dL/dgoal, pre mask) are requested one row ahead (a full iteration in flight).
     Row6 zw[3], pw[3][3];
-    RawRow zn, pn[3];
+    RawRow znA, pnA[3], znB, pnB[3];
     zw[0] = load_row6(zb, H, W, y0 - 1, x0, has_l, has_r);
     zw[1] = load_row6(zb, H, W, y0, x0, has_l, has_r);
     zw[2] = load_row6(zb, H, W, y0 + 1, x0, has_l, has_r);
@@ -834,30 +833,34 @@ __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCon
         pw[f][1] = load_row6(p0 + (size_t)f * plane, H, W, y0, x0, has_l, has_r);
         pw[f][2] = load_row6(p0 + (size_t)f * plane, H, W, y0 + 1, x0, has_l, has_r);
     }
-    // the row's own read-modify-write operands (dL/dx', dL/dgoal, pre mask) are requested one row ahead as well
     const bool goal_ch = c >= gch0, use_pre = goal_ch && a.alive_ch >= 0;
     const float* const gxp = ba.gx + ((size_t)b * C + c) * plane + x0;
     float* const gop = ba.g_out + ((size_t)b * C + c) * plane + x0;
     float* const dgp = goal_ch ? ba.dgoal + ((size_t)b * a.goal_ch + (c - gch0)) * plane + x0 : nullptr;
     const uint8_t* const prp = use_pre ? ba.pre_t + (size_t)b * plane + x0 : nullptr;
-    float4 gxn = make_float4(0.f, 0.f, 0.f, 0.f), dgn = gxn;
-    uchar4 pbn = make_uchar4(1, 1, 1, 1);
-    auto issue_rmw = [&](int y) {
+    struct Rmw { float4 gx, dg; uchar4 pb; };
+    Rmw rn{make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_uchar4(1, 1, 1, 1)};
+    auto issue_rmw = [&](Rmw& r, int y) {
         const size_t ro = (size_t)min(y, H - 1) * W;
-        gxn = *reinterpret_cast<const float4*>(gxp + ro);
-        if (goal_ch) dgn = *reinterpret_cast<const float4*>(dgp + ro);
-        if (use_pre) pbn = *reinterpret_cast<const uchar4*>(prp + ro);
+        r.gx = *reinterpret_cast<const float4*>(gxp + ro);
+        if (goal_ch) r.dg = *reinterpret_cast<const float4*>(dgp + ro);
+        if (use_pre) r.pb = *reinterpret_cast<const uchar4*>(prp + ro);
     };
-    issue_rmw(y0);
-#pragma unroll 1
-    for (int k = 0; k < SR; ++k) {
-        const int y = y0 + k;
-        zn = issue_row6(zb, H, W, y + 2, x0, has_l, has_r);
+    auto issue_rows = [&](RawRow& zi, RawRow (&pi)[3], int y) {
+        zi = issue_row6(zb, H, W, y, x0, has_l, has_r);
 #pragma unroll
-        for (int f = 0; f < 3; ++f) pn[f] = issue_row6(p0 + (size_t)f * plane, H, W, y + 2, x0, has_l, has_r);
-        const float4 gx = gxn, dgc = dgn;
-        const uchar4 pb = pbn;
-        issue_rmw(y + 1);
+        for (int f = 0; f < 3; ++f) pi[f] = issue_row6(p0 + (size_t)f * plane, H, W, y, x0, has_l, has_r);
+    };
+    issue_rows(znA, pnA, y0 + 2);
+    issue_rmw(rn, y0);
+    // one row: request row y+3 into (zi, pi) and the read-modify-write operands of row y+1 (after taking this row's), compute row y,
+    // then move the rows requested an iteration ago (zf, pf) into the window
+    auto row = [&](int k, RawRow& zi, RawRow (&pi)[3], const RawRow& zf, const RawRow (&pf)[3]) {
+        const int y = y0 + k;
+        if (k + 3 <= SR) issue_rows(zi, pi, y + 3);        // rows up to y0 + SR are needed (the halo below the strip)
+        const float4 gx = rn.gx, dgc = rn.dg;
+        const uchar4 pb = rn.pb;
+        if (k + 1 < SR) issue_rmw(rn, y + 1);
         if (active && y < H) {
             // dz[x] = sum_f sum_{ty,tx} Wp[f][ty][tx] * dP[f][y-(ty-1)][x-(tx-1)]      (transpose of the zero-padded correlation)
             float dz[4] = {0.f, 0.f, 0.f, 0.f};
@@ -888,9 +891,16 @@ __global__ __launch_bounds__(256) void cond_step_bwd_stencil_kernel(const NcaCon
                 *reinterpret_cast<float4*>(dgp + ro) = o;
             }
         }
-        zw[0] = zw[1]; zw[1] = zw[2]; zw[2] = finish_row6(zn, has_l, has_r);
+        const bool in2 = y + 2 >= 0 && y + 2 < H;          // (zf, pf) hold row y + 2
+        zw[0] = zw[1]; zw[1] = zw[2]; zw[2] = finish_row6(zf, in2, has_l, has_r);
 #pragma unroll
-        for (int f = 0; f < 3; ++f) { pw[f][0] = pw[f][1]; pw[f][1] = pw[f][2]; pw[f][2] = finish_row6(pn[f], has_l, has_r); }
+        for (int f = 0; f < 3; ++f) { pw[f][0] = pw[f][1]; pw[f][1] = pw[f][2]; pw[f][2] = finish_row6(pf[f], in2, has_l, has_r); }
+    };
+    static_assert(SR % 2 == 0, "the row loop is unrolled by two (register sets A / B)");
+#pragma unroll 1
+    for (int k = 0; k < SR; k += 2) {
+        row(k, znB, pnB, znA, pnA);
+        row(k + 1, znA, pnA, znB, pnB);
     }
     // block reduction of the 27 partial sums, fixed order (deterministic)
     __shared__ float red[4][27];
