@@ -24,16 +24,16 @@ w = ops.CondWeights(prm["perception_net.weight"], prm["update_net.out.0.weight"]
                     prm["update_net.out.2.weight"], prm["update_net.out.2.bias"], prm["update_net.out.4.weight"], x)
 L = ops.lib()
 L.nca_debug_set_stamp_buffer_pc.argtypes = [ctypes.c_void_p]
-out, states, pre = ops.cond_grow(x, T, goal, None, w, 3, seed=1, keep_history=True)
+out, states, pre = ops.cond_grow(x, T, goal, None, w, 3, seed=int(os.environ.get("NCAHIP_STAMP_SEED", "1")), keep_history=True)
 for _ in range(2):
-    ops.cond_grow_backward(states, pre, goal, None, w, cot, T, 3, seed=1)
+    ops.cond_grow_backward(states, pre, goal, None, w, cot, T, 3, seed=int(os.environ.get("NCAHIP_STAMP_SEED", "1")))
 torch.cuda.synchronize()
 NW = 256 * 4
 buf = torch.zeros(NW * 16 + 4096 * 64, dtype=torch.int64, device=dev)
 L.nca_debug_set_stamp_buffer_pc(buf.data_ptr())
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-ops.cond_grow_backward(states, pre, goal, None, w, cot, 1, 3, seed=1) if False else ops.cond_grow_backward(states, pre, goal, None, w, cot, T, 3, seed=1)
+ops.cond_grow_backward(states, pre, goal, None, w, cot, 1, 3, seed=int(os.environ.get("NCAHIP_STAMP_SEED", "1"))) if False else ops.cond_grow_backward(states, pre, goal, None, w, cot, T, 3, seed=int(os.environ.get("NCAHIP_STAMP_SEED", "1")))
 e1.record(); torch.cuda.synchronize()
 L.nca_debug_set_stamp_buffer_pc(None)
 k = buf[:NW * 16].cpu().numpy().reshape(NW, 16).astype(np.float64)   # last launch (t = 0) wins

@@ -742,7 +742,7 @@ size_t ncahip_cond_grow_bwd_workspace(int B, int C, int H, int W, int hidden) {
     return 4 * align256(n) + align256(3 * n) +
            align256((size_t)(nca_cond_bwd_nslab() + 1) * nca_cond_bwd_slab_floats(C, hidden) * sizeof(float)) +
            align256((size_t)nca_cond_bwd_nblk(B, C, H, W) * 27 * sizeof(float)) +
-           align256(nca_cond_bwd_fm_pscr_bytes(B, C, H, W)) + align256(nca_cond_bwd_fm_doscr_bytes(B, C, H, W));
+           align256(nca_cond_bwd_fm_pscr_bytes(B, C, H, W)) + align256(nca_cond_bwd_fm_doscr_bytes(B, C, H, W)) + align256(kNcaCondBwdOpimgBytes);
 }
 
 // states / goal: fp32 or bf16 (sb = bytes per element); everything else fp32
@@ -785,13 +785,14 @@ static int cond_grow_bwd_impl(const void* states_v, int sb, const uint8_t* pre, 
     p += align256((size_t)(nslab + 1) * sf * sizeof(float));
     float* wpp = (float*)p; p += align256((size_t)nblk * 27 * sizeof(float));
     void* pscr = p; p += align256(nca_cond_bwd_fm_pscr_bytes(B, C, H, W));   // front kernel -> matrix kernel scratch (operand order)
-    void* doscr = p;
+    void* doscr = p; p += align256(nca_cond_bwd_fm_doscr_bytes(B, C, H, W));
+    float* opimg = (float*)p;   // the matrix kernel's operand image, built once per call (the weights do not change between the steps)
     hipError_t e = hipMemsetAsync(slabs, 0, (size_t)nslab * sf * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(wpp, 0, (size_t)nblk * 27 * sizeof(float), st);
     if (e == hipSuccess && goal_ch > 0) e = hipMemsetAsync(g_goal, 0, (size_t)B * goal_ch * H * W * sizeof(float), st);
     if (e != hipSuccess) return hip_result(e, "cond grow bwd memset");
     const float* gcur = g_final;
-    for (int t = T - 1; t >= 0; --t) {
+    auto step_args = [&](int t, const float* g_in) {
         NcaCondBwdArgs ba{};
         ba.f = NcaCondArgs{reinterpret_cast<const float*>(states + (size_t)t * slot * sb), t == 0 ? nullptr : pre + (size_t)t * pslot,
                            nullptr, nullptr, reinterpret_cast<const float*>(goal_v),
@@ -800,11 +801,28 @@ static int cond_grow_bwd_impl(const void* states_v, int sb, const uint8_t* pre, 
         ba.f.u_bits = ubits;
         ba.x_next = reinterpret_cast<const float*>(states + (size_t)(t + 1) * slot * sb);
         ba.pre_t = pre + (size_t)(t + 1) * pslot;
-        ba.g_next = gcur;
+        ba.g_next = g_in;
         ba.g_out = t == 0 ? g_x0 : gbuf[t & 1];
         ba.gx = gx; ba.dP = dP; ba.zbuf = zbuf; ba.dgoal = g_goal; ba.slabs = slabs; ba.wp_partials = wpp;
         ba.nslab = nslab; ba.nblk = nblk;
         ba.pscr = pscr; ba.doscr = doscr;
+        ba.opimg = opimg;
+        return ba;
+    };
+    // The weights do not change between the steps: in the front + matrix form ONE workgroup builds the matrix kernel's operand image
+    // (opmode 1, no tile work) and the T step launches copy it (opmode 2) instead of gathering it again each (~6 us per launch).
+    int opmode = 0;
+    if (T >= 2) {
+        NcaCondBwdArgs pa = step_args(T - 1, gcur);
+        if (nca_cond_bwd_is_fm(pa, bf16)) {
+            pa.opmode = 1;
+            if (int rc = hip_result(nca_launch_cond_step_bwd(pa, st, bf16), "cond_grow_bwd operand image")) return rc;
+            opmode = 2;
+        }
+    }
+    for (int t = T - 1; t >= 0; --t) {
+        NcaCondBwdArgs ba = step_args(t, gcur);
+        ba.opmode = opmode;
         if (int rc = hip_result(nca_launch_cond_step_bwd(ba, st, bf16), "cond_grow_bwd step")) return rc;
         gcur = ba.g_out;
     }

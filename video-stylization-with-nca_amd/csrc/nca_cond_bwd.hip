@@ -1019,6 +1019,13 @@ hipError_t launch_stencil(const NcaCondBwdArgs& ba_in, hipStream_t st, bool bf16
                                                                                          : go(cond_step_bwd_stencil_kernel<float, 4>);
 }
 
+// C <= 16: which form of kernel A runs (launch_bwd below)
+bool narrow_is_fm(const NcaCondBwdArgs& ba, bool bfm) {
+    const int nst_ = ba.f.B * ((ba.f.W + 15) / 16) * ((ba.f.H + 15) / 16);
+    const bool default_fm = bfm || 2 * nst_ <= ba.nslab;
+    return ba.pscr && ba.doscr && (g_bwd_variant == 2 || (g_bwd_variant == 0 && default_fm) || (g_bwd_variant == 3 && !default_fm));
+}
+
 template <int CP, typename ST, bool BFM = false>
 hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
     // Kernel A exists in two forms with the same results (the products run in the same per-wave order): ONE launch, everything
@@ -1027,13 +1034,12 @@ hipError_t launch_bwd(const NcaCondBwdArgs& ba, hipStream_t st) {
     // hook (ncahip_debug_force_generic bit 3) swaps them so that the parity suite checks both.
     // Small grids (fewer super-tiles than half the CUs): the matrix kernel splits each super-tile over two workgroups, which the one-launch
     // form cannot -- front + matrix is then the faster form for fp32 products as well (64 x 64, batch 8, C = 16: 53 -> ~40 us per step).
-    const int nst_ = ba.f.B * ((ba.f.W + 15) / 16) * ((ba.f.H + 15) / 16);
-    const bool default_fm = BFM || 2 * nst_ <= ba.nslab;
-    const bool fm = ba.pscr && ba.doscr && (g_bwd_variant == 2 || (g_bwd_variant == 0 && default_fm) || (g_bwd_variant == 3 && !default_fm));
+    const bool fm = narrow_is_fm(ba, BFM);
     if (fm) {
         if (hipError_t e = nca_launch_cond_step_bwd_fm(ba, st, BFM ? 2 : (ST::BYTES == 2 ? 1 : 0)); e != hipSuccess) return e;
-        return launch_stencil(ba, st, BFM);
+        return ba.opmode == 1 ? hipSuccess : launch_stencil(ba, st, BFM);
     }
+    if (ba.opmode == 1) return hipSuccess;   // the one-launch form builds its images itself: nothing to export
     using K = BCfg<CP>;
     auto kern = cond_step_bwd_kernel<CP, ST, BFM>;
     const size_t lds = (size_t)K::LDS_FLOATS * sizeof(float);
@@ -1079,7 +1085,7 @@ hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st, bo
                               // SIMD); with the exact hook: exact-f32 products of the widened history, as the fp32 form
             if (!ba.pscr || !ba.doscr) return hipErrorInvalidValue;
             if (hipError_t e = nca_launch_cond_step_bwd_fm(ba, st, g_bwd_bf16_exact ? 1 : 2); e != hipSuccess) return e;
-            return launch_stencil(ba, st, !g_bwd_bf16_exact);
+            return ba.opmode == 1 ? hipSuccess : launch_stencil(ba, st, !g_bwd_bf16_exact);
         }
         return hipErrorInvalidValue;
     }
@@ -1088,9 +1094,14 @@ hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& ba, hipStream_t st, bo
     if (ba.f.C <= 32) {   // 16 < C <= 32 (the reference's default model is C = 20, nca.py:62-94): front + matrix kernels only
         if (!ba.pscr || !ba.doscr) return hipErrorInvalidValue;
         if (hipError_t e = nca_launch_cond_step_bwd_fm(ba, st, 0); e != hipSuccess) return e;
-        return launch_stencil(ba, st, false);
+        return ba.opmode == 1 ? hipSuccess : launch_stencil(ba, st, false);
     }
     return hipErrorInvalidValue;
+}
+
+bool nca_cond_bwd_is_fm(const NcaCondBwdArgs& ba, bool bf16) {
+    if (ba.f.C > 16) return true;                                   // wide channel counts: front + matrix kernels only
+    return narrow_is_fm(ba, bf16 && !g_bwd_bf16_exact);
 }
 
 hipError_t nca_launch_reduce_rows(const float* src, float* dst, int n, int m, hipStream_t st, bool accumulate) {

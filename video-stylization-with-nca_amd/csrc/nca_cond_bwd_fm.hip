@@ -290,7 +290,16 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
         const int h1 = 16 * (s >> 2) + 4 * (l >> 4) + (s & 3), j = 16 * mj + (l & 15);
         return (h1 < hid && j < K1) ? (long)h1 * K1 + j : -1;
     };
-    {
+    // ba.opmode == 2: the image (operands + biases) was built once for this backward pass (a one-workgroup launch with opmode == 1) and
+    // is copied from memory with 16-byte loads; the gathers below cost ~13 K cycles per launch (6 us of a 70 us kernel)
+    constexpr int IMG = BFM ? FK::OFF_B2 + FK::HID : K::SHARED;   // floats of LDS the prologue fills
+    static_assert(IMG % 4 == 0 && IMG * 4 <= (int)kNcaCondBwdOpimgBytes, "operand image fits its workspace slot");
+    const bool import_img = ba.opmode == 2;
+    if (import_img) {
+        for (int i = 4 * tid; i < IMG; i += 4 * kThr) st4(smem + i, ld4(ba.opimg + i));
+        __syncthreads();
+    }
+    if (!import_img) {
         FillRegs<FK::HID, kThr> fr2;
         FillRegs<FK::HID, kThr> fr3;
         fill_load(fr2, a.b1, tid, [&](int idx) -> long { return idx < hid ? idx : -1; });
@@ -313,7 +322,9 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
         fill_store(fr2, smem + FK::OFF_B1, tid);
         fill_store(fr3, smem + FK::OFF_B2, tid);
     }
-    if constexpr (!BFM) __syncthreads();
+    if constexpr (!BFM) {
+        if (!import_img) __syncthreads();
+    }
 
     const float* const W1L = smem + FK::OFF_W1;
     const float* const W2L = smem + FK::OFF_W2;
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
     constexpr int OP_W1 = 0, OP_W2 = OP_W1 + 4 * KS1, OP_W3T = OP_W2 + 16, OP_W2T = OP_W3T + 4 * K::M3T, OP_W1T = OP_W2T + 16, OP_N = OP_W1T + 4 * K::MJ;
     static_assert(OP_N * 64 * 2 <= FK::OFF_B1, "bf16 operand image fits below the bias vectors");
     const bf_s16x4* const BW = reinterpret_cast<const bf_s16x4*>(smem) + lane;      // operand o of this lane: BW[o * 64]
-    if constexpr (BFM) {
+    if constexpr (BFM) if (!import_img) {
         constexpr int NOP = (OP_N + NW - 1) / NW;    // this wave's share of the operands (round robin)
         float raw[NOP][4];
         const int w2t_lane0 = (ci & 3) * 64 + (ci >> 2) * 16 + 4 * g;
@@ -373,6 +384,10 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
             if (o < OP_N) *(reinterpret_cast<bf_s16x4*>(smem) + o * 64 + lane) = pack4(raw[k][0], raw[k][1], raw[k][2], raw[k][3]);
         }
         __syncthreads();
+    }
+    if (ba.opmode == 1) {   // export launch: the image is complete (barriers above) -- write it out, no tile work
+        for (int i = 4 * tid; i < IMG; i += 4 * kThr) st4(ba.opimg + i, ld4(smem + i));
+        return;
     }
     // persistent weight-gradient accumulators (D = A * B^T with the cell axis as K)
     f32x4 aW1[4][K::MJ], aW2[4][4], aW3[K::M3T][4];
@@ -977,7 +992,7 @@ hipError_t launch_fm(const NcaCondBwdArgs& ba_in, hipStream_t st) {
     ba.f.err = nca_error_word_device();
     const NcaCondArgs& a = ba.f;
     const int nst = a.B * ((a.W + 15) / 16) * ((a.H + 15) / 16);
-    {
+    if (ba.opmode != 1) {
         using KF = FrontCfg<CP>;
         const size_t lds = (size_t)KF::LDS_FLOATS * sizeof(float);
         auto go = [&](auto kern, NcaLdsAttr& attr) -> hipError_t {
@@ -998,7 +1013,7 @@ hipError_t launch_fm(const NcaCondBwdArgs& ba_in, hipStream_t st) {
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
     ba.msplit = (!g_fm_nosplit && 2 * nst <= ba.nslab) ? 1 : 0;           // small grids: (super-tile, pass) items
     const int items = nst << ba.msplit;
-    const int grid = items < ba.nslab ? items : ba.nslab;               // one slab per workgroup
+    const int grid = ba.opmode == 1 ? 1 : (items < ba.nslab ? items : ba.nslab);   // one slab per workgroup (export launch: one workgroup)
 #if defined(NCA_STAMPS)
     ba.f.dbg = nca_debug_stamp_ptr();
 #endif

@@ -130,6 +130,9 @@ struct NcaCondBwdArgs {
     float* wp_partials;     // per-block perception-weight partials             [nblk, 27] accumulated
     int nslab, nblk;
     int srows;              // rows per strip of the stencil-adjoint kernel (set by its launcher: nca_cond_bwd_srows)
+    float* opimg;           // matrix kernel: its LDS operand image kept in memory across the steps of one backward pass (workspace), see opmode
+    int opmode;             // 0 = every launch gathers the image from the weight tensors; 1 = ONE workgroup builds it and writes it to opimg
+                            // (no tile work); 2 = the launch copies it from opimg (16-byte loads instead of ~100 scattered 4-byte gathers per thread)
     int msplit;             // matrix kernel: 1 = a workgroup takes ONE pass (half the rows) of a super-tile per walk item (small grids: twice the workgroups)
     void* pscr;             // front/matrix form: perception vectors in MFMA-operand order  (nca_cond_bwd_fm_pscr_bytes)
     void* doscr;            // front/matrix form: dL/dx'_t * fire mask, [row tile][channel][cell] (nca_cond_bwd_fm_doscr_bytes)
@@ -140,6 +143,8 @@ hipError_t nca_launch_cond_bwd_unpermute(const float* red, int C, int hidden, bo
 int nca_cond_bwd_nslab();
 int nca_cond_bwd_nblk(int B, int C, int H, int W);
 void nca_set_bwd_fm_nosplit(bool on);
+bool nca_cond_bwd_is_fm(const NcaCondBwdArgs& ba, bool bf16);   // the form nca_launch_cond_step_bwd will run for these arguments
+constexpr size_t kNcaCondBwdOpimgBytes = 128 * 1024;            // upper bound of the matrix kernel's operand image (CP = 32: 100 KB)
 hipError_t nca_launch_cond_step_bwd(const NcaCondBwdArgs& a, hipStream_t st, bool bf16 = false);   // bf16: f.x_in / x_next / f.goal hold bf16
 // kernel A as two launches (nca_cond_bwd_fm.hip); mode 0 = f32 history, 1 = bf16 history / exact-f32 products, 2 = bf16 MFMA
 hipError_t nca_launch_cond_step_bwd_fm(const NcaCondBwdArgs& a, hipStream_t st, int mode);
