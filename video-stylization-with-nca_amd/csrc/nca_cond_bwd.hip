@@ -729,9 +729,9 @@ __global__ __launch_bounds__(kBwdThreads, 1) void cond_step_bwd_kernel(const Nca
     // ---- weight-gradient partials: the four waves' accumulators are summed through LDS (tiles and weight images are dead
     //      by now) and added to the WORKGROUP's slab with coalesced accesses; fixed summation order (deterministic).
     using TM = SlabTM<K::MJ, 1>;
-    static_assert(TM::STAGE <= K::LDS_FLOATS, "slab staging fits the LDS carve");
-    slab_flush_tm<TM, kBwdThreads>(smem, ba.slabs + (size_t)blockIdx.x * TM::SF, tid, lane, wave, true, aW1, aW2,
-                                   reinterpret_cast<const f32x4 (&)[1][4]>(aW3), db1, db2);
+    static_assert(TM::stage(4) <= K::LDS_FLOATS, "slab staging fits the LDS carve");
+    slab_flush_tm<TM, kBwdThreads, 4>(smem, ba.slabs + (size_t)blockIdx.x * TM::SF, tid, lane, wave, aW1, aW2,
+                                      reinterpret_cast<const f32x4 (&)[1][4]>(aW3), db1, db2);
 #if defined(NCA_STAMPS)
     NCA_BPHASE(11);  // slab flush
     if (a.dbg && lane == 0) a.dbg[(size_t)(blockIdx.x * kBwdWaves + wave) * 16 + 11] = ph_acc[11];

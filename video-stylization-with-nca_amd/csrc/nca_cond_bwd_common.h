@@ -41,7 +41,8 @@ struct SlabTM {
     static constexpr int S1 = 1024 * MJ;
     static constexpr int OFF_W3 = 4096, OFF_B1 = OFF_W3 + 1024 * M3T, OFF_B2 = OFF_B1 + 64, S2 = OFF_B2 + 64;
     static constexpr int SF = S1 + S2;
-    static constexpr int STAGE = 4 * (S1 > S2 ? S1 : S2);   // LDS floats the flush needs (four partials of one section)
+    static constexpr int SECMAX = S1 > 4096 ? S1 : 4096;     // largest of the three flush sections (W1 | W2 | W3 + biases)
+    static constexpr int stage(int np) { return np * SECMAX; }   // LDS floats the flush needs (np partials of one section)
 };
 __host__ __device__ inline int slab_mj(int cp) { return (3 * cp + 15) / 16; }
 __host__ __device__ inline int slab_m3t(int cp) { return (cp + 15) / 16; }
@@ -76,13 +77,17 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// The flush of one workgroup: `stager` waves (four of them, partial index `part`) hold the accumulators; every thread takes part in
-// the read-modify-write.  Sums in a fixed order (deterministic): slab += (p0 + p1) + (p2 + p3), element by element.
-template <typename TM, int THREADS>
-__device__ __forceinline__ void slab_flush_tm(float* __restrict__ smem, float* __restrict__ slab, int tid, int lane, int part, bool stager,
+// The flush of one workgroup: NP waves hold partial accumulators (NP = 4: one wave per SIMD; NP = 8: two waves per SIMD, waves 2p and
+// 2p + 1 share a tile); wave `part` stages its registers, every thread takes part in the read-modify-write.  Three sections (W1 | W2 |
+// W3 + biases) so that NP partials of a section fit the LDS.  Sums in a fixed order (deterministic), element by element:
+// slab += (p0 + p1) + (p2 + p3)   [+ ((p4 + p5) + (p6 + p7)) as the second operand of the outer sum for NP = 8: the pair sums first].
+template <typename TM, int THREADS, int NP>
+__device__ __forceinline__ void slab_flush_tm(float* __restrict__ smem, float* __restrict__ slab, int tid, int lane, int part,
                                               const f32x4 (&aW1)[4][TM::MJ], const f32x4 (&aW2)[4][4], const f32x4 (&aW3)[TM::M3T][4],
                                               const float (&db1)[4][4], const float (&db2)[4][4]) {
-    constexpr int N4 = TM::SF / 4, N41 = TM::S1 / 4, PER4 = (N4 + THREADS - 1) / THREADS;
+    static_assert(NP == 4 || NP == 8, "partials per workgroup");
+    constexpr int N4 = TM::SF / 4, PER4 = (N4 + THREADS - 1) / THREADS;
+    constexpr int SEC_OFF[3] = {0, TM::S1, TM::S1 + 4096}, SEC_LEN[3] = {TM::S1, 4096, TM::S2 - 4096};
     f32x4* const slab4 = reinterpret_cast<f32x4*>(slab);
     // the read half of the read-modify-write goes out first: one memory round trip, under the LDS staging below
     f32x4 cur[PER4];
@@ -92,53 +97,49 @@ __device__ __forceinline__ void slab_flush_tm(float* __restrict__ smem, float* _
         cur[k] = i4 < N4 ? slab4[i4] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __builtin_amdgcn_sched_barrier(0);
-    lds_barrier();   // tiles and weight images are dead in every wave
-    if (stager) {
-        float* const s1 = smem + part * TM::S1 + lane * 4;
 #pragma unroll
-        for (int ma = 0; ma < 4; ++ma)
+    for (int sec = 0; sec < 3; ++sec) {
+        constexpr int dummy = 0; (void)dummy;
+        const int LEN = SEC_LEN[sec], OFF = SEC_OFF[sec];
+        lds_barrier();   // first section: tiles and weight images are dead in every wave; later: the previous section has been summed
+        float* const sp = smem + part * LEN;
+        if (sec == 0) {
 #pragma unroll
-            for (int nb = 0; nb < TM::MJ; ++nb) st4(s1 + (ma * TM::MJ + nb) * 256, aW1[ma][nb]);
-    }
-    lds_barrier();
+            for (int ma = 0; ma < 4; ++ma)
 #pragma unroll
-    for (int k = 0; k < PER4; ++k) {
-        const int i4 = tid + THREADS * k;
-        if (i4 < N41) {
-            const float* const q = smem + 4 * i4;
-            slab4[i4] = cur[k] + ((ld4(q) + ld4(q + TM::S1)) + (ld4(q + 2 * TM::S1) + ld4(q + 3 * TM::S1)));
-        }
-    }
-    lds_barrier();
-    if (stager) {
-        float* const s2 = smem + part * TM::S2;
+                for (int nb = 0; nb < TM::MJ; ++nb) st4(sp + ((ma * TM::MJ + nb) * 64 + lane) * 4, aW1[ma][nb]);
+        } else if (sec == 1) {
 #pragma unroll
-        for (int ma = 0; ma < 4; ++ma)
+            for (int ma = 0; ma < 4; ++ma)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) st4(s2 + ((ma * 4 + nb) * 64 + lane) * 4, aW2[ma][nb]);
+                for (int nb = 0; nb < 4; ++nb) st4(sp + ((ma * 4 + nb) * 64 + lane) * 4, aW2[ma][nb]);
+        } else {
 #pragma unroll
-        for (int m3 = 0; m3 < TM::M3T; ++m3)
+            for (int m3 = 0; m3 < TM::M3T; ++m3)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) st4(s2 + TM::OFF_W3 + ((m3 * 4 + nb) * 64 + lane) * 4, aW3[m3][nb]);
-        const int g = (lane >> 4) & 3, ci = lane & 15;
+                for (int nb = 0; nb < 4; ++nb) st4(sp + ((m3 * 4 + nb) * 64 + lane) * 4, aW3[m3][nb]);
+            const int g = (lane >> 4) & 3, ci = lane & 15;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float t1 = row16_sum(db1[m][r]), t2 = row16_sum(db2[m][r]);
-                if (ci == 0) {
-                    s2[TM::OFF_B1 + 16 * m + 4 * g + r] = t1;
-                    s2[TM::OFF_B2 + 16 * m + 4 * g + r] = t2;
+                for (int r = 0; r < 4; ++r) {
+                    const float t1 = row16_sum(db1[m][r]), t2 = row16_sum(db2[m][r]);
+                    if (ci == 0) {
+                        sp[1024 * TM::M3T + 16 * m + 4 * g + r] = t1;
+                        sp[1024 * TM::M3T + 64 + 16 * m + 4 * g + r] = t2;
+                    }
                 }
-            }
-    }
-    lds_barrier();
+        }
+        lds_barrier();
 #pragma unroll
-    for (int k = 0; k < PER4; ++k) {
-        const int i4 = tid + THREADS * k;
-        if (i4 >= N41 && i4 < N4) {
-            const float* const q = smem + 4 * (i4 - N41);
-            slab4[i4] = cur[k] + ((ld4(q) + ld4(q + TM::S2)) + (ld4(q + 2 * TM::S2) + ld4(q + 3 * TM::S2)));
+        for (int k = 0; k < PER4; ++k) {
+            const int i4 = tid + THREADS * k, j4 = i4 - OFF / 4;
+            if (j4 >= 0 && j4 < LEN / 4) {
+                const float* const q = smem + 4 * j4;
+                f32x4 v = (ld4(q) + ld4(q + LEN)) + (ld4(q + 2 * LEN) + ld4(q + 3 * LEN));
+                if constexpr (NP == 8) v = v + ((ld4(q + 4 * LEN) + ld4(q + 5 * LEN)) + (ld4(q + 6 * LEN) + ld4(q + 7 * LEN)));
+                slab4[i4] = cur[k] + v;
+            }
         }
     }
 }

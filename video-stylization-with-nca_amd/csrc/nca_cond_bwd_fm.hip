@@ -231,8 +231,8 @@ struct MCfg {
     static constexpr int OFF_DB = SHARED + NW * PW;         // NW = 8: bias-gradient sums, [wave][32 values][64 lanes], accumulated with LDS adds
     static constexpr int DB = NW == 8 ? NW * 32 * 64 : 0;
     // the flush stages four partial slabs in their tile-major form, one section at a time (SlabTM)
-    static constexpr int SLABS = SlabTM<MJ, M3T>::STAGE;
-    static constexpr int MERGE = NW == 8 ? 4 * 128 * 64 : 0;   // two waves per SIMD: the pairs' accumulators meet in LDS before the flush
+    static constexpr int SLABS = SlabTM<MJ, M3T>::stage(NW);
+    static constexpr int MERGE = 0;   // (the pairs' accumulators meet in the flush's sum: no separate merge)
     static constexpr int LDS_A = (SHARED + NW * PW + DB) > SLABS ? (SHARED + NW * PW + DB) : SLABS;
     static constexpr int LDS_FLOATS = LDS_A > MERGE ? LDS_A : MERGE;
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
@@ -926,57 +926,19 @@ __global__ __launch_bounds__(64 * NW, 1) void cond_step_bwd_mlp_kernel(const Nca
     // ---- weight-gradient partials: the four waves' accumulators are summed through LDS (tiles and weight images are dead
     //      by now) and added to the WORKGROUP's slab with coalesced accesses; fixed summation order (deterministic).
     using TM = SlabTM<K::MJ, K::M3T>;
-    static_assert(TM::STAGE <= K::LDS_FLOATS, "slab staging fits the LDS carve");
+    static_assert(TM::stage(NW) <= K::LDS_FLOATS, "slab staging fits the LDS carve");
     float* const slab = ba.slabs + (size_t)blockIdx.x * TM::SF;
-    if constexpr (NW == 8) lds_barrier();   // every wave is out of the tile loop: the carve is free for the pair merge (LDS-only hand-offs:
-                                            // none of these barriers waits for the last tile's global stores)
     if constexpr (NW == 8) {
-        // the bias sums leave their LDS accumulators (the merge below reuses that part of the carve)
+        // the bias sums leave their LDS accumulators (lane-private addresses: no barrier needed before, the flush's first barrier
+        // separates these reads from the staging that reuses the carve).  The two waves of a tile are partials 2p and 2p + 1: the flush
+        // adds them first (the association the pair merge through LDS had, which this replaces: 44 16-byte stores + loads per lane and
+        // five workgroup barriers per launch).
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { db1[m][r] = DBL[m * 256 + r]; db2[m][r] = DBL[(4 + m) * 256 + r]; }
-        lds_barrier();
     }
-    if constexpr (NW == 8) {
-        // the pair's partial sums meet in the even wave: the odd wave parks its accumulators in LDS (16-byte groups, lane-major:
-        // conflict-free), the even wave adds them; then the bias sums the same way.  Fixed order: deterministic.
-        float* const xb = smem + (size_t)(wave >> 1) * (128 * 64) + lane * 4;
-        const bool odd = (wave & 1) != 0;
-        auto each_acc = [&](auto&& f) {
-            int q = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int j = 0; j < K::MJ; ++j) f(aW1[i][j], q++);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) f(aW2[i][j], q++);
-                f(aW3[0][i], q++);
-            }
-        };
-        if (odd) each_acc([&](f32x4& v, int q) { st4(xb + q * 256, v); });
-        lds_barrier();
-        if (!odd) each_acc([&](f32x4& v, int q) { v += ld4(xb + q * 256); });
-        lds_barrier();
-        if (odd) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                st4(xb + m * 256, f32x4{db1[m][0], db1[m][1], db1[m][2], db1[m][3]});
-                st4(xb + (4 + m) * 256, f32x4{db2[m][0], db2[m][1], db2[m][2], db2[m][3]});
-            }
-        }
-        lds_barrier();
-        if (!odd) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const f32x4 u = ld4(xb + m * 256), v = ld4(xb + (4 + m) * 256);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { db1[m][r] += u[r]; db2[m][r] += v[r]; }
-            }
-        }
-        lds_barrier();
-    }
-    slab_flush_tm<TM, kThr>(smem, slab, tid, lane, tslot, NW == 4 || (wave & 1) == 0, aW1, aW2, aW3, db1, db2);
+    slab_flush_tm<TM, kThr, NW>(smem, slab, tid, lane, wave, aW1, aW2, aW3, db1, db2);
 #if defined(NCA_STAMPS)
     NCA_BPHASE(11);  // slab flush
     if (a.dbg && lane == 0) a.dbg[(size_t)(blockIdx.x * kBwdWaves + wave) * 16 + 11] = ph_acc[11];
