@@ -57,15 +57,14 @@ __global__ __launch_bounds__(kFrontThreads, FrontCfg<CP>::OCC) void cond_step_bw
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C = a.C, H = a.H, W = a.W;
     const unsigned plane = (unsigned)(H * W);
-    {
-        FillRegs<CP * FK::WPS, kFrontThreads> fr;
-        fill_load(fr, a.wp, tid, [&](int idx) -> long {
-            const int ch = idx / FK::WPS, j = idx % FK::WPS;
-            return (ch < C && j < 27) ? (long)ch * 27 + j : -1;
-        });
-        fill_store(fr, smem + K::OFF_WP, tid);
-    }
-    __syncthreads();
+    // The perception taps are needed last (after staging, gate and the z / dO outputs): their gather is REQUESTED here, ahead of the tile's
+    // own loads, and lands in LDS (with the workgroup barrier) right before the perception -- the kernel used to wait for this round trip
+    // and a barrier before it requested anything of its tile.
+    FillRegs<CP * FK::WPS, kFrontThreads> frwp;
+    fill_load(frwp, a.wp, tid, [&](int idx) -> long {
+        const int ch = idx / FK::WPS, j = idx % FK::WPS;
+        return (ch < C && j < 27) ? (long)ch * 27 + j : -1;
+    });
     const float* const WS = smem + K::OFF_WP - FK::OFF_WP;
     float* const PWR = smem + wave * K::PW;
     float* const Z = PWR + K::PW_Z;
@@ -77,14 +76,17 @@ __global__ __launch_bounds__(kFrontThreads, FrontCfg<CP>::OCC) void cond_step_bw
     // super-tile of this workgroup: consecutive super-tiles go to the same XCD (workgroups are dealt round-robin over 8 XCDs)
     const int st_x = (W + 15) / 16, st_y = (H + 15) / 16, nst = a.B * st_x * st_y;
     const int chunk = (nst + 7) / 8, sidx = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= chunk || sidx >= nst) return;
+    if ((int)(blockIdx.x >> 3) >= chunk || sidx >= nst) return;   // (whole workgroup)
     const int halo = a.alive_ch >= 0 ? 3 : 1;
     const bool use_alive = a.alive_ch >= 0;
     WTile t;
     t.b = sidx / (st_x * st_y);
     t.ty0 = ((sidx / st_x) % st_y) * 16 + wave * WTH;
     t.tx0 = (sidx % st_x) * 16;
-    if (t.ty0 >= H || t.tx0 >= W) return;
+    if (t.ty0 >= H || t.tx0 >= W) {   // this wave's rows lie below the image: it still delivers its share of the taps (a finished wave does
+        fill_store(frwp, smem + K::OFF_WP, tid);   // not count at the barrier the others wait at)
+        return;
+    }
     t.valid = true;
     t.inner = t.ty0 >= halo && t.ty0 + WTH + halo <= H && t.tx0 >= halo && t.tx0 + WTW + halo <= W;
     const int ty0 = t.ty0, tx0 = t.tx0;
@@ -179,6 +181,8 @@ __global__ __launch_bounds__(kFrontThreads, FrontCfg<CP>::OCC) void cond_step_bw
         }
     }
     // ---- perception of the four rows, stored as the B operands kernel M will load
+    fill_store(frwp, smem + K::OFF_WP, tid);
+    __syncthreads();
 #pragma unroll 1
     for (int n0 = 0; n0 < WTH; n0 += 2) {
         float P[2][FK::K1S];
