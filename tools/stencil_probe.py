@@ -1,5 +1,6 @@
-"""Times the standalone DyNCA perception stencil (one variant per process: NCAHIP_STENCIL_VARIANT is read once) and prints a
-checksum of its output so variants can be compared bit for bit.  usage: python tools/stencil_probe.py [B ...]"""
+"""Times the standalone DyNCA perception stencil on buffers that stay resident (same input / output every launch: the warm, cache-assisted
+figure; the cold one is `tools/bench_paths.py big`) and prints a checksum of its output, so that two builds of the library can be compared
+bit for bit (NCAHIP_LIB selects the build).  usage: python tools/stencil_probe.py [B ...]"""
 import hashlib, json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "video-stylization-with-nca_amd"))
 import torch
@@ -25,5 +26,5 @@ for B in [int(a) for a in sys.argv[1:]] or [8, 64]:
         ms = sorted(ts)[len(ts) // 2]
         gbs = B * H * W * 20 * C / (ms * 1e-3) / 1e9
         h = hashlib.sha1(y.cpu().numpy().tobytes()).hexdigest()[:12]
-        print(json.dumps({"variant": os.environ.get("NCAHIP_STENCIL_VARIANT", "0"), "B": B, "C": C, "H": H, "W": W, "pad": pad,
+        print(json.dumps({"lib": os.path.basename(os.environ.get("NCAHIP_LIB", "libncahip.so")), "B": B, "C": C, "H": H, "W": W, "pad": pad,
                           "us": round(ms * 1e3, 2), "GBs": round(gbs, 1), "frac": round(gbs / 8000, 3), "sha": h}))
